@@ -1,0 +1,87 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the ECoG->text hot path.
+// wave = 64 lanes; bf16 operands, fp32 accumulate (MFMA 16x16x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;        // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;         // MFMA 16x16 accumulator
+
+#define E2T_WAVE 64
+
+// fp32 -> bf16, round-to-nearest-even (bit-identical to oracle/bf16.py:round_bf16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
+    float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (bit-identical to oracle/philox.py).  Element e of a dropped
+// tensor uses counter (e>>2, stream) and output lane e&3; key = 64-bit seed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct DropCfg {
+    float rate;                  // 0 => disabled
+    unsigned long long seed;     // base seed; effective seed = seed + *step (if step != null)
+    const int* step;             // device step counter (graph-replay safe) or null
+    unsigned stream;             // tensor id
+};
+
+// returns the multiplicative scale for logical element `idx`: 0 or 1/(1-rate)
+__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
+    if (d.rate <= 0.0f) return 1.0f;
+    unsigned long long seed = d.seed + (d.step ? (unsigned long long)(*d.step) : 0ull);
+    unsigned long long ctr = idx >> 2;
+    unsigned r[4];
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), d.stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+    unsigned v = r[idx & 3ull] >> 8;
+    unsigned thresh = (unsigned)(d.rate * 16777216.0f);
+    return v >= thresh ? 1.0f / (1.0f - d.rate) : 0.0f;
+}
+
+// wave-level reductions (64 lanes) via shuffles
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// host-side status plumbing -------------------------------------------------
+#define E2T_OK 0
+#define E2T_ERR_ARG 1
+#define E2T_ERR_HIP 2
+
+int e2t_set_error(const char* fmt, ...);
+#define E2T_CHECK_ARG(cond)                                                             \
+    do { if (!(cond)) return e2t_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond) , E2T_ERR_ARG; } while (0)
+#define E2T_LAUNCH_CHECK()                                                              \
+    do { hipError_t e_ = hipGetLastError();                                             \
+         if (e_ != hipSuccess) { e2t_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return E2T_ERR_HIP; } \
+    } while (0)

@@ -1,0 +1,467 @@
+// HBM-bound / small kernels around the matmuls of the ECoG->text hot path:
+// length extraction, time reversal + decimation gathers, conv im2row packing,
+// transposes, weight packing, embedding, softmax cross-entropy, squared-error
+// head, Adam+EMA.  Reference rows: a4, a5, a6, a8, a9, a10.
+#include "common.h"
+#include "ecog2txt_hip.h"
+
+// ---------------------------------------------------------------------------
+// a4: valid length of a zero-padded batch = number of non-zero rows
+// (nn.sequences_tools usage at ecog2txt/trainers.py:789-790, 806-807).
+// One workgroup per utterance, one wave per time row, 16-B coalesced loads.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seq_lengths_f32(const float* x, int T, int C, int div, int* lens, int* lens_div) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (size_t)b * T * C;
+    int cnt = 0;
+    for (int t = wave; t < T; t += 4) {
+        const float* row = xb + (size_t)t * C;
+        bool nz = false;
+        if ((C & 3) == 0) {
+            for (int c = lane * 4; c < C; c += 256) {
+                float4 v = *(const float4*)(row + c);
+                nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+            }
+        } else {
+            for (int c = lane; c < C; c += 64) nz |= row[c] != 0.f;
+        }
+        if (__any(nz)) cnt++;            // wave-uniform
+    }
+    __shared__ int sc[4];
+    if (lane == 0) sc[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = sc[0] + sc[1] + sc[2] + sc[3];
+        lens[b] = n;
+        if (lens_div) lens_div[b] = (n + div - 1) / div;
+    }
+}
+
+__global__ void k_seq_lengths_i32(const int* x, int B, int L, int pad, int div, int* lens, int* lens_div) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    for (int l = 0; l < L; ++l) n += x[(size_t)b * L + l] != pad;
+    lens[b] = n;
+    if (lens_div) lens_div[b] = (n + div - 1) / div;
+}
+
+// out[0] = sum_b x[b]   (single block, deterministic)
+__global__ __launch_bounds__(256) void k_sum_i32(const int* x, int n, int* out) {
+    __shared__ int sh[256];
+    int acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// out[slot] = scale * sum_i x[i] / max(*count,1)  (single block, fixed order => deterministic)
+__global__ __launch_bounds__(256) void k_sum_f32(const float* x, int n, const int* count, float scale, float* out) {
+    __shared__ float sh[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float d = count ? (float)max(*count, 1) : 1.f;
+        out[0] = scale * sh[0] / d;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a5 + a6 staging: A[(t',b)][(w,c)] = bf16( Xrev[b][t'*N + w][c] ), where Xrev
+// is tf.reverse_sequence over the valid length (trainers.py:808-810) and the
+// ragged tail is zero-padded.  Every source row is one contiguous C*4-byte
+// read; every destination row one contiguous N*C*2-byte write.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_pack(const float* x, const int* lens, int B, int T, int C, int N,
+                                                    int S, bf16_t* A, int lda) {
+    const int m = blockIdx.x;               // (t', b) time-major
+    const int tp = m / B, b = m % B;
+    const int len = lens[b];
+    bf16_t* arow = A + (size_t)m * lda;
+    const int K = N * C;
+    if ((C & 3) == 0) {
+        for (int k4 = threadIdx.x * 4; k4 < lda; k4 += 1024) {
+            ushort4 o = make_ushort4(0, 0, 0, 0);
+            if (k4 < K) {
+                const int w = k4 / C, c = k4 - w * C;
+                const int tt = tp * N + w;
+                if (tt < len) {
+                    float4 v = *(const float4*)(x + ((size_t)b * T + (len - 1 - tt)) * C + c);
+                    o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+                }
+            }
+            *(ushort4*)(arow + k4) = o;
+        }
+    } else {
+        for (int k = threadIdx.x; k < lda; k += 256) {
+            bf16_t o = 0;
+            if (k < K) {
+                const int w = k / C, c = k - w * C;
+                const int tt = tp * N + w;
+                if (tt < len) o = f2bf(x[((size_t)b * T + (len - 1 - tt)) * C + c]);
+            }
+            arow[k] = o;
+        }
+    }
+}
+
+// scatter of d(loss)/dA back to the batch-major, un-reversed input (a12 saliency)
+__global__ __launch_bounds__(256) void k_conv_unpack_grad(const float* dA, int ldda, const int* lens, int B, int T, int C,
+                                                           int N, int S, float* dx) {
+    const int bt = blockIdx.x;              // (b, t) batch-major destination row
+    const int b = bt / T, t = bt % T;
+    const int len = lens[b];
+    float* drow = dx + (size_t)bt * C;
+    if (t >= len) { for (int c = threadIdx.x; c < C; c += 256) drow[c] = 0.f; return; }
+    const int tt = len - 1 - t;             // reversed time
+    const int tp = tt / N, w = tt - tp * N;
+    const float* src = dA + ((size_t)tp * B + b) * ldda + (size_t)w * C;
+    for (int c = threadIdx.x; c < C; c += 256) drow[c] = src[c];
+}
+
+// time-major, reversed, every-N-th-sample gather of encoder targets
+// (trainers.py:791-795: reverse_sequence then [:, 0::N, :])
+__global__ void k_gather_rev_decim_f32(const float* a, const int* tlens, int B, int T, int Kf, int N, int S, float* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)S * B * Kf) return;
+    const int k = i % Kf; const size_t m = i / Kf;
+    const int b = m % B, tp = m / B;
+    const int len = tlens[b], tt = tp * N;
+    out[i] = tt < len ? a[((size_t)b * T + (len - 1 - tt)) * Kf + k] : 0.f;
+}
+__global__ void k_gather_rev_decim_i32(const int* a, const int* tlens, int B, int T, int N, int S, int* out) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= (size_t)S * B) return;
+    const int b = m % B, tp = m / B;
+    const int len = tlens[b], tt = tp * N;
+    out[m] = tt < len ? a[(size_t)b * T + (len - 1 - tt)] : 0;
+}
+
+// decoder inputs/targets, time-major: U[l][b] = l==0 ? <EOS> : Y[b][l-1];  Tg[l][b] = Y[b][l]
+__global__ void k_decoder_tokens(const int* y, int B, int L, int eos, int* U, int* Tg) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= L * B) return;
+    const int b = m % B, l = m / B;
+    U[m] = l == 0 ? eos : y[(size_t)b * L + l - 1];
+    Tg[m] = y[(size_t)b * L + l];
+}
+
+// ---------------------------------------------------------------------------
+// bf16 transpose through LDS: out[c][r] = in[r][c], r < R, c < Ccols; columns
+// R..ld_out-1 of every written output row are zero-filled (K padding for the GEMM).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* in, int ld_in, int R, int Ccols, bf16_t* out, int ld_out) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Ccols) ? in[(size_t)r * ld_in + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Ccols && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing (fp32 master -> bf16 operand images), run after every Adam step
+// ---------------------------------------------------------------------------
+// dst[r][c] = bf16(src[r*sr + c*sc]) for r<R, c<C
+__global__ void k_cast_pack(const float* src, long sr, long sc, int R, int C, bf16_t* dst, int ld_dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c < C && r < R) dst[(size_t)r * ld_dst + c] = f2bf(src[(size_t)r * sr + (size_t)c * sc]);
+}
+// MFMA B-fragment image of the logical matrix Bn[n][k] = src[n*sn + k*sk]  (n < Nn, k < Kk):
+// dst[(nt*KB + kb)*64 + lane][j] = Bn[nt*16 + (lane&15)][kb*32 + (lane>>4)*8 + j]   (0 outside)
+__global__ __launch_bounds__(64) void k_pack_frag(const float* src, long sn, long sk, int Nn, int Kk, int KB, bf16_t* dst) {
+    const int nt = blockIdx.y, kb = blockIdx.x, lane = threadIdx.x;
+    const int n = nt * 16 + (lane & 15);
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kb * 32 + (lane >> 4) * 8 + j;
+        o[j] = (n < Nn && k < Kk) ? f2bf(src[(size_t)n * sn + (size_t)k * sk]) : (bf16_t)0;
+    }
+    uint4 v;
+    v.x = o[0] | ((unsigned)o[1] << 16); v.y = o[2] | ((unsigned)o[3] << 16);
+    v.z = o[4] | ((unsigned)o[5] << 16); v.w = o[6] | ((unsigned)o[7] << 16);
+    ((uint4*)dst)[((size_t)nt * KB + kb) * 64 + lane] = v;
+}
+
+// ---------------------------------------------------------------------------
+// a9: decoder embedding gather (+FF dropout) and its scatter-add gradient
+// ---------------------------------------------------------------------------
+__global__ void k_embed_fwd(const bf16_t* emb, int ld_emb, const int* tok, int M, int E, bf16_t* out, int ld_out, DropCfg drop,
+                            int row0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * E) return;
+    const int e = i % E; const size_t m = i / E + row0;
+    float v = bf2f(emb[(size_t)tok[m] * ld_emb + e]);
+    v *= drop_scale(drop, (unsigned long long)(m * E + e));
+    out[m * ld_out + e] = f2bf(v);
+}
+__global__ void k_embed_bwd(const float* de, int ld_de, const int* tok, int M, int E, float* demb, int ld_demb, DropCfg drop) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * E) return;
+    const int e = i % E; const size_t m = i / E;
+    float g = de[m * ld_de + e] * drop_scale(drop, (unsigned long long)(m * E + e));
+    if (g != 0.f) atomicAdd(demb + (size_t)tok[m] * ld_demb + e, g);
+}
+
+// ---------------------------------------------------------------------------
+// a9: masked softmax cross-entropy over the vocabulary, one wave per row, all
+// reductions by wavefront shuffles.  Emits per-row loss, arg-max, and the bf16
+// gradient dlogits = (softmax - onehot) * w / ntok for valid rows, 0 otherwise.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_softmax_ce(const float* logits, int ldl, int M, int V, const int* tgt, const int* lens,
+                                                     int rowsB, const int* ntok, float w, float* rowloss, int* pred,
+                                                     float* correct, bf16_t* dl, int lddl) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* row = logits + (size_t)m * ldl;
+    const bool valid = lens ? ((m / rowsB) < lens[m % rowsB]) : true;
+    float mx = -INFINITY; int arg = 0;
+    for (int v = lane; v < V; v += 64) { float x = row[v]; if (x > mx) { mx = x; arg = v; } }
+    // wave arg-max with lowest-index tie-break (matches numpy argmax)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float omx = __shfl_xor(mx, o, 64); int oarg = __shfl_xor(arg, o, 64);
+        if (omx > mx || (omx == mx && oarg < arg)) { mx = omx; arg = oarg; }
+    }
+    float se = 0.f;
+    for (int v = lane; v < V; v += 64) se += __expf(row[v] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    const int t = tgt ? tgt[m] : 0;
+    if (lane == 0) {
+        if (rowloss) rowloss[m] = (valid && tgt) ? (lse - row[t]) : 0.f;
+        if (pred) pred[m] = arg;
+        if (correct) correct[m] = (valid && tgt && arg == t) ? 1.f : 0.f;
+    }
+    if (dl) {
+        const float sc = valid ? w / (float)max(ntok ? *ntok : 1, 1) : 0.f;
+        bf16_t* drow = dl + (size_t)m * lddl;
+        for (int v = lane; v < V; v += 64) {
+            float pr = __expf(row[v] - lse);
+            drow[v] = f2bf((pr - (v == t ? 1.f : 0.f)) * sc);
+        }
+    }
+}
+
+// a8 Gaussian head: rowloss[m] = sum_k (P - A)^2 on valid rows; dP = 2 (P - A) w / (nval K)
+__global__ void k_mse(const float* P, int ldp, const float* At, int M, int Kf, const int* lens, int rowsB, const int* nval,
+                      float w, float* rowloss, bf16_t* dP, int lddp) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const bool valid = (m / rowsB) < lens[m % rowsB];
+    const float sc = valid ? 2.f * w / ((float)max(*nval, 1) * Kf) : 0.f;
+    float acc = 0.f;
+    for (int k = 0; k < Kf; ++k) {
+        const float d = valid ? (P[(size_t)m * ldp + k] - At[(size_t)m * Kf + k]) : 0.f;
+        acc += d * d;
+        if (dP) dP[(size_t)m * lddp + k] = f2bf(d * sc);
+    }
+    rowloss[m] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// encoder -> decoder seam: final (c,h) of the last encoder layer at each
+// utterance's own last valid step (plotters.py:1388)
+// ---------------------------------------------------------------------------
+__global__ void k_final_state(const bf16_t* Yext, int ldy, const float* Cs, const int* lens, int B, int H, int H8,
+                              bf16_t* h0, int ldh0, float* c0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * H) return;
+    const int b = i / (2 * H), r = i % (2 * H), d = r / H, u = r % H;
+    const int len = lens[b];
+    bf16_t h = 0; float c = 0.f;
+    if (len > 0) {
+        const int t = d ? 0 : len - 1;
+        h = Yext[((size_t)(t + 1) * B + b) * ldy + d * H8 + u];
+        c = Cs[((size_t)t * B + b) * (2 * H) + d * H + u];
+    }
+    h0[(size_t)b * ldh0 + r] = h;
+    c0[(size_t)b * 2 * H + r] = c;
+}
+
+// greedy decoding bookkeeping (beam_width 1): record token, latch <EOS>, feed next input
+__global__ void k_greedy_update(const int* pred, int B, int l, int Lmax, int eos, int pad, int* done, int* out, int* next_tok) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int tok = pred[b];
+    const int dn = done[b];
+    out[(size_t)b * Lmax + l] = dn ? pad : tok;
+    done[b] = dn | (tok == eos);
+    if (next_tok) next_tok[b] = tok;
+}
+
+// ---------------------------------------------------------------------------
+// a10: fused Adam (TF1 AdamOptimizer form) + EMA shadow over a flat fp32 range
+// ---------------------------------------------------------------------------
+__global__ void k_inc_step(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+
+__global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n,
+                                                   const int* step, float lr, float b1, float b2, float eps, float decay,
+                                                   float gscale) {
+    const float t = (float)(*step);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        ema[i] = decay * ema[i] + (1.f - decay) * pi;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C ABI wrappers
+// ---------------------------------------------------------------------------
+#define ST ((hipStream_t)stream)
+
+extern "C" int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream) {
+    E2T_CHECK_ARG(x && lens && B > 0 && T > 0 && C > 0 && div > 0);
+    hipLaunchKernelGGL(k_seq_lengths_f32, dim3(B), dim3(256), 0, ST, x, T, C, div, lens, lens_div);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int div, int32_t* lens, int32_t* lens_div, void* stream) {
+    E2T_CHECK_ARG(x && lens && B > 0 && L > 0 && div > 0);
+    hipLaunchKernelGGL(k_seq_lengths_i32, dim3((B + 63) / 64), dim3(64), 0, ST, x, B, L, pad, div, lens, lens_div);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_sum_i32(const int32_t* x, int n, int32_t* out, void* stream) {
+    E2T_CHECK_ARG(x && out && n > 0);
+    hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(256), 0, ST, x, n, out);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float* out, void* stream) {
+    E2T_CHECK_ARG(x && out && n > 0);
+    hipLaunchKernelGGL(k_sum_f32, dim3(1), dim3(256), 0, ST, x, n, count, scale, out);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_conv_pack(const float* x, const int32_t* lens, int B, int T, int C, int N, void* A, int lda, void* stream) {
+    E2T_CHECK_ARG(x && lens && A && B > 0 && T > 0 && C > 0 && N > 0);
+    E2T_CHECK_ARG(lda % 8 == 0 && lda >= N * C);
+    const int S = (T + N - 1) / N;
+    hipLaunchKernelGGL(k_conv_pack, dim3(S * B), dim3(256), 0, ST, x, lens, B, T, C, N, S, (bf16_t*)A, lda);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_conv_unpack_grad(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, float* dx, void* stream) {
+    E2T_CHECK_ARG(dA && lens && dx && B > 0 && T > 0 && C > 0 && N > 0 && ldda >= N * C);
+    const int S = (T + N - 1) / N;
+    hipLaunchKernelGGL(k_conv_unpack_grad, dim3(B * T), dim3(256), 0, ST, dA, ldda, lens, B, T, C, N, S, dx);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_gather_rev_decim_f32(const float* a, const int32_t* tlens, int B, int T, int K, int N, float* out, void* stream) {
+    E2T_CHECK_ARG(a && tlens && out && B > 0 && T > 0 && K > 0 && N > 0);
+    const int S = (T + N - 1) / N;
+    const size_t n = (size_t)S * B * K;
+    hipLaunchKernelGGL(k_gather_rev_decim_f32, dim3((n + 255) / 256), dim3(256), 0, ST, a, tlens, B, T, K, N, S, out);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_gather_rev_decim_i32(const int32_t* a, const int32_t* tlens, int B, int T, int N, int32_t* out, void* stream) {
+    E2T_CHECK_ARG(a && tlens && out && B > 0 && T > 0 && N > 0);
+    const int S = (T + N - 1) / N;
+    const size_t n = (size_t)S * B;
+    hipLaunchKernelGGL(k_gather_rev_decim_i32, dim3((n + 255) / 256), dim3(256), 0, ST, a, tlens, B, T, N, S, out);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_decoder_tokens(const int32_t* y, int B, int L, int eos, int32_t* U, int32_t* Tg, void* stream) {
+    E2T_CHECK_ARG(y && U && Tg && B > 0 && L > 0);
+    hipLaunchKernelGGL(k_decoder_tokens, dim3((B * L + 255) / 256), dim3(256), 0, ST, y, B, L, eos, U, Tg);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream) {
+    E2T_CHECK_ARG(in && out && R > 0 && C > 0 && ld_in >= C && ld_out >= R);
+    hipLaunchKernelGGL(k_transpose_bf16, dim3((ld_out + 63) / 64, (C + 63) / 64), dim3(256), 0, ST, (const bf16_t*)in, ld_in, R, C,
+                       (bf16_t*)out, ld_out);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_cast_pack(const float* src, long row_stride, long col_stride, int R, int C, void* dst, int ld_dst, void* stream) {
+    E2T_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_dst >= C);
+    hipLaunchKernelGGL(k_cast_pack, dim3((C + 255) / 256, R), dim3(256), 0, ST, src, row_stride, col_stride, R, C, (bf16_t*)dst, ld_dst);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_pack_frag(const float* src, long n_stride, long k_stride, int Nn, int Kk, void* dst, void* stream) {
+    E2T_CHECK_ARG(src && dst && Nn > 0 && Kk > 0);
+    const int NT = (Nn + 15) / 16, KB = (Kk + 31) / 32;
+    hipLaunchKernelGGL(k_pack_frag, dim3(KB, NT), dim3(64), 0, ST, src, n_stride, k_stride, Nn, Kk, KB, (bf16_t*)dst);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+static DropCfg mk_drop(const e2t_dropout* d) {
+    DropCfg c{}; if (d) { c.rate = d->rate; c.seed = d->seed; c.step = d->step; c.stream = d->stream; } return c;
+}
+extern "C" int e2t_embed_fwd(const void* emb, int ld_emb, const int32_t* tok, int row0, int M, int E, void* out, int ld_out,
+                             const e2t_dropout* drop, void* stream) {
+    E2T_CHECK_ARG(emb && tok && out && M > 0 && E > 0 && row0 >= 0);
+    const size_t n = (size_t)M * E;
+    hipLaunchKernelGGL(k_embed_fwd, dim3((n + 255) / 256), dim3(256), 0, ST, (const bf16_t*)emb, ld_emb, tok, M, E, (bf16_t*)out, ld_out,
+                       mk_drop(drop), row0);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_embed_bwd(const float* de, int ld_de, const int32_t* tok, int M, int E, float* demb, int ld_demb,
+                             const e2t_dropout* drop, void* stream) {
+    E2T_CHECK_ARG(de && tok && demb && M > 0 && E > 0);
+    const size_t n = (size_t)M * E;
+    hipLaunchKernelGGL(k_embed_bwd, dim3((n + 255) / 256), dim3(256), 0, ST, de, ld_de, tok, M, E, demb, ld_demb, mk_drop(drop));
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_softmax_ce(const float* logits, int ldl, int M, int V, const int32_t* tgt, const int32_t* lens, int rows_per_step,
+                              const int32_t* ntok, float weight, float* rowloss, int32_t* pred, float* correct, void* dlogits,
+                              int lddl, void* stream) {
+    E2T_CHECK_ARG(logits && M > 0 && V > 0 && ldl >= V);
+    E2T_CHECK_ARG(!dlogits || (tgt && lddl >= V));
+    hipLaunchKernelGGL(k_softmax_ce, dim3((M + 3) / 4), dim3(256), 0, ST, logits, ldl, M, V, tgt, lens,
+                       rows_per_step > 0 ? rows_per_step : 1, ntok, weight, rowloss, pred, correct, (bf16_t*)dlogits, lddl);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_mse(const float* P, int ldp, const float* At, int M, int K, const int32_t* lens, int rows_per_step,
+                       const int32_t* nval, float weight, float* rowloss, void* dP, int lddp, void* stream) {
+    E2T_CHECK_ARG(P && At && lens && nval && rowloss && M > 0 && K > 0 && rows_per_step > 0);
+    hipLaunchKernelGGL(k_mse, dim3((M + 255) / 256), dim3(256), 0, ST, P, ldp, At, M, K, lens, rows_per_step, nval, weight, rowloss,
+                       (bf16_t*)dP, lddp);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_final_state(const void* Yext, int ldy, const float* Cs, const int32_t* lens, int B, int H, void* h0, int ldh0,
+                               float* c0, void* stream) {
+    E2T_CHECK_ARG(Yext && Cs && lens && h0 && c0 && B > 0 && H > 0 && ldh0 >= 2 * H);
+    const int n = B * 2 * H;
+    hipLaunchKernelGGL(k_final_state, dim3((n + 255) / 256), dim3(256), 0, ST, (const bf16_t*)Yext, ldy, Cs, lens, B, H, (H + 7) / 8 * 8,
+                       (bf16_t*)h0, ldh0, c0);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
+                                 int32_t* next_tok, void* stream) {
+    E2T_CHECK_ARG(pred && done && out && B > 0 && l >= 0 && l < Lmax);
+    hipLaunchKernelGGL(k_greedy_update, dim3((B + 255) / 256), dim3(256), 0, ST, pred, B, l, Lmax, eos, pad, done, out, next_tok);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_inc_step(int32_t* step, void* stream) {
+    E2T_CHECK_ARG(step);
+    hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(64), 0, ST, step);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,
+                                 const e2t_adam_hyper* h, void* stream) {
+    E2T_CHECK_ARG(p && g && m && v && ema && step && h);
+    if (n == 0) return E2T_OK;
+    size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam_ema, dim3((unsigned)blocks), dim3(256), 0, ST, p, g, m, v, ema, n, step, h->lr, h->beta1, h->beta2,
+                       h->eps, h->ema_decay, h->grad_scale);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}

@@ -1,0 +1,886 @@
+"""Device engine of the ECoG->text hot path: parameter store, operand packing,
+workspaces and the launch sequences for train / assess / greedy decode.
+
+This is host-side plumbing only: every FLOP runs in libecog2txt_hip.so
+(hand-written gfx950 kernels) through the C ABI of include/ecog2txt_hip.h.
+torch supplies device memory, streams, hipGraph capture and torch.distributed.
+There is no CPU fallback: constructing an engine without a GPU or without the
+built library raises.
+
+Reference stages replaced (all inside the un-vendored SequenceNetwork.fit,
+ecog2txt/trainers.py:318): reverse inputs (trainers.py:808-810) ->
+_convolve_sequences (813-818) -> _encode_sequences (821-823) ->
+_prepare_encoder_targets (798-799) -> decoder + losses -> Adam/EMA.
+Parameter naming follows the checkpoint grammar recovered by
+MultiSubjectTrainer.recover_model_sizes (trainers.py:444-554).
+"""
+from dataclasses import dataclass, field, asdict
+from typing import Dict, List, Optional
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip_lib as H
+from .hip_lib import lib
+
+PAD_ID, EOS_ID, OOV_ID = 0, 1, 2          # trainers.py:191-196
+
+STREAM_CONV, STREAM_ENC, STREAM_DEC_EMB, STREAM_DEC_OUT, STREAM_AUX = 1, 10, 20, 21, 30
+
+
+def r8(x):
+    return (x + 7) // 8 * 8
+
+
+def ceil_div(a, b):
+    return -(-a // b)
+
+
+@dataclass
+class NetSpec:
+    """Network sizes; field-for-field the manifest's layer_sizes & co.
+    (mocha-1_word_sequence.yaml:5-14, 56-69)."""
+    channels: Dict[object, int]
+    decimation: int = 12
+    enc_embed: int = 100
+    enc_rnn: List[int] = field(default_factory=lambda: [400, 400, 400])
+    dec_embed: int = 150
+    dec_rnn: int = 800
+    dec_proj_hidden: List[int] = field(default_factory=list)
+    vocab: int = 1806
+    aux_layer: Optional[int] = 1
+    aux_hidden: List[int] = field(default_factory=lambda: [225])
+    aux_dim: int = 13
+    aux_dist: str = 'Gaussian'
+    aux_scale: float = 1.0
+    dec_scale: float = 1.0
+    ff_dropout: float = 0.1
+    rnn_dropout: float = 0.5
+    forget_bias: float = 1.0
+    conv_relu: bool = True
+
+    def as_dict(self):
+        return asdict(self)
+
+
+def _tf2int(w, Hh):
+    """TF gate-major columns [..., 4H] (i|j|f|o) -> unit-major interleaved (u*4+g)."""
+    return w.reshape(w.shape[:-1] + (4, Hh)).swapaxes(-1, -2).reshape(w.shape)
+
+
+def _int2tf(w, Hh):
+    return w.reshape(w.shape[:-1] + (Hh, 4)).swapaxes(-1, -2).reshape(w.shape)
+
+
+class ParamStore:
+    """Flat fp32 master / grad / Adam / EMA buffers with named segments.
+
+    Segment order = order in which backward produces the gradients (vocab
+    projection first, per-subject conv last) so that contiguous ranges are the
+    all-reduce buckets of the data-parallel path."""
+
+    def __init__(self, spec, device):
+        self.spec, self.device = spec, device
+        self.segs = {}
+        self.order = []
+        off = 0
+
+        def add(name, *shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            self.segs[name] = (off, tuple(shape))
+            self.order.append(name)
+            off += r8(n) if True else n        # keep every segment 32-B aligned
+
+        # decoder projection stack (last layer stored transposed, trainers.py:513-520)
+        sizes = [spec.dec_rnn] + list(spec.dec_proj_hidden) + [spec.vocab]
+        for i in range(len(sizes) - 2, -1, -1):
+            if i == len(sizes) - 2:
+                add('proj%d.WT' % i, sizes[i + 1], sizes[i]); add('proj%d.b' % i, sizes[i + 1])
+            else:
+                add('proj%d.W' % i, sizes[i] + 1, sizes[i + 1])
+        add('dec.Wx', spec.dec_embed + 1, 4 * spec.dec_rnn)
+        add('dec.Wh', 1, spec.dec_rnn, 4 * spec.dec_rnn)
+        add('dec.emb', spec.vocab, spec.dec_embed)
+        for l in range(len(spec.enc_rnn) - 1, -1, -1):
+            Hh = spec.enc_rnn[l]
+            if spec.aux_layer == l:
+                asz = [2 * Hh] + list(spec.aux_hidden) + [spec.aux_dim]
+                for i in range(len(asz) - 2, -1, -1):
+                    if i == len(asz) - 2:
+                        add('aux%d.WT' % i, asz[i + 1], asz[i]); add('aux%d.b' % i, asz[i + 1])
+                    else:
+                        add('aux%d.W' % i, asz[i] + 1, asz[i + 1])
+            D = spec.enc_embed if l == 0 else 2 * spec.enc_rnn[l - 1]
+            add('enc%d.Wx' % l, D + 1, 2 * 4 * Hh)
+            add('enc%d.Wh' % l, 2, Hh, 4 * Hh)
+        self.shared_end = off
+        for sid, Cc in spec.channels.items():
+            add('conv%s.W' % sid, spec.decimation * Cc + 1, spec.enc_embed)
+        self.n = off
+        z = lambda: torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.p, self.g, self.m, self.v, self.ema = z(), z(), z(), z(), z()
+
+    def view(self, name, buf=None):
+        off, shape = self.segs[name]
+        buf = self.p if buf is None else buf
+        return buf[off:off + int(np.prod(shape))].view(*shape)
+
+    def ptr(self, name, buf=None, elem_off=0):
+        off, _ = self.segs[name]
+        buf = self.p if buf is None else buf
+        return buf.data_ptr() + 4 * (off + elem_off)
+
+    def seg_range(self, name):
+        off, shape = self.segs[name]
+        return off, off + r8(int(np.prod(shape)))
+
+    # ---- TF-layout names (checkpoint grammar, trainers.py:444-554) -------------
+    def tf_names(self):
+        s = self.spec
+        out = []
+        for sid, Cc in s.channels.items():
+            out.append('seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, Cc, s.enc_embed))
+        return out
+
+    def import_tf(self, P, bufs=('p', 'ema')):
+        """Load a dict of TF-layout arrays (oracle.init_params naming) into the masters."""
+        s = self.spec
+        N = s.decimation
+        for bn in bufs:
+            buf = getattr(self, bn)
+
+            def put(name, arr):
+                self.view(name, buf).copy_(torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32))
+            for sid, Cc in s.channels.items():
+                nm = 'seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, Cc, s.enc_embed)
+                put('conv%s.W' % sid, np.concatenate([P[nm + '/weights'].reshape(N * Cc, s.enc_embed),
+                                                     P[nm + '/biases'][None]], 0))
+            for l, Hh in enumerate(s.enc_rnn):
+                D = s.enc_embed if l == 0 else 2 * s.enc_rnn[l - 1]
+                wx, wh = [], []
+                for d in ('fw', 'bw'):
+                    K = P['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, d)]
+                    b = P['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, d)]
+                    wx.append(np.concatenate([_tf2int(K[:D], Hh), _tf2int(b[None], Hh)], 0))
+                    wh.append(_tf2int(K[D:], Hh))
+                put('enc%d.Wx' % l, np.concatenate(wx, 1))
+                put('enc%d.Wh' % l, np.stack(wh, 0))
+            self._ff_io(P, 'aux', 'encoder_%s_projection' % s.aux_layer,
+                        None if s.aux_layer is None else [2 * s.enc_rnn[s.aux_layer]] + list(s.aux_hidden) + [s.aux_dim], put)
+            put('dec.emb', P['seq2seq/decoder_embedding_%d_%d_0/weights' % (s.vocab, s.dec_embed)])
+            K = P['seq2seq/decoder_rnn/cell_0/kernel']
+            b = P['seq2seq/decoder_rnn/cell_0/bias']
+            put('dec.Wx', np.concatenate([_tf2int(K[:s.dec_embed], s.dec_rnn), _tf2int(b[None], s.dec_rnn)], 0))
+            put('dec.Wh', _tf2int(K[s.dec_embed:], s.dec_rnn)[None])
+            self._ff_io(P, 'proj', 'decoder_projection', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab], put)
+
+    def _ff_io(self, P, prefix, tfprefix, sizes, put):
+        if sizes is None:
+            return
+        for i in range(len(sizes) - 1):
+            nm = 'seq2seq/%s_%d_%d_%d' % (tfprefix, sizes[i], sizes[i + 1], i)
+            if i == len(sizes) - 2:
+                put('%s%d.WT' % (prefix, i), P[nm + '/weights'])
+                put('%s%d.b' % (prefix, i), P[nm + '/biases'])
+            else:
+                put('%s%d.W' % (prefix, i), np.concatenate([P[nm + '/weights'], P[nm + '/biases'][None]], 0))
+
+    def export_tf(self, which='p'):
+        """Inverse of import_tf: dict of TF-layout float64 numpy arrays."""
+        s = self.spec
+        N = s.decimation
+        buf = getattr(self, which)
+        host = buf.detach().cpu().numpy().astype(np.float64)
+
+        def get(name):
+            off, shape = self.segs[name]
+            return host[off:off + int(np.prod(shape))].reshape(shape)
+        out = {}
+        for sid, Cc in s.channels.items():
+            nm = 'seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, Cc, s.enc_embed)
+            w = get('conv%s.W' % sid)
+            out[nm + '/weights'] = w[:-1].reshape(1, N, Cc, s.enc_embed).copy()
+            out[nm + '/biases'] = w[-1].copy()
+        for l, Hh in enumerate(s.enc_rnn):
+            D = s.enc_embed if l == 0 else 2 * s.enc_rnn[l - 1]
+            wx, wh = get('enc%d.Wx' % l), get('enc%d.Wh' % l)
+            for d, dn in enumerate(('fw', 'bw')):
+                blk = wx[:, d * 4 * Hh:(d + 1) * 4 * Hh]
+                out['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, dn)] = np.concatenate(
+                    [_int2tf(blk[:D], Hh), _int2tf(wh[d], Hh)], 0)
+                out['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, dn)] = _int2tf(blk[D:D + 1], Hh)[0]
+        if s.aux_layer is not None:
+            self._ff_out(out, get, 'aux', 'encoder_%s_projection' % s.aux_layer,
+                         [2 * s.enc_rnn[s.aux_layer]] + list(s.aux_hidden) + [s.aux_dim])
+        out['seq2seq/decoder_embedding_%d_%d_0/weights' % (s.vocab, s.dec_embed)] = get('dec.emb').copy()
+        wx, wh = get('dec.Wx'), get('dec.Wh')
+        out['seq2seq/decoder_rnn/cell_0/kernel'] = np.concatenate(
+            [_int2tf(wx[:s.dec_embed], s.dec_rnn), _int2tf(wh[0], s.dec_rnn)], 0)
+        out['seq2seq/decoder_rnn/cell_0/bias'] = _int2tf(wx[s.dec_embed:], s.dec_rnn)[0]
+        self._ff_out(out, get, 'proj', 'decoder_projection', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab])
+        return out
+
+    def _ff_out(self, out, get, prefix, tfprefix, sizes):
+        for i in range(len(sizes) - 1):
+            nm = 'seq2seq/%s_%d_%d_%d' % (tfprefix, sizes[i], sizes[i + 1], i)
+            if i == len(sizes) - 2:
+                out[nm + '/weights'] = get('%s%d.WT' % (prefix, i)).copy()
+                out[nm + '/biases'] = get('%s%d.b' % (prefix, i)).copy()
+            else:
+                w = get('%s%d.W' % (prefix, i))
+                out[nm + '/weights'] = w[:-1].copy()
+                out[nm + '/biases'] = w[-1].copy()
+
+
+def _bf(*shape, device):
+    return torch.zeros(*shape, dtype=torch.bfloat16, device=device)
+
+
+def _f32(*shape, device):
+    return torch.zeros(*shape, dtype=torch.float32, device=device)
+
+
+def _i32(*shape, device):
+    return torch.zeros(*shape, dtype=torch.int32, device=device)
+
+
+class _FFStack:
+    """hidden ReLU(+FF dropout) layers then a linear layer stored transposed."""
+
+    def __init__(self, eng, prefix, sizes, in_blocks, in_ld, stream0):
+        # in_blocks: [(src_row0, n, dst_k0)] maps dense input features onto the padded K layout
+        self.eng, self.prefix, self.sizes, self.in_blocks, self.in_ld, self.stream0 = eng, prefix, sizes, in_blocks, in_ld, stream0
+        dev = eng.device
+        self.nl = len(sizes) - 1
+        self.WT, self.WB = [], []
+        for i in range(self.nl):
+            kin = in_ld if i == 0 else r8(sizes[i])
+            self.WT.append(_bf(sizes[i + 1], kin, device=dev))          # B operand of the forward GEMM
+            self.WB.append(_bf(kin, r8(sizes[i + 1]), device=dev))      # B operand of the input-gradient GEMM
+
+    def pack_ops(self, ops, src):
+        st = self.eng.store
+        for i in range(self.nl):
+            last = i == self.nl - 1
+            fin, fout = self.sizes[i], self.sizes[i + 1]
+            blocks = self.in_blocks if i == 0 else [(0, fin, 0)]
+            name = '%s%d.%s' % (self.prefix, i, 'WT' if last else 'W')
+            for (r0, n, k0) in blocks:
+                if last:      # master [out][in]
+                    ops.append(('cast', st.ptr(name, src, r0), fin, 1, fout, n, self.WT[i], k0, 0))
+                    ops.append(('cast', st.ptr(name, src, r0), 1, fin, n, fout, self.WB[i], 0, k0))
+                else:         # master [in+1][out]
+                    ops.append(('cast', st.ptr(name, src, r0 * fout), 1, fout, fout, n, self.WT[i], k0, 0))
+                    ops.append(('cast', st.ptr(name, src, r0 * fout), fout, 1, n, fout, self.WB[i], 0, k0))
+
+    def bias_ptr(self, i, src):
+        st = self.eng.store
+        if i == self.nl - 1:
+            return st.ptr('%s%d.b' % (self.prefix, i), src)
+        return st.ptr('%s%d.W' % (self.prefix, i), src, self.sizes[i] * self.sizes[i + 1])
+
+    def alloc(self, M):
+        dev = self.eng.device
+        Mk = r8(M)
+        ws = dict(M=M, Mk=Mk, act=[], actT=[], dT=[], dpre=[])
+        for i in range(self.nl):
+            fin = self.sizes[i]
+            if i > 0:
+                ws['act'].append(_bf(M, r8(fin), device=dev))            # hidden activation i-1
+                ws['dpre'].append(_bf(M, r8(fin), device=dev))
+            t = _bf(fin + 1, Mk, device=dev)
+            t[fin, :M] = 1.0                                             # ones row => bias gradient for free
+            ws['actT'].append(t)
+            ws['dT'].append(_bf(self.sizes[i + 1], Mk, device=dev))
+        ws['out'] = _f32(M, self.sizes[-1], device=dev)
+        ws['ones'] = _bf(8, Mk, device=dev)
+        ws['ones'][0, :M] = 1.0
+        return ws
+
+    def fwd(self, ws, x_ptr, src, train):
+        e = self.eng
+        M = ws['M']
+        cur, ld = x_ptr, self.in_ld
+        for i in range(self.nl):
+            last = i == self.nl - 1
+            fout = self.sizes[i + 1]
+            kin = self.in_ld if i == 0 else r8(self.sizes[i])
+            if last:
+                e.gemm(cur, ld, self.WT[i].data_ptr(), kin, ws['out'].data_ptr(), fout, M, fout, kin,
+                       bias=self.bias_ptr(i, src))
+            else:
+                o = ws['act'][i]
+                e.gemm(cur, ld, self.WT[i].data_ptr(), kin, o.data_ptr(), r8(fout), M, fout, kin,
+                       bias=self.bias_ptr(i, src), relu=True, out_bf16=True,
+                       drop=(e.spec.ff_dropout if train else 0.0, self.stream0 + i, fout))
+                cur, ld = o.data_ptr(), r8(fout)
+        return ws['out']
+
+    def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train):
+        """d_out: bf16 [M][r8(out)] gradient of the final linear output.  Writes weight grads
+        into the store and the input gradient (fp32) into d_in_ptr."""
+        e = self.eng
+        st = e.store
+        M, Mk = ws['M'], ws['Mk']
+        d, ldd = d_out.data_ptr(), r8(self.sizes[-1])
+        keep = 1.0 / (1.0 - e.spec.ff_dropout) if (train and e.spec.ff_dropout > 0) else 1.0
+        for i in range(self.nl - 1, -1, -1):
+            last = i == self.nl - 1
+            fin, fout = self.sizes[i], self.sizes[i + 1]
+            # transposes (K-contiguous operands for the weight-gradient GEMM)
+            lib.e2t_transpose_bf16(d, ldd, M, fout, ws['dT'][i].data_ptr(), Mk, e.stream)
+            xp, xld = (x_ptr, self.in_ld) if i == 0 else (ws['act'][i - 1].data_ptr(), r8(fin))
+            blocks = self.in_blocks if i == 0 else [(0, fin, 0)]
+            for (r0, n, k0) in blocks:
+                lib.e2t_transpose_bf16(xp + 2 * k0, xld, M, n, ws['actT'][i].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
+            if last:
+                e.gemm(ws['dT'][i].data_ptr(), Mk, ws['actT'][i].data_ptr(), Mk,
+                       st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin, Mk)
+                e.gemm(ws['ones'].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
+                       st.ptr('%s%d.b' % (self.prefix, i), st.g), fout, 1, fout, Mk)
+            else:
+                e.gemm(ws['actT'][i].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
+                       st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk)
+            kin = self.in_ld if i == 0 else r8(fin)
+            if i > 0:
+                dp = ws['dpre'][i - 1]
+                e.gemm(d, ldd, self.WB[i].data_ptr(), r8(fout), dp.data_ptr(), r8(fin), M, fin, r8(fout),
+                       out_bf16=True, alpha=keep, mask_src=(ws['act'][i - 1].data_ptr(), r8(fin)))
+                d, ldd = dp.data_ptr(), r8(fin)
+            else:
+                e.gemm(d, ldd, self.WB[0].data_ptr(), r8(fout), d_in_ptr, d_in_ld, M, kin, r8(fout),
+                       accumulate=accumulate)
+
+
+class _Lstm:
+    """One (bi)directional LSTM layer: operand images + launch helpers."""
+
+    def __init__(self, eng, name, ndir, D, in_blocks, in_ld, Hh, stream):
+        self.eng, self.name, self.ndir, self.D, self.in_blocks, self.in_ld, self.H, self.stream = \
+            eng, name, ndir, D, in_blocks, in_ld, Hh, stream
+        dev = eng.device
+        self.H8 = r8(Hh)
+        self.ldy = ndir * self.H8
+        self.N4 = ndir * 4 * Hh
+        self.UT, self.KB, self.KB4 = ceil_div(Hh, 16), ceil_div(self.H8, 32), ceil_div(4 * Hh, 32)
+        self.WxT = _bf(self.N4, in_ld, device=dev)
+        self.WxB = _bf(in_ld, r8(self.N4), device=dev)
+        self.WhF = _bf(ndir, 4, self.UT, self.KB, 64, 8, device=dev)
+        self.WhB = _bf(ndir, self.UT, self.KB4, 64, 8, device=dev)
+
+    def pack_ops(self, ops, src):
+        st = self.eng.store
+        N4, Hh = self.N4, self.H
+        for (r0, n, k0) in self.in_blocks:
+            ops.append(('cast', st.ptr(self.name + '.Wx', src, r0 * N4), 1, N4, N4, n, self.WxT, k0, 0))
+            ops.append(('cast', st.ptr(self.name + '.Wx', src, r0 * N4), N4, 1, n, N4, self.WxB, 0, k0))
+        for d in range(self.ndir):
+            base = d * Hh * 4 * Hh
+            for g in range(4):
+                ops.append(('frag', st.ptr(self.name + '.Wh', src, base + g), 4, 4 * Hh, Hh, Hh, self.WhF[d, g]))
+            ops.append(('frag', st.ptr(self.name + '.Wh', src, base), 4 * Hh, 1, Hh, 4 * Hh, self.WhB[d]))
+
+    def bias_ptr(self, src):
+        return self.eng.store.ptr(self.name + '.Wx', src, self.D * self.N4)
+
+    def alloc(self, S, B):
+        dev = self.eng.device
+        M, Mk = S * B, r8(S * B)
+        nd, Hh = self.ndir, self.H
+        ws = dict(S=S, B=B, M=M, Mk=Mk)
+        ws['Gx'] = _f32(M, self.N4, device=dev)
+        ws['Yext'] = _bf((S + 2) * B, self.ldy, device=dev)
+        ws['Ydrop'] = _bf(M, self.ldy, device=dev)
+        ws['Cs'] = _f32(M, nd * Hh, device=dev)
+        ws['Gs'] = _f32(M, nd * Hh, 4, device=dev)
+        ws['dG'] = _bf(M, r8(self.N4), device=dev)
+        ws['dGT'] = _bf(self.N4, Mk, device=dev)
+        ws['YT'] = _bf(nd, Hh, Mk, device=dev)
+        ws['xT'] = _bf(self.D + 1, Mk, device=dev)
+        ws['xT'][self.D, :M] = 1.0
+        ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
+        return ws
+
+    def desc(self, ws, train):
+        e = self.eng
+        d = H.LstmDesc()
+        d.S, d.B, d.H, d.ndir, d.ldy = ws['S'], ws['B'], self.H, self.ndir, self.ldy
+        d.forget_bias = e.spec.forget_bias
+        d.drop_rate = e.spec.rnn_dropout if train else 0.0
+        d.drop_seed, d.drop_step, d.drop_stream = e.seed, e.step_t.data_ptr(), self.stream
+        return d
+
+    def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None):
+        e = self.eng
+        M = ws['M']
+        if steps is None:
+            e.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, M, self.N4, self.in_ld,
+                   bias=self.bias_ptr(src))
+            steps = (0, ws['S'])
+        d = self.desc(ws, train)
+        lib.e2t_lstm_seq_fwd(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
+                             ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
+                             c0.data_ptr() if c0 is not None else None, steps[0], steps[1], e.stream)
+
+    def bwd(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
+            dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0):
+        """BPTT + weight gradients + input gradient.  d_in_bf16_mask=(src_ptr, ld): emit the input
+        gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue)."""
+        e = self.eng
+        st = e.store
+        M, Mk, S, B = ws['M'], ws['Mk'], ws['S'], ws['B']
+        nd, Hh = self.ndir, self.H
+        d = self.desc(ws, train)
+        p = lambda t: t.data_ptr() if t is not None else None
+        lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
+                             ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
+                             ws['dc_carry'].data_ptr(), p(dh0), p(dc0), e.stream)
+        lib.e2t_transpose_bf16(ws['dG'].data_ptr(), r8(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
+        for (r0, n, k0) in self.in_blocks:
+            lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
+        e.gemm(ws['xT'].data_ptr(), Mk, ws['dGT'].data_ptr(), Mk, st.ptr(self.name + '.Wx', st.g), self.N4,
+               self.D + 1, self.N4, Mk)
+        for dd in range(nd):
+            # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction)
+            row_off = (2 * B if dd == 1 else 0) * self.ldy
+            lib.e2t_transpose_bf16(ws['Yext'].data_ptr() + 2 * (row_off + dd * self.H8), self.ldy, M, Hh,
+                                   ws['YT'][dd].data_ptr(), Mk, e.stream)
+            e.gemm(ws['YT'][dd].data_ptr(), Mk, ws['dGT'].data_ptr() + 2 * dd * 4 * Hh * Mk, Mk,
+                   st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, Mk)
+        if d_in_ptr is not None:
+            if d_in_bf16_mask is not None:
+                e.gemm(ws['dG'].data_ptr(), r8(self.N4), self.WxB.data_ptr(), r8(self.N4), d_in_ptr, d_in_ld, M, self.D,
+                       r8(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
+            else:
+                e.gemm(ws['dG'].data_ptr(), r8(self.N4), self.WxB.data_ptr(), r8(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
+                       r8(self.N4))
+
+
+class Seq2SeqEngine:
+    def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99):
+        if not torch.cuda.is_available():
+            raise RuntimeError('ecog2txt_amd needs an MI355X (HIP) device; there is no CPU fallback for this path')
+        H.load()
+        self.spec = spec
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.seed = int(seed)
+        self.hyper = dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, ema_decay=ema_decay)
+        self.grad_scale = 1.0
+        self.store = ParamStore(spec, self.device)
+        self.step_t = _i32(1, device=self.device)
+        s = spec
+        assert all(h % 2 == 0 for h in s.enc_rnn) and s.dec_rnn % 2 == 0, 'hidden sizes must be even'
+        assert s.dec_rnn == 2 * s.enc_rnn[-1], 'decoder state = concat(fwd, bwd) encoder state (App. D2)'
+        dev = self.device
+        self.F8 = r8(s.enc_embed)
+        # conv operand per subject: B operand [F][Kc8]; input-gradient operand [Kc8][F8] made on demand
+        self.convT = {sid: _bf(s.enc_embed, r8(s.decimation * Cc), device=dev) for sid, Cc in s.channels.items()}
+        self.convB = {}
+        self.enc = []
+        for l, Hh in enumerate(s.enc_rnn):
+            if l == 0:
+                D, blocks, ld = s.enc_embed, [(0, s.enc_embed, 0)], self.F8
+            else:
+                Hp = s.enc_rnn[l - 1]
+                D, blocks, ld = 2 * Hp, [(0, Hp, 0), (Hp, Hp, r8(Hp))], 2 * r8(Hp)
+            self.enc.append(_Lstm(self, 'enc%d' % l, 2, D, blocks, ld, Hh, STREAM_ENC + l))
+        self.aux = None
+        if s.aux_layer is not None:
+            Hk = s.enc_rnn[s.aux_layer]
+            self.aux = _FFStack(self, 'aux', [2 * Hk] + list(s.aux_hidden) + [s.aux_dim],
+                                [(0, Hk, 0), (Hk, Hk, r8(Hk))], 2 * r8(Hk), STREAM_AUX)
+        self.E8 = r8(s.dec_embed)
+        self.emb = _bf(s.vocab, self.E8, device=dev)
+        self.dec = _Lstm(self, 'dec', 1, s.dec_embed, [(0, s.dec_embed, 0)], self.E8, s.dec_rnn, STREAM_DEC_OUT)
+        self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
+                             [(0, s.dec_rnn, 0)], r8(s.dec_rnn), STREAM_DEC_OUT + 1)
+        self._pack_lists = {}
+        self._ws = {}
+        self._packed = None
+        self.trainable = None         # None = everything; else set of segment names
+
+    def init_params(self, seed=0):
+        """Glorot-uniform weights, zero biases [BUILD-DEFINES]; masters and EMA shadows start equal."""
+        gen = torch.Generator(device='cpu').manual_seed(int(seed))
+        st = self.store
+        st.p.zero_()
+        for nm in st.order:
+            off, shape = st.segs[nm]
+            if nm.endswith('.b'):
+                continue
+            if nm.endswith('.Wh'):
+                fi, fo, rows = shape[1], shape[2], None
+            elif nm.endswith('.WT') or nm == 'dec.emb':
+                fi, fo, rows = shape[1], shape[0], None
+            else:                              # [in+1][out] with the bias as last row
+                fi, fo, rows = shape[0] - 1, shape[1], shape[0] - 1
+            lim = float(np.sqrt(6.0 / (fi + fo)))
+            w = (torch.rand(shape, generator=gen) * 2 - 1) * lim
+            if rows is not None:
+                w[rows:] = 0.0
+            st.view(nm).copy_(w)
+        st.ema.copy_(st.p)
+        st.m.zero_(); st.v.zero_(); self.step_t.zero_()
+        self.pack('p')
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
+             drop=None, mask_src=None, row_lens=None, alpha=1.0):
+        ep = H.GemmEpilogue()
+        ep.bias = bias
+        ep.alpha = alpha
+        flags = (H.GEMM_RELU if relu else 0) | (H.GEMM_OUT_BF16 if out_bf16 else 0) | (H.GEMM_ACCUMULATE if accumulate else 0)
+        if drop is not None and drop[0] > 0:
+            flags |= H.GEMM_DROPOUT
+            ep.drop_rate, ep.drop_stream, ep.drop_ld = drop[0], drop[1], drop[2]
+            ep.drop_seed, ep.drop_step = self.seed, self.step_t.data_ptr()
+        if mask_src is not None:
+            ep.relu_bwd_src, ep.ld_relu_bwd_src = mask_src
+        if row_lens is not None:
+            ep.row_lens, ep.rows_per_step = row_lens
+        ep.flags = flags
+        lib.e2t_gemm_nt_bf16(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
+
+    def _dropout(self, rate, stream):
+        d = H.Dropout()
+        d.rate, d.seed, d.step, d.stream = rate, self.seed, self.step_t.data_ptr(), stream
+        return d
+
+    # ------------------------------------------------------------------ packing
+    def pack(self, which='p'):
+        """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema')."""
+        src = getattr(self.store, which)
+        ops = self._pack_lists.get(which)
+        if ops is None:
+            ops = []
+            st, s = self.store, self.spec
+            for sid, Cc in s.channels.items():
+                Kc = s.decimation * Cc
+                ops.append(('cast', st.ptr('conv%s.W' % sid, src), 1, s.enc_embed, s.enc_embed, Kc, self.convT[sid], 0, 0))
+            for lay in self.enc:
+                lay.pack_ops(ops, src)
+            if self.aux:
+                self.aux.pack_ops(ops, src)
+            ops.append(('cast', st.ptr('dec.emb', src), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
+            self.dec.pack_ops(ops, src)
+            self.proj.pack_ops(ops, src)
+            self._pack_lists[which] = ops
+        for op in ops:
+            if op[0] == 'cast':
+                _, sp, rs, cs, R, Cn, dst, k0, r0 = op
+                ld = dst.shape[-1]
+                lib.e2t_cast_pack(sp, rs, cs, R, Cn, dst.data_ptr() + 2 * (r0 * ld + k0), ld, self.stream)
+            else:
+                _, sp, ns, ks, Nn, Kk, dst = op
+                lib.e2t_pack_frag(sp, ns, ks, Nn, Kk, dst.data_ptr(), self.stream)
+        self._packed = which
+
+    def load_params(self, P):
+        self.store.import_tf(P)
+        self.pack('p')
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, sid, B, T, L):
+        key = (sid, B, T, L)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        s, dev = self.spec, self.device
+        Cc, N = s.channels[sid], s.decimation
+        S = ceil_div(T, N)
+        M, Mk = S * B, r8(S * B)
+        Kc, Kc8 = N * Cc, r8(N * Cc)
+        ws = dict(sid=sid, B=B, T=T, L=L, S=S, M=M, Mk=Mk, C=Cc, Kc=Kc, Kc8=Kc8)
+        ws['X'] = _f32(B, T, Cc, device=dev)
+        ws['Y'] = _i32(B, L, device=dev)
+        ws['lens'], ws['lens_d'] = _i32(B, device=dev), _i32(B, device=dev)
+        ws['A'] = _bf(M, Kc8, device=dev)
+        ws['AT'] = _bf(Kc + 1, Mk, device=dev)
+        ws['AT'][Kc, :M] = 1.0
+        ws['E'] = _bf(M, self.F8, device=dev)
+        ws['dEpre'] = _bf(M, self.F8, device=dev)
+        ws['dEpreT'] = _bf(s.enc_embed, Mk, device=dev)
+        ws['enc'] = [lay.alloc(S, B) for lay in self.enc]
+        ws['dY'] = [_f32(M, lay.ldy, device=dev) for lay in self.enc]
+        if self.aux:
+            cat = s.aux_dist == 'categorical'
+            ws['auxT'] = _i32(B, T, device=dev) if cat else _f32(B, T, s.aux_dim, device=dev)
+            ws['tlens'], ws['tlens_d'], ws['nval'] = _i32(B, device=dev), _i32(B, device=dev), _i32(1, device=dev)
+            ws['At'] = _i32(M, device=dev) if cat else _f32(M, s.aux_dim, device=dev)
+            ws['aux'] = self.aux.alloc(M)
+            ws['dP'] = _bf(M, r8(s.aux_dim), device=dev)
+            ws['aux_rowloss'] = _f32(M, device=dev)
+        Md = L * B
+        ws['Md'] = Md
+        ws['dlens'], ws['ntok'] = _i32(B, device=dev), _i32(1, device=dev)
+        ws['U'], ws['Tg'] = _i32(Md, device=dev), _i32(Md, device=dev)
+        ws['e'] = _bf(Md, self.E8, device=dev)
+        ws['dec'] = self.dec.alloc(L, B)
+        ws['c0'] = _f32(B, s.dec_rnn, device=dev)
+        ws['proj'] = self.proj.alloc(Md)
+        ws['dlogits'] = _bf(Md, r8(s.vocab), device=dev)
+        ws['dHd'] = _f32(Md, r8(s.dec_rnn), device=dev)
+        ws['de'] = _f32(Md, self.E8, device=dev)
+        ws['dh0'], ws['dc0'] = _f32(B, s.dec_rnn, device=dev), _f32(B, s.dec_rnn, device=dev)
+        ws['rowloss'], ws['correct'] = _f32(Md, device=dev), _f32(Md, device=dev)
+        ws['pred'] = _i32(Md, device=dev)
+        ws['loss'] = _f32(4, device=dev)           # decoder CE, aux, accuracy, (unused)
+        ws['done'], ws['hyp'] = _i32(B, device=dev), _i32(B, L, device=dev)
+        ws['graph'] = {}
+        self._ws[key] = ws
+        return ws
+
+    def set_batch(self, ws, batch):
+        ws['X'].copy_(torch.as_tensor(np.asarray(batch['encoder_inputs']), dtype=torch.float32))
+        ws['Y'].copy_(torch.as_tensor(np.asarray(batch['decoder_targets']), dtype=torch.int32))
+        if self.aux and 'encoder_targets' in batch:
+            ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, ws, src, train):
+        s = self.spec
+        B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
+        st = self.stream
+        lib.e2t_seq_lengths_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
+        lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
+        self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
+                  M, s.enc_embed, ws['Kc8'],
+                  bias=self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed), relu=s.conv_relu, out_bf16=True,
+                  drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B))
+        x = ws['E'].data_ptr()
+        for lay, lw in zip(self.enc, ws['enc']):
+            lay.fwd(lw, x, ws['lens_d'], src, train)
+            x = lw['Ydrop'].data_ptr()
+        last, lw = self.enc[-1], ws['enc'][-1]
+        # encoder final state -> block 0 of the decoder's ext output array, and c0
+        lib.e2t_final_state(lw['Yext'].data_ptr(), last.ldy, lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), B, last.H,
+                            ws['dec']['Yext'].data_ptr(), self.dec.ldy, ws['c0'].data_ptr(), st)
+
+    def forward(self, ws, train=True, which=None, with_aux=True):
+        """Teacher-forced forward incl. losses and d(logits); leaves everything backward needs in ws."""
+        s = self.spec
+        src = getattr(self.store, which or 'p')
+        B, T, L, S, M, Md, N = ws['B'], ws['T'], ws['L'], ws['S'], ws['M'], ws['Md'], s.decimation
+        st = self.stream
+        self.encode(ws, src, train)
+        ws['use_aux'] = bool(self.aux and with_aux and s.aux_scale != 0.0)
+        if ws['use_aux']:
+            cat = s.aux_dist == 'categorical'
+            k = s.aux_layer
+            if cat:
+                lib.e2t_seq_lengths_i32(ws['auxT'].data_ptr(), B, T, PAD_ID, N, ws['tlens'].data_ptr(), ws['tlens_d'].data_ptr(), st)
+                lib.e2t_gather_rev_decim_i32(ws['auxT'].data_ptr(), ws['tlens'].data_ptr(), B, T, N, ws['At'].data_ptr(), st)
+            else:
+                lib.e2t_seq_lengths_f32(ws['auxT'].data_ptr(), B, T, s.aux_dim, N, ws['tlens'].data_ptr(), ws['tlens_d'].data_ptr(), st)
+                lib.e2t_gather_rev_decim_f32(ws['auxT'].data_ptr(), ws['tlens'].data_ptr(), B, T, s.aux_dim, N, ws['At'].data_ptr(), st)
+            lib.e2t_sum_i32(ws['tlens_d'].data_ptr(), B, ws['nval'].data_ptr(), st)
+            out = self.aux.fwd(ws['aux'], ws['enc'][k]['Ydrop'].data_ptr(), src, train)
+            if cat:
+                lib.e2t_softmax_ce(out.data_ptr(), s.aux_dim, M, s.aux_dim, ws['At'].data_ptr(), ws['tlens_d'].data_ptr(), B,
+                                   ws['nval'].data_ptr(), s.aux_scale, ws['aux_rowloss'].data_ptr(), None, None,
+                                   ws['dP'].data_ptr(), r8(s.aux_dim), st)
+                lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0, ws['loss'].data_ptr() + 4, st)
+            else:
+                lib.e2t_mse(out.data_ptr(), s.aux_dim, ws['At'].data_ptr(), M, s.aux_dim, ws['tlens_d'].data_ptr(), B,
+                            ws['nval'].data_ptr(), s.aux_scale, ws['aux_rowloss'].data_ptr(), ws['dP'].data_ptr(),
+                            r8(s.aux_dim), st)
+                lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0 / s.aux_dim,
+                                ws['loss'].data_ptr() + 4, st)
+        # decoder (teacher forced)
+        lib.e2t_seq_lengths_i32(ws['Y'].data_ptr(), B, L, PAD_ID, 1, ws['dlens'].data_ptr(), None, st)
+        lib.e2t_sum_i32(ws['dlens'].data_ptr(), B, ws['ntok'].data_ptr(), st)
+        lib.e2t_decoder_tokens(ws['Y'].data_ptr(), B, L, EOS_ID, ws['U'].data_ptr(), ws['Tg'].data_ptr(), st)
+        dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
+        lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), 0, Md, s.dec_embed, ws['e'].data_ptr(), self.E8,
+                          C.byref(dr), st)
+        self.dec.fwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], src, train, c0=ws['c0'])
+        logits = self.proj.fwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), src, train)
+        lib.e2t_softmax_ce(logits.data_ptr(), s.vocab, Md, s.vocab, ws['Tg'].data_ptr(), ws['dlens'].data_ptr(), B,
+                           ws['ntok'].data_ptr(), s.dec_scale, ws['rowloss'].data_ptr(), ws['pred'].data_ptr(),
+                           ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), r8(s.vocab), st)
+        lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr(), st)
+        lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr() + 8, st)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ws, train=True):
+        s, store = self.spec, self.store
+        B, L, S, M, Md, Mk = ws['B'], ws['L'], ws['S'], ws['M'], ws['Md'], ws['Mk']
+        st = self.stream
+        sid = ws['sid']
+        # vocabulary projection
+        self.proj.bwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'], ws['dHd'].data_ptr(), r8(s.dec_rnn), False, train)
+        # decoder BPTT (+ gradient into the encoder's final state)
+        self.dec.bwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), r8(s.dec_rnn), train,
+                     ws['de'].data_ptr(), self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
+        store.view('dec.emb', store.g).zero_()
+        dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
+        lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), Md, s.dec_embed,
+                          store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), st)
+        # encoder, top layer first
+        nl = len(self.enc)
+        have_dy = [False] * nl
+        for l in range(nl - 1, -1, -1):
+            lay, lw = self.enc[l], ws['enc'][l]
+            if ws['use_aux'] and s.aux_layer == l:
+                self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, have_dy[l], train)
+                have_dy[l] = True
+            x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
+            dY = ws['dY'][l].data_ptr() if have_dy[l] else None
+            fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
+            if l > 0:
+                lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy, **fin)
+                have_dy[l - 1] = True
+            else:
+                keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
+                lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dEpre'].data_ptr(), self.F8,
+                        d_in_bf16_mask=(ws['E'].data_ptr(), self.F8), d_in_alpha=keep, **fin)
+        # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
+        lib.e2t_transpose_bf16(ws['dEpre'].data_ptr(), self.F8, M, s.enc_embed, ws['dEpreT'].data_ptr(), Mk, st)
+        lib.e2t_transpose_bf16(ws['A'].data_ptr(), ws['Kc8'], M, ws['Kc'], ws['AT'].data_ptr(), Mk, st)
+        self.gemm(ws['AT'].data_ptr(), Mk, ws['dEpreT'].data_ptr(), Mk, store.ptr('conv%s.W' % sid, store.g), s.enc_embed,
+                  ws['Kc'] + 1, s.enc_embed, Mk)
+
+    # ------------------------------------------------------------------ optimiser
+    def adam_step(self, sid=None):
+        """Adam + EMA on the shared body and (if given) subject `sid`'s conv; then re-pack operands."""
+        store = self.store
+        st = self.stream
+        lib.e2t_inc_step(self.step_t.data_ptr(), st)
+        h = H.AdamHyper()
+        h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
+        h.ema_decay, h.grad_scale = self.hyper['ema_decay'], self.grad_scale
+        for a, b in self.trainable_ranges(sid):
+            o = 4 * a
+            lib.e2t_adam_ema_step(store.p.data_ptr() + o, store.g.data_ptr() + o, store.m.data_ptr() + o,
+                                  store.v.data_ptr() + o, store.ema.data_ptr() + o, b - a, self.step_t.data_ptr(),
+                                  C.byref(h), st)
+        self.pack('p')
+
+    def trainable_ranges(self, sid=None):
+        """Contiguous [a,b) element ranges of the flat buffers that receive updates."""
+        store = self.store
+        names = []
+        for nm in store.order:
+            if nm.startswith('conv') and (sid is None or nm != 'conv%s.W' % sid):
+                continue
+            if self.trainable is not None and nm not in self.trainable:
+                continue
+            names.append(nm)
+        ranges = []
+        for nm in names:
+            a, b = store.seg_range(nm)
+            if ranges and ranges[-1][1] == a:
+                ranges[-1][1] = b
+            else:
+                ranges.append([a, b])
+        return [tuple(r) for r in ranges]
+
+    # ------------------------------------------------------------------ steps
+    def train_step(self, ws, use_graph=True, sync_grads=None):
+        """One optimisation step on the batch staged in ws['X'], ws['Y'], ws['auxT']."""
+        if self._packed != 'p':
+            self.pack('p')
+        if not use_graph:
+            self.forward(ws, train=True)
+            self.backward(ws, train=True)
+            if sync_grads:
+                sync_grads()
+            self.adam_step(ws['sid'])
+            return
+        key = 'train_dp' if sync_grads else 'train'
+        g = ws['graph'].get(key)
+        if g is None:
+            # warm-up launch outside capture (lazy module loading), then capture
+            self.forward(ws, train=True)
+            self.backward(ws, train=True)
+            torch.cuda.synchronize(self.device)
+            if sync_grads:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    self.forward(ws, train=True)
+                    self.backward(ws, train=True)
+                with torch.cuda.graph(g2):
+                    self.adam_step(ws['sid'])
+                g = (g1, g2)
+            else:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    self.forward(ws, train=True)
+                    self.backward(ws, train=True)
+                    self.adam_step(ws['sid'])
+                g = (g1,)
+            ws['graph'][key] = g
+        g[0].replay()
+        if sync_grads:
+            sync_grads()
+            g[1].replay()
+
+    def losses(self, ws):
+        v = ws['loss'].cpu().numpy()
+        out = dict(decoder=float(v[0]), accuracy=float(v[2]))
+        if ws.get('use_aux'):
+            out['aux'] = float(v[1])
+        out['total'] = self.spec.dec_scale * out['decoder'] + self.spec.aux_scale * out.get('aux', 0.0)
+        return out
+
+    # ------------------------------------------------------------------ decode
+    def greedy_decode(self, ws, which='ema', max_len=None):
+        """beam_width 1 decoding (mocha-1_word_sequence.yaml:31); returns int32 [B, L] token ids."""
+        s = self.spec
+        if self._packed != which:
+            self.pack(which)
+        src = getattr(self.store, which)
+        B, L = ws['B'], ws['L']
+        max_len = L if max_len is None else min(max_len, L)
+        st = self.stream
+        self.encode(ws, src, False)
+        ws['done'].zero_()
+        ws['hyp'].fill_(PAD_ID)
+        ws['U'][:B].fill_(EOS_ID)
+        ws['dlens'].fill_(L)
+        dw = ws['dec']
+        dr = self._dropout(0.0, STREAM_DEC_EMB)
+        pw = ws['proj']
+        for l in range(max_len):
+            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), l * B, B, s.dec_embed, ws['e'].data_ptr(),
+                              self.E8, C.byref(dr), st)
+            # input projection for this step's rows only
+            self.gemm(ws['e'].data_ptr() + 2 * l * B * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
+                      dw['Gx'].data_ptr() + 4 * l * B * self.dec.N4, self.dec.N4, B, self.dec.N4, self.E8,
+                      bias=self.dec.bias_ptr(src))
+            self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
+            # logits for this step: run the projection stack on rows [l*B, (l+1)*B) of the ext array (t+1 block)
+            self._proj_rows(ws, src, l)
+            lib.e2t_softmax_ce(pw['out'].data_ptr() + 4 * l * B * s.vocab, s.vocab, B, s.vocab, None, None, 1, None, 0.0,
+                               None, ws['pred'].data_ptr(), None, None, 0, st)
+            nxt = ws['U'].data_ptr() + 4 * (l + 1) * B if l + 1 < L else None
+            lib.e2t_greedy_update(ws['pred'].data_ptr(), B, l, L, EOS_ID, PAD_ID, ws['done'].data_ptr(),
+                                  ws['hyp'].data_ptr(), nxt, st)
+        return ws['hyp']
+
+    def _proj_rows(self, ws, src, l):
+        """Projection stack on decoder step l (un-dropped h_t = ext block l+1)."""
+        s = self.spec
+        B = ws['B']
+        pr, pw = self.proj, ws['proj']
+        cur = ws['dec']['Yext'].data_ptr() + 2 * (l + 1) * B * self.dec.ldy
+        ld = self.dec.ldy
+        for i in range(pr.nl):
+            last = i == pr.nl - 1
+            fout = pr.sizes[i + 1]
+            kin = pr.in_ld if i == 0 else r8(pr.sizes[i])
+            if last:
+                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, pw['out'].data_ptr() + 4 * l * B * fout, fout, B, fout, kin,
+                          bias=pr.bias_ptr(i, src))
+            else:
+                o = pw['act'][i].data_ptr() + 2 * l * B * r8(fout)
+                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, o, r8(fout), B, fout, kin, bias=pr.bias_ptr(i, src),
+                          relu=True, out_bf16=True)
+                cur, ld = o, r8(fout)

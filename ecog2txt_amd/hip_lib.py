@@ -1,0 +1,109 @@
+"""ctypes binding of libecog2txt_hip.so (the C ABI in include/ecog2txt_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or an entry point is
+absent, importing the symbol raises.  Every wrapper raises RuntimeError with
+`e2t_last_error()` when the C side returns non-zero.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip.so')
+
+GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT = 1, 2, 4, 8
+
+
+class Dropout(C.Structure):
+    _fields_ = [('rate', C.c_float), ('seed', C.c_ulonglong), ('step', C.c_void_p), ('stream', C.c_uint)]
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('relu_bwd_src', C.c_void_p), ('ld_relu_bwd_src', C.c_int),
+                ('row_lens', C.c_void_p), ('rows_per_step', C.c_int), ('alpha', C.c_float), ('flags', C.c_int),
+                ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong), ('drop_step', C.c_void_p),
+                ('drop_stream', C.c_uint), ('drop_ld', C.c_int)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [('S', C.c_int), ('B', C.c_int), ('H', C.c_int), ('ndir', C.c_int), ('ldy', C.c_int),
+                ('forget_bias', C.c_float), ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong),
+                ('drop_step', C.c_void_p), ('drop_stream', C.c_uint)]
+
+
+class AdamHyper(C.Structure):
+    _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+                ('ema_decay', C.c_float), ('grad_scale', C.c_float)]
+
+
+_p, _i, _f, _l, _z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
+
+# name -> argtypes; the list mirrors include/ecog2txt_hip.h one to one
+SIGNATURES = {
+    'e2t_seq_lengths_f32': [_p, _i, _i, _i, _i, _p, _p, _p],
+    'e2t_seq_lengths_i32': [_p, _i, _i, _i, _i, _p, _p, _p],
+    'e2t_sum_i32': [_p, _i, _p, _p],
+    'e2t_sum_f32': [_p, _i, _p, _f, _p, _p],
+    'e2t_conv_pack': [_p, _p, _i, _i, _i, _i, _p, _i, _p],
+    'e2t_conv_unpack_grad': [_p, _i, _p, _i, _i, _i, _i, _p, _p],
+    'e2t_gather_rev_decim_f32': [_p, _p, _i, _i, _i, _i, _p, _p],
+    'e2t_gather_rev_decim_i32': [_p, _p, _i, _i, _i, _p, _p],
+    'e2t_decoder_tokens': [_p, _i, _i, _i, _p, _p, _p],
+    'e2t_gemm_nt_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    'e2t_transpose_bf16': [_p, _i, _i, _i, _p, _i, _p],
+    'e2t_cast_pack': [_p, _l, _l, _i, _i, _p, _i, _p],
+    'e2t_pack_frag': [_p, _l, _l, _i, _i, _p, _p],
+    'e2t_lstm_seq_fwd': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    'e2t_lstm_seq_bwd': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'e2t_final_state': [_p, _i, _p, _p, _i, _i, _p, _i, _p, _p],
+    'e2t_embed_fwd': [_p, _i, _p, _i, _i, _i, _p, _i, C.POINTER(Dropout), _p],
+    'e2t_embed_bwd': [_p, _i, _p, _i, _i, _p, _i, C.POINTER(Dropout), _p],
+    'e2t_softmax_ce': [_p, _i, _i, _i, _p, _p, _i, _p, _f, _p, _p, _p, _p, _i, _p],
+    'e2t_greedy_update': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    'e2t_mse': [_p, _i, _p, _i, _i, _p, _i, _p, _f, _p, _p, _i, _p],
+    'e2t_inc_step': [_p, _p],
+    'e2t_adam_ema_step': [_p, _p, _p, _p, _p, _z, _p, C.POINTER(AdamHyper), _p],
+}
+PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int)}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libecog2txt_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+            'or ecog2txt_amd/csrc/build.sh. There is no CPU fallback for this path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, res
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes, fn.restype = args, C.c_int
+    _lib = lib
+    return lib
+
+
+class _Calls:
+    """Attribute access returns a checked wrapper: lib.e2t_xxx(...) raises on failure."""
+
+    def __getattr__(self, name):
+        lib = load()
+        fn = getattr(lib, name)
+        if name in PLAIN:
+            return fn
+
+        def checked(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise RuntimeError('%s failed (%d): %s' % (name, rc, lib.e2t_last_error().decode()))
+        checked.__name__ = name
+        setattr(self, name, checked)
+        return checked
+
+
+lib = _Calls()

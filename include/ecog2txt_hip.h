@@ -1,0 +1,137 @@
+/* ecog2txt_hip.h -- C ABI of libecog2txt_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the ONE hot path of jgmakin/ecog2txt: everything that
+ * `machine_learning.neural_networks.sequence_networks.SequenceNetwork` executes
+ * on the device when the reference calls
+ *     net.fit(subjects, ...)                   ecog2txt/trainers.py:318, 355, 367
+ *     net.restore_and_assess(subjects, epoch)  ecog2txt/trainers.py:379-380
+ *     net.restore_and_get_saliencies(...)      ecog2txt/trainers.py:722-725
+ * The reference has no FFI of its own (pure Python over TF1.x),
+ * so these entry points are [BUILD-DEFINES]: one per device stage of that path,
+ * each citing the reference stage it replaces.  The Python host
+ * (ecog2txt_amd/sequence_network.py) binds them with ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    stated otherwise; the caller owns all buffers; `stream` is a hipStream_t.
+ *  - all launches are asynchronous on `stream`; no entry point synchronises,
+ *    allocates or frees, so every call is hipGraph-capturable.
+ *  - return 0 on success, non-zero on failure; e2t_last_error() gives the text.
+ *    Nothing throws across the boundary.
+ *  - "bf16" buffers are raw uint16 bfloat16 bits.  Every bf16 matrix has a leading
+ *    dimension that is a multiple of 8 elements and ZERO padding columns that no
+ *    kernel ever writes (the GEMM reads K rounded up to 8).
+ *  - sequence tensors are TIME-MAJOR on the device: row m = t * B + b.
+ */
+#ifndef ECOG2TXT_HIP_H
+#define ECOG2TXT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2T_ABI_VERSION 1
+
+int e2t_abi_version(void);
+const char* e2t_last_error(void);          /* thread-local, host pointer */
+/* number of compute units / XCDs of `device`, 0 if no device is usable */
+int e2t_device_cus(int device);
+
+/* ---- dropout descriptor (FF_dropout / RNN_dropout, mocha-1_word_sequence.yaml:6,13) ---- */
+typedef struct e2t_dropout {
+    float rate;                 /* 0 disables */
+    unsigned long long seed;    /* Philox key; effective key = seed + *step */
+    const int32_t* step;        /* device step counter or NULL */
+    unsigned stream;            /* tensor id (oracle/seq2seq.py STREAM_*) */
+} e2t_dropout;
+
+/* ---- a4: nn.sequences_tools (trainers.py:789-790, 806-807) ---- */
+int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream);
+int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int div, int32_t* lens, int32_t* lens_div, void* stream);
+int e2t_sum_i32(const int32_t* x, int n, int32_t* out, void* stream);
+int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float* out, void* stream);
+
+/* ---- a5+a6: tf.reverse_sequence (trainers.py:808-810) fused with the im2row staging of
+ *      SequenceNetwork._convolve_sequences (trainers.py:813-818): x [B][T][C] fp32 ->
+ *      A [(T/N)*B][lda] bf16, row (t',b), column (w,c)  ---- */
+int e2t_conv_pack(const float* x, const int32_t* lens, int B, int T, int C, int N, void* A, int lda, void* stream);
+/* a12: scatter d/dA [S*B][ldda] fp32 back to d/dx [B][T][C] (restore_and_get_saliencies, trainers.py:722-725) */
+int e2t_conv_unpack_grad(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, float* dx, void* stream);
+
+/* ---- a8: _prepare_encoder_targets: reverse then [:, 0::N, :] (trainers.py:791-799) ---- */
+int e2t_gather_rev_decim_f32(const float* a, const int32_t* tlens, int B, int T, int K, int N, float* out, void* stream);
+int e2t_gather_rev_decim_i32(const int32_t* a, const int32_t* tlens, int B, int T, int N, int32_t* out, void* stream);
+/* a9: teacher-forcing inputs/targets, time-major; <EOS> as start symbol */
+int e2t_decoder_tokens(const int32_t* y, int B, int L, int eos, int32_t* U, int32_t* Tg, void* stream);
+
+/* ---- the matmul: C[M][N] (+)= alpha * A[M][K] . B[N][K]^T with fused epilogue ---- */
+#define E2T_GEMM_RELU 1
+#define E2T_GEMM_OUT_BF16 2
+#define E2T_GEMM_ACCUMULATE 4      /* fp32 output only */
+#define E2T_GEMM_DROPOUT 8
+typedef struct e2t_gemm_epilogue {
+    const float* bias;             /* [N] or NULL */
+    const void* relu_bwd_src;      /* bf16 [M][ld]: out = src != 0 ? out : 0 (ReLU/dropout backward) */
+    int ld_relu_bwd_src;
+    const int32_t* row_lens;       /* [rows_per_step] or NULL: row m kept iff m / rows_per_step < row_lens[m % rows_per_step] */
+    int rows_per_step;
+    float alpha;
+    int flags;
+    float drop_rate; unsigned long long drop_seed; const int32_t* drop_step; unsigned drop_stream; int drop_ld;
+} e2t_gemm_epilogue;
+int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const e2t_gemm_epilogue* ep /* host pointer or NULL */, void* stream);
+int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
+
+/* ---- weight packing: fp32 masters -> bf16 operand images (after every optimiser step) ---- */
+int e2t_cast_pack(const float* src, long row_stride, long col_stride, int R, int C, void* dst, int ld_dst, void* stream);
+int e2t_pack_frag(const float* src, long n_stride, long k_stride, int Nn, int Kk, void* dst, void* stream);
+
+/* ---- a7/a9: SequenceNetwork._encode_sequences (trainers.py:821-823) and the decoder RNN ---- */
+typedef struct e2t_lstm_desc {
+    int S, B, H, ndir;             /* steps, utterances, hidden units per direction, 1 or 2 directions */
+    int ldy;                       /* leading dim of Yext / Ydrop (>= ndir * roundup(H,8), multiple of 8) */
+    float forget_bias;
+    float drop_rate; unsigned long long drop_seed; const int32_t* drop_step; unsigned drop_stream;
+} e2t_lstm_desc;
+/* Gx [S*B][ndir*H*4] fp32 (dir,unit,gate interleaved; bias folded in); WhF: e2t_pack_frag images
+ * [ndir][4][UT][KB]; Yext bf16 [(S+2)*B][ldy] (time block t+1); Ydrop bf16 [S*B][ldy] or NULL;
+ * Cs fp32 [S*B][ndir*H]; Gs fp32 [S*B][ndir*H][4]; c0 fp32 [B][ndir*H] or NULL.
+ * Runs steps [step_begin, step_end). */
+int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
+                     float* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
+/* BPTT over all S steps (+ pseudo-step -1 when dh0/dc0 are given).  dG bf16 [S*B][lddg] out. */
+int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
+                     const float* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
+                     const float* dc_final, float* dc_carry, float* dh0, float* dc0, void* stream);
+/* encoder final state -> decoder initial state (App. D2) */
+int e2t_final_state(const void* Yext, int ldy, const float* Cs, const int32_t* lens, int B, int H, void* h0, int ldh0,
+                    float* c0, void* stream);
+
+/* ---- a9: embedding, softmax cross-entropy, greedy decoding ---- */
+int e2t_embed_fwd(const void* emb, int ld_emb, const int32_t* tok, int row0, int M, int E, void* out, int ld_out,
+                  const e2t_dropout* drop, void* stream);
+int e2t_embed_bwd(const float* de, int ld_de, const int32_t* tok, int M, int E, float* demb, int ld_demb,
+                  const e2t_dropout* drop, void* stream);
+int e2t_softmax_ce(const float* logits, int ldl, int M, int V, const int32_t* tgt, const int32_t* lens, int rows_per_step,
+                   const int32_t* ntok, float weight, float* rowloss, int32_t* pred, float* correct, void* dlogits,
+                   int lddl, void* stream);
+int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
+                      int32_t* next_tok, void* stream);
+/* ---- a8: Gaussian encoder-target head ---- */
+int e2t_mse(const float* P, int ldp, const float* At, int M, int K, const int32_t* lens, int rows_per_step,
+            const int32_t* nval, float weight, float* rowloss, void* dP, int lddp, void* stream);
+
+/* ---- a10: Adam + EMA (EMA_decay, mocha-1_word_sequence.yaml:5) ---- */
+typedef struct e2t_adam_hyper { float lr, beta1, beta2, eps, ema_decay, grad_scale; } e2t_adam_hyper;
+int e2t_inc_step(int32_t* step, void* stream);
+int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,
+                      const e2t_adam_hyper* h /* host pointer */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

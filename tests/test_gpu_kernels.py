@@ -1,0 +1,185 @@
+"""Kernel-level parity tests (call through the C ABI, compare with NumPy/oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.bf16 import round_bf16, to_bf16_bits, from_bf16_bits
+from oracle.philox import keep_mask
+from oracle import seq2seq as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hl():
+    from ecog2txt_amd import hip_lib
+    hip_lib.load()
+    return hip_lib
+
+
+def dev_bf16(a):
+    """numpy float -> cuda bf16 tensor holding round_bf16(a)."""
+    bits = to_bf16_bits(a).astype(np.int16)
+    return torch.from_numpy(bits).cuda().view(torch.bfloat16)
+
+
+def host(t):
+    if t.dtype == torch.bfloat16:
+        return from_bf16_bits(t.view(torch.int16).cpu().numpy().view(np.uint16))
+    return t.cpu().numpy().astype(np.float64)
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def r8(x):
+    return (x + 7) // 8 * 8
+
+
+@pytest.mark.parametrize('M,N,K', [(16, 16, 32), (128, 128, 64), (130, 70, 40), (300, 257, 136), (1, 50, 264),
+                                   (513, 100, 3072)])
+def test_gemm_nt_plain(hl, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K))
+    Bm = rng.standard_normal((N, K))            # asymmetric operands catch transposed outputs
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    c = torch.full((M, N), 7.0, device='cuda')
+    hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N, K, None, st())
+    torch.cuda.synchronize()
+    want = round_bf16(A) @ round_bf16(Bm).T
+    np.testing.assert_allclose(host(c), want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+
+
+def test_gemm_epilogues(hl):
+    rng = np.random.default_rng(3)
+    M, N, K, rowsB = 96, 52, 72, 8
+    A, Bm = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+    bias = rng.standard_normal(N)
+    lens = rng.integers(0, M // rowsB + 1, size=rowsB)
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    bt = torch.tensor(bias, dtype=torch.float32, device='cuda')
+    lt = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    step = torch.tensor([5], dtype=torch.int32, device='cuda')
+    ldc = r8(N)
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device='cuda')
+    ep = hl.GemmEpilogue()
+    ep.bias, ep.alpha = bt.data_ptr(), 1.0
+    ep.flags = hl.GEMM_RELU | hl.GEMM_OUT_BF16 | hl.GEMM_DROPOUT
+    ep.drop_rate, ep.drop_seed, ep.drop_step, ep.drop_stream, ep.drop_ld = 0.25, 1000, step.data_ptr(), 9, N
+    ep.row_lens, ep.rows_per_step = lt.data_ptr(), rowsB
+    hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, out.data_ptr(), ldc, M, N, K, C.byref(ep), st())
+    torch.cuda.synchronize()
+    ref = np.maximum(round_bf16(A) @ round_bf16(Bm).T + bias, 0.0)
+    ref = ref * keep_mask((M, N), 0.25, 1005, 9) / 0.75
+    valid = (np.arange(M) // rowsB) < lens[np.arange(M) % rowsB]
+    ref = round_bf16(ref * valid[:, None])
+    got = host(out)[:, :N]
+    # bf16 outputs: allow one ulp where fp32 vs fp64 accumulation straddles a rounding boundary
+    np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-6)
+    assert (got[~valid] == 0).all()
+    assert np.all(host(out)[:, N:] == 0)
+    # accumulate + relu-backward mask + alpha
+    c0 = rng.standard_normal((M, N))
+    ct = torch.tensor(c0, dtype=torch.float32, device='cuda')
+    ep2 = hl.GemmEpilogue()
+    ep2.alpha, ep2.flags = 0.5, hl.GEMM_ACCUMULATE
+    ep2.relu_bwd_src, ep2.ld_relu_bwd_src = out.data_ptr(), ldc
+    hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, ct.data_ptr(), N, M, N, K, C.byref(ep2), st())
+    torch.cuda.synchronize()
+    want = c0 + 0.5 * (round_bf16(A) @ round_bf16(Bm).T) * (ref != 0)
+    np.testing.assert_allclose(host(ct), want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('R,Cc', [(5, 3), (64, 64), (100, 37), (257, 130)])
+def test_transpose(hl, R, Cc):
+    rng = np.random.default_rng(R)
+    x = rng.standard_normal((R, r8(Cc)))
+    xt = dev_bf16(x)
+    ldo = r8(R) + 8
+    out = torch.full((Cc + 1, ldo), 1.0, dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_transpose_bf16(xt.data_ptr(), r8(Cc), R, Cc, out.data_ptr(), ldo, st())
+    torch.cuda.synchronize()
+    got = host(out)
+    np.testing.assert_array_equal(got[:Cc, :R], round_bf16(x)[:, :Cc].T)
+    assert (got[:Cc, R:] == 0).all()          # K padding zero-filled
+    assert (got[Cc] == 1).all()               # ones row untouched
+
+
+@pytest.mark.parametrize('C_', [8, 6])
+def test_lengths_and_conv_pack(hl, C_):
+    rng = np.random.default_rng(C_)
+    B, T, N = 7, 23, 4
+    X = np.abs(rng.standard_normal((B, T, C_))) + 0.1
+    lens = np.array([23, 1, 0, 10, 22, 4, 5])
+    for b in range(B):
+        X[b, lens[b]:] = 0
+    xt = torch.tensor(X, dtype=torch.float32, device='cuda')
+    lt = torch.zeros(B, dtype=torch.int32, device='cuda')
+    ld = torch.zeros(B, dtype=torch.int32, device='cuda')
+    hl.lib.e2t_seq_lengths_f32(xt.data_ptr(), B, T, C_, N, lt.data_ptr(), ld.data_ptr(), st())
+    S = -(-T // N)
+    K8 = r8(N * C_)
+    A = torch.full((S * B, K8), 3.0, dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_conv_pack(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, A.data_ptr(), K8, st())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(lt.cpu().numpy(), lens)
+    np.testing.assert_array_equal(ld.cpu().numpy(), -(-lens // N))
+    Xr = O.reverse_time_major(X.astype(np.float32).astype(np.float64), lens)
+    Xp = np.zeros((S * N, B, C_))
+    Xp[:T] = Xr
+    want = round_bf16(Xp.reshape(S, N, B, C_).transpose(0, 2, 1, 3).reshape(S * B, N * C_))
+    got = host(A)
+    np.testing.assert_array_equal(got[:, :N * C_], want)
+    assert (got[:, N * C_:] == 0).all()
+
+
+def test_softmax_ce(hl):
+    rng = np.random.default_rng(0)
+    B, L, V = 6, 5, 1806
+    M = B * L
+    logits = 3 * rng.standard_normal((M, V))
+    tgt = rng.integers(0, V, size=M)
+    lens = np.array([5, 1, 0, 3, 5, 2])
+    lg = torch.tensor(logits, dtype=torch.float32, device='cuda')
+    tg = torch.tensor(tgt, dtype=torch.int32, device='cuda')
+    ln = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    ntok = torch.tensor([int(lens.sum())], dtype=torch.int32, device='cuda')
+    rl = torch.zeros(M, device='cuda'); cr = torch.zeros(M, device='cuda')
+    pr = torch.zeros(M, dtype=torch.int32, device='cuda')
+    dl = torch.zeros(M, r8(V), dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_softmax_ce(lg.data_ptr(), V, M, V, tg.data_ptr(), ln.data_ptr(), B, ntok.data_ptr(), 0.7, rl.data_ptr(),
+                          pr.data_ptr(), cr.data_ptr(), dl.data_ptr(), r8(V), st())
+    torch.cuda.synchronize()
+    l32 = logits.astype(np.float32).astype(np.float64)
+    mx = l32.max(1, keepdims=True)
+    lse = mx[:, 0] + np.log(np.exp(l32 - mx).sum(1))
+    valid = (np.arange(M) // B) < lens[np.arange(M) % B]
+    np.testing.assert_allclose(host(rl), (lse - l32[np.arange(M), tgt]) * valid, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(pr.cpu().numpy(), l32.argmax(1))
+    p = np.exp(l32 - lse[:, None])
+    oh = np.zeros_like(p); oh[np.arange(M), tgt] = 1
+    want = (p - oh) * valid[:, None] * 0.7 / lens.sum()
+    np.testing.assert_allclose(host(dl)[:, :V], want, rtol=2 ** -7, atol=1e-7)
+
+
+def test_adam_ema_matches_oracle(hl):
+    rng = np.random.default_rng(1)
+    n = 1000
+    p0, g1, g2 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    P, state = {'w': p0.copy()}, {}
+    for g in (g1, g2):
+        O.adam_ema_step(P, {'w': g}, state, lr=1e-2)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda')
+    p, m, v, ema = t(p0), t(np.zeros(n)), t(np.zeros(n)), t(p0)
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    h = hl.AdamHyper(1e-2, 0.9, 0.999, 1e-8, 0.99, 1.0)
+    for g in (g1, g2):
+        hl.lib.e2t_inc_step(step.data_ptr(), st())
+        hl.lib.e2t_adam_ema_step(p.data_ptr(), t(g).data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n,
+                                 step.data_ptr(), C.byref(h), st())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(p), P['w'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(host(ema), state['ema']['w'], rtol=2e-5, atol=1e-6)
