@@ -61,6 +61,28 @@ __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long
     return v >= thresh ? 1.0f / (1.0f - d.rate) : 0.0f;
 }
 
+// ---------------------------------------------------------------------------
+// Direct-to-LDS DMA (global_load_lds_dwordx4): every lane supplies its own global source
+// address; the 64 x 16 B land LINEARLY at LDS byte address `lds_addr` (wave-uniform) + lane*16.
+// Issued from inline asm on purpose: hipcc tracks the builtin form as a pending LDS write and
+// then drains it (s_waitcnt vmcnt(0)) in front of the next ds_read of ANY address, which
+// serialises a double-buffered pipeline (seen in the ISA; cdna_hip_programming.md 5.7).  An asm
+// DMA is invisible to that bookkeeping: completion is awaited explicitly with dma_wait_all()
+// followed by a barrier before any wave reads the tile.  M0 is saved/restored inside the
+// statement (compiler-reserved register).
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void e2t_lds_void;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long long)(e2t_lds_void*)p;
+}
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(m) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // wave-level reductions (64 lanes) via shuffles
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -290,9 +290,13 @@ __global__ void k_final_state(const bf16_t* Yext, int ldy, const float* Cs, cons
     const int len = lens[b];
     bf16_t h = 0; float c = 0.f;
     if (len > 0) {
-        const int t = d ? 0 : len - 1;
+        const int t = d ? 0 : len - 1;             // time index of the direction's last processed step
         h = Yext[((size_t)(t + 1) * B + b) * ldy + d * H8 + u];
-        c = Cs[((size_t)t * B + b) * (2 * H) + d * H + u];
+        // lane-native c save (lstm.hip): processing step len-1, tile (rt, ut), lane (fq, frow), component u&3
+        const int RT = (B + 15) >> 4, UT = (H + 15) >> 4;
+        const size_t tile = ((size_t)((len - 1) * 2 + d) * RT + (b >> 4)) * UT + (u >> 4);
+        const int lane = (((u & 15) >> 2) << 4) + (b & 15);
+        c = Cs[(tile * 64 + lane) * 4 + (u & 3)];
     }
     h0[(size_t)b * ldh0 + r] = h;
     c0[(size_t)b * 2 * H + r] = c;

@@ -7,11 +7,22 @@
 //
 // Tile: 128 x 128 x 64 per 256-thread workgroup (4 waves as 2x2, each wave a
 // 64x64 patch = 4x4 MFMA 16x16x32 tiles, 64 fp32 accumulators per lane).
-// LDS image: [128 rows][8 x 16-B chunks] per operand with the chunk index
-// XOR-swizzled by (row & 7): conflict-free for both the ds_write_b128 staging
-// pattern and the ds_read_b128 fragment pattern (checked against the gfx950
-// lane-group table, MI355X_MICROARCH.md "LDS").  Global->register->LDS staging
-// with the next tile's loads issued before the current tile's MFMAs (T14).
+// Staging: direct-to-LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave
+// instruction), two LDS buffers, ONE barrier per K tile: tile t+1 is in flight
+// while tile t is multiplied.  LDS image per operand: [128 rows][8 x 16-B
+// chunks] with the chunk index XOR-swizzled by (row & 7).  The DMA writes LDS
+// linearly (wave base + lane*16), so the swizzle is applied to the per-lane
+// SOURCE address and again on the fragment read (cdna_hip_programming.md rule
+// 21); the 8 lanes of a row still cover the same 128 B, so coalescing is kept.
+// Conflict-free for ds_read_b128 against the gfx950 lane-group table.
+// Rows beyond M/N are clamped to the last valid row (their products land in
+// output rows/columns that are never stored); a K tail (K % 64 != 0) is staged
+// through registers with zero fill.
+//
+// Split-K (grid.y): weight-gradient GEMMs have K = S*B (8704) but only a few
+// dozen output tiles; splitting K fills the 256 CUs and shortens each block's
+// serial K loop.  Partial tiles are combined with fp32 atomics into a
+// pre-zeroed C.
 //
 // Used for every non-recurrent matmul of the path (reference rows: conv a6,
 // LSTM input projections a7, aux head a8, vocab projection a9 and all their
@@ -23,6 +34,9 @@
 #define BN 128
 #define BK 64
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K, lda, ldb, ldc;
@@ -32,18 +46,17 @@ struct GemmArgs {
     float alpha;
     int flags;
     DropCfg drop; int ld_logical;
+    float* last_col_out;       // if set: column N-1 of the product goes to last_col_out[row] instead of C
+    int splits;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
 
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs p) {
-    __shared__ uint4 sA[BM * 8];      // 16 KB
-    __shared__ uint4 sB[BN * 8];      // 16 KB
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
+    __shared__ uint4 smem[4 * BM * 8];       // [buf][A|B][128 rows][8 chunks] = 64 KiB, ONE object
 
-    // XCD-aware tile order: consecutive tile ids (sharing an A row-panel) are
-    // spread by the dispatcher over the 8 XCDs (block b -> XCD b%8); remap so
-    // each XCD walks a contiguous run of tiles and re-reads its panels from
-    // its own L2 (cdna_hip_programming.md T1, bijective form).
+    // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): each XCD walks a
+    // contiguous run of tiles so an A row-panel is re-read from that XCD's own L2.
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const int nwg = ntm * ntn;
     int bid = blockIdx.x;
@@ -51,12 +64,20 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // walk N fastest inside a panel of rows
     const int tm = bid / ntn, tn = bid % ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // K range of this split (in full 64-wide tiles; the zero-filled tail belongs to the last split)
+    const int nfull = p.K / BK;
+    const bool has_tail = (p.K % BK) != 0;
+    const int per = (nfull + p.splits - 1) / p.splits;
+    const int t0 = blockIdx.y * per;
+    const int t1 = min(nfull, t0 + per);
+    const bool my_tail = has_tail && (blockIdx.y == p.splits - 1);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -64,46 +85,35 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging map: thread -> (row = tid/8 + 32*i, chunk = tid%8), i = 0..3
-    const int srow = tid >> 3, schunk = tid & 7;
-    uint4 ra[4], rb[4];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto load_tile = [&](int k0) {
-        const int kk = k0 + schunk * 8;
-        const bool kin = kk < p.K;                   // K is a multiple of 8 by contract
+    // DMA map: wave w, instruction i (0..3) fills rows (w*4+i)*8 .. +8 of an operand tile;
+    // lane -> (row = base + lane/8, physical chunk = lane%8), source chunk = physical ^ (row&7).
+    const int drow = lane >> 3, dpc = lane & 7;
+    auto issue = [&](int t, int buf) {
+        const int k0 = t * BK;
+        uint4* sa = smem + buf * 2048;
+        uint4* sb = sa + 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            const int gm = m0 + r, gn = n0 + r;
-            ra[i] = (kin && gm < p.M) ? *(const uint4*)(p.A + (size_t)gm * p.lda + kk) : zero4;
-            rb[i] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
+            const int rb = (wave * 4 + i) * 8;
+            const int r = rb + drow;
+            const int c = dpc ^ (r & 7);
+            const int gm = min(m0 + r, p.M - 1), gn = min(n0 + r, p.N - 1);
+            dma16_to_lds(p.A + (size_t)gm * p.lda + k0 + c * 8, lds_addr_of(sa + rb * 8));
+            dma16_to_lds(p.B + (size_t)gn * p.ldb + k0 + c * 8, lds_addr_of(sb + rb * 8));
         }
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            sA[swz(r, schunk)] = ra[i];
-            sB[swz(r, schunk)] = rb[i];
-        }
-    };
-
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
     const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    auto compute = [&](int buf) {
+        const uint4* sa = smem + buf * 2048;
+        const uint4* sb = sa + 1024;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             bf16x8 fa[4], fb[4];
             const int ch = kb * 4 + fq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint4 va = sA[swz(wm + i * 16 + frow, ch)];
-                uint4 vb = sB[swz(wn + i * 16 + frow, ch)];
+                uint4 va = sa[swz(wm + i * 16 + frow, ch)];
+                uint4 vb = sb[swz(wn + i * 16 + frow, ch)];
                 fa[i] = *(bf16x8*)&va;
                 fb[i] = *(bf16x8*)&vb;
             }
@@ -113,7 +123,35 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    int cur = 0;
+    if (t0 < t1) issue(t0, 0);
+    for (int t = t0; t < t1; ++t) {
+        dma_wait_all();                                        // tile t has landed (only tile t is in flight here)
+        __syncthreads();                                       // ... for every wave; and buf[cur^1] is free again
+        if (t + 1 < t1) issue(t + 1, cur ^ 1);
+        compute(cur);
+        cur ^= 1;
+    }
+    if (my_tail) {
+        // register-staged, zero-filled K tail into the same swizzled image
         __syncthreads();
+        const int srow = tid >> 3, schunk = tid & 7;
+        const int kk = nfull * BK + schunk * 8;
+        const bool kin = kk < p.K;
+        uint4* sa = smem + cur * 2048;
+        uint4* sb = sa + 1024;
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            const int gm = m0 + r, gn = n0 + r;
+            sa[swz(r, schunk)] = (kin && gm < p.M) ? *(const uint4*)(p.A + (size_t)gm * p.lda + kk) : zero4;
+            sb[swz(r, schunk)] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
+        }
+        __syncthreads();
+        compute(cur);
     }
 
     // epilogue.  C/D map of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
@@ -121,6 +159,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs p) {
     const bool accum = p.flags & E2T_GEMM_ACCUMULATE;
     const bool relu = p.flags & E2T_GEMM_RELU;
     const bool dodrop = (p.flags & E2T_GEMM_DROPOUT) && p.drop.rate > 0.f;
+    const bool atomic = p.splits > 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -134,6 +173,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs p) {
                 const int gn = n0 + wn + j * 16 + frow;
                 if (gn >= p.N) continue;
                 float v = acc[i][j][r] * p.alpha;
+                if (p.last_col_out && gn == p.N - 1) {
+                    if (atomic) atomicAdd(p.last_col_out + gm, v); else p.last_col_out[gm] = v;
+                    continue;
+                }
+                if (atomic) { atomicAdd((float*)p.C + (size_t)gm * p.ldc + gn, v); continue; }
                 if (p.bias) v += p.bias[gn];
                 if (relu) v = fmaxf(v, 0.f);
                 if (p.mask_src) v = (p.mask_src[(size_t)gm * p.ld_mask + gn] & 0x7FFF) != 0 ? v : 0.f;   // kept & active
@@ -155,13 +199,14 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     E2T_CHECK_ARG(A && B && C);
     E2T_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
     E2T_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
-    E2T_CHECK_ARG(lda >= K && ldb >= K && ldc >= N);
+    E2T_CHECK_ARG(lda >= K && ldb >= K);
     E2T_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0);
     if (M == 0 || N == 0) return E2T_OK;
     GemmArgs p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = 1.0f;
+    p.splits = 1;
     if (ep) {
         p.bias = ep->bias;
         p.mask_src = (const bf16_t*)ep->relu_bwd_src; p.ld_mask = ep->ld_relu_bwd_src;
@@ -170,10 +215,21 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
         p.flags = ep->flags;
         p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;
         p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : N;
+        p.last_col_out = ep->last_col_out;
         E2T_CHECK_ARG(!((p.flags & E2T_GEMM_OUT_BF16) && (p.flags & E2T_GEMM_ACCUMULATE)));
     }
+    E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(ntm * ntn), dim3(256), 0, (hipStream_t)stream, p);
+    if (ep && (ep->flags & E2T_GEMM_SPLITK)) {
+        // plain products only: partial sums meet in a pre-zeroed fp32 C through atomics
+        E2T_CHECK_ARG(!p.bias && !p.mask_src && !p.lens && !(p.flags & (E2T_GEMM_OUT_BF16 | E2T_GEMM_RELU | E2T_GEMM_DROPOUT)));
+        const int nfull = K / BK, tiles = ntm * ntn;
+        int s = (768 + tiles - 1) / tiles;             // aim at ~3 workgroups per CU
+        if (s > nfull / 4) s = nfull / 4;              // keep >= 4 K tiles per split
+        if (s < 1) s = 1;
+        p.splits = s;
+    }
+    hipLaunchKernelGGL(k_gemm_nt, dim3(ntm * ntn, p.splits), dim3(256), 0, (hipStream_t)stream, p);
     E2T_LAUNCH_CHECK();
     return E2T_OK;
 }

@@ -7,129 +7,377 @@
 // the whole sequence replays from a hipGraph.  Layers of a bidirectional stack
 // are strictly serial (layer l+1 at t=0 needs layer l's backward direction at
 // t=0, produced last), so the only concurrency is {fwd,bwd} x batch x units,
-// which is exactly the grid: (unit tiles of 16, row tiles of 16, directions).
+// which is exactly the grid: (unit tiles of 16, row blocks of 64, directions).
 //
-// Forward step, per wave (64 lanes): a 16-row x 16-unit patch, four MFMA
-// 16x16x32 accumulators (one per gate i,j,f,o) so every lane ends up holding
-// all four pre-activations of its (row, unit) cells: the gate nonlinearities,
-// cell update, dropout and the bf16 store are lane-local.  A operand = h_{t-1}
-// rows gathered straight from the layer's bf16 output array (per-row time
-// index => tf.reverse_sequence and variable lengths cost nothing); B operand =
-// W_h pre-packed in MFMA fragment order so each load is one coalesced 1-KiB
-// wave transaction served from the XCD-local L2.
+// A step is latency-bound (0.66 GFLOP), so the kernel is built to pay ONE memory
+// round trip: a 256-thread workgroup owns 64 rows x 16 units; the W_h tile for
+// those units (all four gates, pre-packed in MFMA fragment order so it is one
+// linear stream) is DMA'd into LDS with global_load_lds by all four waves, each
+// wave's own h_{t-1} rows and the epilogue operands (Gx, c_{t-1}) are requested
+// into registers at the same time, then a single wait + barrier, then the MFMAs
+// read B fragments conflict-free from LDS (ds_read_b128, lane-linear image).
+// Every lane ends up holding all four gate pre-activations of its (row, unit)
+// cells, so nonlinearities, cell update, dropout and stores are lane-local.
+// h_{t-1} rows are gathered straight from the layer's bf16 output array with a
+// per-row time index, so tf.reverse_sequence and ragged lengths cost nothing.
 //
-// Backward step: dh_rec = dG_{t+1} . W_h^T (K = 4H) for a 16x16 patch, then
-// the full LSTM cell backward for those cells (dG_t in bf16 for the later
+// Backward step: dh_rec = dG_{t+1} . W_h^T (K = 4H) for the same 64x16 patch,
+// then the LSTM cell backward for those cells (dG_t in bf16 for the later
 // weight-gradient GEMMs, dc carried in fp32).  dW_h / dW_x are NOT accumulated
-// per step: they are two large GEMMs over all steps afterwards (better MFMA
-// utilisation).
+// per step: they are large split-K GEMMs over all steps afterwards (SURVEY.md
+// 7.3 item 3).
 #include "common.h"
 #include "ecog2txt_hip.h"
+#include <stdlib.h>
 
-struct LstmFwdArgs {
-    const float* Gx;        // [S*B][ndir*H*4]  fp32, (dir, unit, gate) interleaved, bias included
-    const bf16_t* WhF;      // [ndir][4 gates][UT][KB][64 lanes][8]  fragment-packed W_h
-    bf16_t* Yext;           // [(S+2)*B][ldy]   time block tau = t+1; blocks 0 / S+1 = initial h / zero
-    bf16_t* Ydrop;          // [S*B][ldy] or null
-    float* Cs;              // [S*B][ndir*H]
-    float* Gs;              // [S*B][ndir*H][4] post-activation gates (i,j,f,o)
-    const int* lens;        // [B]
-    const float* c0;        // [B][ndir*H] or null
-    int S, B, H, H8, ndir, ldy, UT, KB, step;
-    float forget_bias;
-    DropCfg drop;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+extern __shared__ __attribute__((aligned(16))) uint4 lstm_smem[];
+
+// ---------------------------------------------------------------------------
+// Ownership (identical in the forward and backward step kernels):
+//   workgroup = (unit tile ut of 16 units, row block of 64 utterances, direction);
+//   8 waves: waves 0-3 each own the 16-utterance tile rt = row_block*4 + w (MFMA + cell update),
+//   all 8 waves issue the operand DMA (a step moves ~124 KiB into the CU and is bound by how many
+//   1-KiB wave transactions the CU keeps in flight: 8 issuing waves ~2x 4, LDS-DMA ~2x register loads).
+//   MFMA roles: A operand = weight fragment (rows = units), B operand = state fragment
+//   (columns = utterances), so D[i][j]: j = lane&15 = utterance, i = (lane>>4)*4 + r = unit.
+//   => lane (frow, fq) owns utterance b = rt*16 + frow and the FOUR CONSECUTIVE units
+//      u0 .. u0+3, u0 = ut*16 + fq*4.
+// Saved per-cell state is "lane-native", indexed by PROCESSING STEP s (not by time):
+//   Gs[((((s*ndir + dir)*RT + rt)*UT + ut)*4 + r)*64 + lane]  float4 = (i, j, f, o) of unit u0 + r
+//   Cs[ (((s*ndir + dir)*RT + rt)*UT + ut)*64 + lane ]         float4 = c of units u0 .. u0+3
+// so every save/restore is a fully coalesced 1-KiB wave transaction and needs no time index.
+//
+// LDS image of one K chunk of `kch` k-blocks (32 k each), in 16-B units:
+//   W section : [NG gates][kch][64 lanes]                 MFMA fragment order (linear copy of the packed image)
+//   S section : [4 row tiles][npair][2 row halves][64]    state rows, 8 rows x 128 B per DMA instruction,
+//               16-B chunk position XOR-swizzled by (row & 7) on the SOURCE side (DMA writes LDS linearly)
+//               -> conflict-free ds_read_b128 fragment reads, full 128-B lines on the global side.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ size_t native_tile(int s, int dir, int rt, int ut, int ndir, int RT, int UT) {
+    return ((size_t)(s * ndir + dir) * RT + rt) * UT + ut;
+}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * fast_rcp(__expf(2.0f * x) + 1.0f); }
+
+__device__ __forceinline__ float drop_scale_k(float rate, unsigned long long key, unsigned stream, unsigned long long idx) {
+    if (rate <= 0.0f) return 1.0f;
+    unsigned long long ctr = idx >> 2;
+    unsigned r[4];
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), stream, 0u, (unsigned)key, (unsigned)(key >> 32), r);
+    unsigned v = r[idx & 3ull] >> 8;
+    unsigned thresh = (unsigned)(rate * 16777216.0f);
+    return v >= thresh ? 1.0f / (1.0f - rate) : 0.0f;
+}
+// scales for the 4 consecutive logical elements e0..e0+3: one Philox evaluation when they share a
+// counter (e0 % 4 == 0, the common case), else four
+__device__ __forceinline__ void drop_scale4(float rate, unsigned long long key, unsigned stream, unsigned long long e0, float (&sc)[4]) {
+    const unsigned thresh = (unsigned)(rate * 16777216.0f);
+    const float keep = 1.0f / (1.0f - rate);
+    if ((e0 & 3ull) == 0) {
+        unsigned long long ctr = e0 >> 2;
+        unsigned r[4];
+        philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), stream, 0u, (unsigned)key, (unsigned)(key >> 32), r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[i] = (r[i] >> 8) >= thresh ? keep : 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[i] = drop_scale_k(rate, key, stream, e0 + i);
+    }
+}
+// streaming (non-temporal) stores for outputs nobody re-reads soon
+__device__ __forceinline__ void nt_store_f4(float* p, float a, float b, float c, float d) {
+    __builtin_nontemporal_store((f32x4){a, b, c, d}, (f32x4*)p);
+}
+__device__ __forceinline__ void nt_store_bf4(bf16_t* p, bf16_t a, bf16_t b, bf16_t c, bf16_t d) {
+    unsigned long long v = (unsigned long long)a | ((unsigned long long)b << 16) | ((unsigned long long)c << 32) | ((unsigned long long)d << 48);
+    __builtin_nontemporal_store(v, (unsigned long long*)p);
+}
+__device__ __forceinline__ float4 ld4(const float* p, bool vec, int n) {
+    if (vec) return *(const float4*)p;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n > 0) v.x = p[0]; if (n > 1) v.y = p[1]; if (n > 2) v.z = p[2]; if (n > 3) v.w = p[3];
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, float4 v, bool vec, int n) {
+    if (vec) { *(float4*)p = v; return; }
+    if (n > 0) p[0] = v.x; if (n > 1) p[1] = v.y; if (n > 2) p[2] = v.z; if (n > 3) p[3] = v.w;
+}
+
+// geometry shared by host and device
+struct StepGeom {
+    int kch;        // k-blocks per LDS chunk (even, or == KB when single chunk)
+    int nch;        // number of chunks
+    int npair;      // ceil(kch / 2)
+    int bufsz;      // 16-B units per chunk buffer
+    int nbuf;       // 1 or 2
 };
+__host__ __device__ inline StepGeom step_geom(int KB, int NG, int extra16 /* 16-B units outside the chunk buffers */) {
+    // one k-block costs NG KiB (weights) + 4 KiB (4 state tiles); 160 KiB LDS per CU
+    const int per_kb = NG * 64 + 4 * 64;                 // 16-B units
+    const int budget = (160 * 1024) / 16 - extra16;
+    StepGeom g;
+    int kb_pad = (KB + 1) & ~1;
+    if (kb_pad * per_kb <= budget) { g.kch = KB; g.nch = 1; g.nbuf = 1; }
+    else {
+        int k = (budget / 2) / per_kb; k &= ~1; if (k < 2) k = 2;
+        g.kch = k; g.nch = (KB + k - 1) / k; g.nbuf = 2;
+    }
+    g.npair = (g.kch + 1) / 2;
+    g.bufsz = NG * g.kch * 64 + 4 * g.npair * 128;
+    return g;
+}
 
-__global__ __launch_bounds__(64) void k_lstm_step_fwd(LstmFwdArgs p) {
-    const int lane = threadIdx.x;
-    const int ut = blockIdx.x, rt = blockIdx.y, dir = blockIdx.z;
-    const int s = p.step, B = p.B, H = p.H;
+// issue the DMA instructions of one chunk.  Division-free work split over the 8 waves:
+//   state rows : wave w owns (row tile w>>1, row half w&1) -> one source row pointer per lane, all k pairs;
+//   weights    : NG*kc fragments of 1 KiB; wave w takes gate w % NG and every (8/NG)-th k-block.
+template <int NG>
+__device__ __forceinline__ void issue_chunk(const uint4* wsrc /* [NG][KB][64] base for (dir, ut) */, size_t wgate_stride16, int KB,
+                                            const bf16_t* srow, int c, uint4* buf, const StepGeom& G, int wave, int lane) {
+    const int kb0 = c * G.kch, kc = min(G.kch, KB - kb0);
+    const int npr = (kc + 1) >> 1;
+    uint4* ssec = buf + NG * G.kch * 64;
+    {
+        const int g = wave % NG, i0 = wave / NG, istep = 8 / NG;       // NG is 4 or 1: compile-time
+        for (int i = i0; i < kc; i += istep)
+            dma16_to_lds(wsrc + g * wgate_stride16 + (size_t)(kb0 + i) * 64 + lane, lds_addr_of(buf + (g * G.kch + i) * 64));
+    }
+    const int rtl = wave >> 1, hh = wave & 1;
+    const int lrow = hh * 8 + (lane >> 3);
+    const bf16_t* src = srow + (size_t)((kb0 >> 1 << 3) + ((lane & 7) ^ (lrow & 7))) * 8;     // 16-B chunk, XOR-swizzled source
+    uint4* dst = ssec + ((rtl * G.npair) * 2 + hh) * 64;
+    for (int pp = 0; pp < npr; ++pp)
+        dma16_to_lds(src + (size_t)pp * 64, lds_addr_of(dst + pp * 128));
+}
+// state fragment (MFMA B operand) of k-block kbl of tile rtl for lane (frow, fq)
+__device__ __forceinline__ bf16x8 state_frag(const uint4* ssec, const StepGeom& G, int rtl, int kbl, int frow, int fq) {
+    const int cidx = (kbl & 1) * 4 + fq;
+    uint4 v = ssec[((rtl * G.npair + (kbl >> 1)) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8 + (cidx ^ (frow & 7))];
+    return *(bf16x8*)&v;
+}
+
+// One chunk of the recurrent product for this wave's 16-utterance tile: acc[g] += W_g(16 units x K) . state(K x 16).
+// Walks the chunk by k-block PAIRS with pure pointer increments (weights: +128 slots per pair and gate;
+// state: +128 slots per pair, even/odd k-block = swizzled position / position ^ 4) and requests the next
+// pair's fragments from LDS before the current pair's MFMAs.
+template <int NG>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NG], const uint4* buf, const StepGeom& G, int kc, int rtl, int lane) {
     const int frow = lane & 15, fq = lane >> 4;
-
-    // ---- A operand: h_{t-1} rows (16 rows x K), gathered per row -------------
-    const int ab = rt * 16 + frow;                    // batch row this lane loads for
-    const bf16_t* arow = nullptr;
-    if (ab < B) {
-        const int len = p.lens[ab];
-        // The backward direction starts from a zero state at its first step; the ext
-        // block it would read (position t = len) is only re-zeroed for THIS batch at a
-        // later launch, so it must not be read here.  The forward direction's first
-        // step reads block 0 (initial state: zeros for the encoder, h0 for the decoder).
-        if (s < len && !(dir == 1 && s == 0)) {
-            const int t = dir ? (len - 1 - s) : s;
-            const int tau_prev = dir ? (t + 2) : t;   // ext index of h_{t-1} in processing order
-            arow = p.Yext + ((size_t)tau_prev * B + ab) * p.ldy + dir * p.H8;
+    const uint4* wp = buf + lane;                                           // gate g at wp + g*kch*64
+    const int gs = G.kch * 64;
+    const uint4* sp = buf + NG * gs + ((rtl * G.npair) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8;
+    const int pe = fq ^ (frow & 7), po = pe ^ 4;
+    const int npr = kc >> 1;
+    uint4 se, so, we[NG], wo[NG];
+    if (npr > 0) {
+        se = sp[pe]; so = sp[po];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { we[g] = wp[g * gs]; wo[g] = wp[g * gs + 64]; }
+    }
+    for (int pp = 0; pp < npr; ++pp) {
+        uint4 nse = se, nso = so, nwe[NG], nwo[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { nwe[g] = we[g]; nwo[g] = wo[g]; }
+        if (pp + 1 < npr) {
+            sp += 128; wp += 128;
+            nse = sp[pe]; nso = sp[po];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { nwe[g] = wp[g * gs]; nwo[g] = wp[g * gs + 64]; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&we[g], *(bf16x8*)&se, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&wo[g], *(bf16x8*)&so, acc[g], 0, 0, 0);
+        se = nse; so = nso;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { we[g] = nwe[g]; wo[g] = nwo[g]; }
+    }
+    if (kc & 1) {                                                            // odd tail k-block (even position of the last pair)
+        const uint4* wl = buf + lane + (size_t)(kc - 1) * 64;
+        const uint4 sl = (buf + NG * gs + ((rtl * G.npair + npr) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8)[pe];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint4 w = wl[g * gs];
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&w, *(bf16x8*)&sl, acc[g], 0, 0, 0);
         }
     }
-    const bf16x8* wf = (const bf16x8*)p.WhF + ((size_t)(dir * 4) * p.UT + ut) * p.KB * 64 + lane;
-    const size_t gate_stride = (size_t)p.UT * p.KB * 64;
+}
+
+struct LstmFwdArgs {
+    const float* Gx;        // [S*B][ndir*H*4]  fp32, (dir, unit, gate) interleaved, bias included (row-major, time-major rows)
+    const bf16_t* WhF;      // [ndir][4 gates][UT][KB][64 lanes][8]  fragment-packed W_h
+    bf16_t* Yext;           // [(S+3)*B][ldy]   time block tau = t+1; block 0 = initial h, S+1.. = zero slack
+    bf16_t* Ydrop;          // [S*B][ldy] or null
+    float* Cs;              // lane-native, see above
+    float* Gs;              // lane-native, see above
+    const int* lens;        // [B]
+    const float* c0;        // [B][ndir*H] or null
+    int S, B, H, H8, ndir, ldy, UT, KB, step, ablate;
+    float forget_bias;
+    DropCfg drop;
+    long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
+};
+
+__global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile map: the dispatcher places workgroup id on XCD id % 8 (observed, speed only);
+    // XCD x owns the unit tiles ut == x (mod 8) for every row block and direction, so its slice of
+    // the W_h image (1/8 of it) stays resident in that XCD's L2 for all S steps of the sequence.
+    const int RB = (p.B + 63) >> 6, RT = (p.B + 15) >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ut = (slot / (RB * p.ndir)) * 8 + xcd;
+    if (ut >= p.UT) return;
+    const int rem = slot % (RB * p.ndir);
+    const int rb = rem % RB, dir = rem / RB;
+    const int s = p.step, B = p.B, H = p.H, KB = p.KB;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int NH = p.ndir * H;
+    const StepGeom G = step_geom(KB, 4, 4 * 256);
+    uint4* gx_lds = lstm_smem + (size_t)G.nbuf * G.bufsz;          // [4 tiles][2 halves][2 chunk halves][64]
+    long long ts[8];
+#define STAMP(i) do { if (p.dbg) ts[i] = clock64(); } while (0)
+    STAMP(0);
+
+    // ---- round trip 0 (tiny, L2-resident): length of the row this lane FETCHES for (wave w moves the
+    //      state / Gx rows of tile w>>1, row half w&1) and of the row it UPDATES (compute waves)
+    const int fb = (rb * 4 + (wave >> 1)) * 16 + (wave & 1) * 8 + (lane >> 3);
+    const int flen = (fb < B) ? p.lens[fb] : 0;
+    const bool compute = wave < 4;
+    const int rt = rb * 4 + (wave & 3);
+    const int b = rt * 16 + frow;
+    const int len = (b < B) ? p.lens[b] : 0;
+    const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
+    asm volatile("" :: "v"(flen), "v"(len) : "memory");       // pin hipcc's wait for these words HERE
+    STAMP(1);
+
+    // state-row / Gx-row sources of the fetched row.  Rows that are inactive or beyond B read ext block 0
+    // (finite; their results are discarded); the backward direction's FIRST step must see a zero state and
+    // reads the all-zero slack block S+1 (the block at position t = len is only re-zeroed later this pass).
+    const bf16_t* srow;
+    const float* gxrow;
+    {
+        const bool act = (fb < B) && s < flen;
+        const int gb = min(fb, B - 1);
+        const int tt = dir ? (flen - 1 - s) : s;
+        size_t tau = 0, srb = gb;
+        if (act) {
+            if (dir == 1 && s == 0) { tau = (size_t)p.S + 1; srb = 0; }
+            else tau = dir ? (tt + 2) : tt;
+        }
+        srow = p.Yext + (tau * B + srb) * p.ldy + dir * p.H8;
+        gxrow = p.Gx + (act ? (((size_t)tt * B + gb) * NH + dir * H) * 4 : 0);
+    }
+
+    // ---- round trip 1 (bulk, everything in flight together, issued by all 8 waves) -------------
+    const uint4* wsrc = (const uint4*)p.WhF + ((size_t)(dir * 4) * p.UT + ut) * KB * 64;
+    const size_t wgs = (size_t)p.UT * KB * 64;
+    if (!(p.ablate & 1)) {
+        issue_chunk<4>(wsrc, wgs, KB, srow, 0, lstm_smem, G, wave, lane);
+        if (G.nch > 1) issue_chunk<4>(wsrc, wgs, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
+    }
+    // Gx of the fetched rows: 8 rows x 256 B = two 8-row x 128-B instructions (unit halves)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const int gu = ut * 16 + ch * 8 + (lane & 7);                   // unit whose 4 gates this lane moves
+        dma16_to_lds(gxrow + (gu < H ? (size_t)gu * 4 : 0), lds_addr_of(gx_lds + (wave * 2 + ch) * 64));
+    }
+    const int u0 = ut * 16 + fq * 4;                  // first of this lane's 4 units
+    const bool vec = (H & 3) == 0;
+    const int nu = min(4, H - u0);
+    const bool active = compute && s < len;
+    const int t = dir ? (len - 1 - s) : s;
+    float4 cprev = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
+    if (active && nu > 0) {
+        if (s > 0) cprev = ((const float4*)p.Cs)[native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 64 + lane];
+        else if (p.c0) cprev = ld4(p.c0 + (size_t)b * NH + dir * H + u0, vec, nu);
+    }
+    STAMP(2);
 
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 4
-    for (int kb = 0; kb < p.KB; ++kb) {
-        const int k = kb * 32 + fq * 8;
-        bf16x8 a = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (arow && k < p.H8) a = *(const bf16x8*)(arow + k);
-        bf16x8 b0 = wf[(size_t)kb * 64];
-        bf16x8 b1 = wf[gate_stride + (size_t)kb * 64];
-        bf16x8 b2 = wf[2 * gate_stride + (size_t)kb * 64];
-        bf16x8 b3 = wf[3 * gate_stride + (size_t)kb * 64];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b3, acc[3], 0, 0, 0);
+    for (int c = 0; c < G.nch; c += 2) {
+        dma_wait_all();
+        STAMP(3);
+        __syncthreads();
+        STAMP(4);
+        if (compute && !(p.ablate & 4)) {
+            for (int cc = c; cc < min(c + 2, G.nch); ++cc) {
+                const uint4* buf = lstm_smem + (size_t)(cc & 1) * G.bufsz;
+                mma_chunk<4>(acc, buf, G, min(G.kch, KB - cc * G.kch), wave, lane);
+            }
+        }
+        if (c + 2 < G.nch) {
+            __syncthreads();                         // everyone is done reading both buffers
+            issue_chunk<4>(wsrc, wgs, KB, srow, c + 2, lstm_smem, G, wave, lane);
+            if (c + 3 < G.nch) issue_chunk<4>(wsrc, wgs, KB, srow, c + 3, lstm_smem + G.bufsz, G, wave, lane);
+        }
     }
+    STAMP(5);
+    if (!compute) return;                            // loader waves are done
 
-    // ---- lane-local cell update: lane owns unit u for rows fq*4 + r ----------
-    const int u = ut * 16 + frow;
-    if (u >= H) return;
-    const int NH = p.ndir * H;
+    // ---- lane-local cell update for (utterance b, units u0..u0+3) ------------------------------
+    if (b >= B || nu <= 0) return;
+    if (active) {
+        const size_t m = (size_t)t * B + b;
+        const size_t e0 = m * NH + dir * H + u0;      // logical element index (dropout key)
+        float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.Ydrop && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e0, dsc);
+        float hv[4], cv[4], hd[4];
+        const float cp[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
+        const uint4* gxt = gx_lds + ((wave * 2 + (frow >> 3)) * 2) * 64 + (frow & 7) * 8;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = rt * 16 + fq * 4 + r;
-        if (b >= B) continue;
-        const int len = p.lens[b];
-        if (s < len) {
-            const int t = dir ? (len - 1 - s) : s;
-            const size_t m = (size_t)t * B + b;
-            const float4 gx = *(const float4*)(p.Gx + (m * NH + dir * H + u) * 4);
-            const float gi = sigmoidf_(acc[0][r] + gx.x);
-            const float gj = tanhf_(acc[1][r] + gx.y);
-            const float gf = sigmoidf_(acc[2][r] + gx.z + p.forget_bias);
-            const float go = sigmoidf_(acc[3][r] + gx.w);
-            float cprev;
-            if (s > 0) {
-                const int tp = dir ? (t + 1) : (t - 1);
-                cprev = p.Cs[((size_t)tp * B + b) * NH + dir * H + u];
-            } else {
-                cprev = p.c0 ? p.c0[(size_t)b * NH + dir * H + u] : 0.f;
-            }
-            const float c = gf * cprev + gi * gj;
-            const float h = go * tanhf_(c);
-            p.Cs[m * NH + dir * H + u] = c;
-            *(float4*)(p.Gs + (m * NH + dir * H + u) * 4) = make_float4(gi, gj, gf, go);
-            p.Yext[((size_t)(t + 1) * B + b) * p.ldy + dir * p.H8 + u] = f2bf(h);
-            if (p.Ydrop) {
-                const float sc = drop_scale(p.drop, (unsigned long long)(m * NH + dir * H + u));
-                p.Ydrop[m * p.ldy + dir * p.H8 + u] = f2bf(h * sc);
-            }
-        } else if (s < p.S) {
-            // padded position s of this utterance: emit zeros (dynamic_rnn semantics)
-            const size_t m = (size_t)s * B + b;
-            p.Yext[((size_t)(s + 1) * B + b) * p.ldy + dir * p.H8 + u] = 0;
-            if (p.Ydrop) p.Ydrop[m * p.ldy + dir * p.H8 + u] = 0;
+        for (int r = 0; r < 4; ++r) {
+            const int cidx = fq * 4 + r;              // unit index within the tile
+            uint4 raw = gxt[(cidx >> 3) * 64 + (cidx & 7)];
+            const float4 gx = *(float4*)&raw;
+            const float gi = fsigmoid(acc[0][r] + gx.x);
+            const float gj = ftanh(acc[1][r] + gx.y);
+            const float gf = fsigmoid(acc[2][r] + gx.z + p.forget_bias);
+            const float go = fsigmoid(acc[3][r] + gx.w);
+            cv[r] = gf * cp[r] + gi * gj;
+            hv[r] = go * ftanh(cv[r]);
+            nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi, gj, gf, go);
+            hd[r] = hv[r] * dsc[r];
+        }
+        STAMP(6);
+        ((float4*)p.Cs)[tile * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        bf16_t* yp = p.Yext + ((size_t)(t + 1) * B + b) * p.ldy + dir * p.H8 + u0;
+        bf16_t* ydp = p.Ydrop ? p.Ydrop + m * p.ldy + dir * p.H8 + u0 : nullptr;
+        if (nu == 4) {
+            *(ushort4*)yp = make_ushort4(f2bf(hv[0]), f2bf(hv[1]), f2bf(hv[2]), f2bf(hv[3]));     // re-read next step: keep in L2
+            if (ydp) nt_store_bf4(ydp, f2bf(hd[0]), f2bf(hd[1]), f2bf(hd[2]), f2bf(hd[3]));
+        } else {
+            for (int r = 0; r < nu; ++r) { yp[r] = f2bf(hv[r]); if (ydp) ydp[r] = f2bf(hd[r]); }
+        }
+        STAMP(7);
+        if (p.dbg && lane == 0) {
+            long long* o = p.dbg + ((size_t)(blockIdx.x * 4 + wave)) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+        }
+    } else if (s < p.S) {
+        // padded position s of this utterance: emit zeros (dynamic_rnn semantics)
+        bf16_t* yp = p.Yext + ((size_t)(s + 1) * B + b) * p.ldy + dir * p.H8 + u0;
+        bf16_t* ydp = p.Ydrop ? p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0 : nullptr;
+        if (nu == 4) {
+            *(ushort4*)yp = make_ushort4(0, 0, 0, 0);
+            if (ydp) *(ushort4*)ydp = make_ushort4(0, 0, 0, 0);
+        } else {
+            for (int r = 0; r < nu; ++r) { yp[r] = 0; if (ydp) ydp[r] = 0; }
         }
     }
 }
 
 struct LstmBwdArgs {
     const bf16_t* WhB;      // [ndir][UT][KB4][64][8]  fragment-packed W_h^T operand (K = 4H gate columns)
-    bf16_t* dG;             // [S*B][lddg]  (dir, unit, gate) interleaved, bf16
+    bf16_t* dG;             // [(S+1)*B][lddg]  (dir, unit, gate) interleaved, bf16, time-major rows; block S = zero slack
     const float* dY;        // [S*B][lddy] gradient wrt the (dropped) layer output, or null
-    const float* Gs; const float* Cs;
+    const float* Gs; const float* Cs;     // lane-native saves of the forward pass
     const int* lens;
     const float* c0;        // [B][ndir*H] or null
     const float* dh_final;  // [B][ndir*H] or null: gradient wrt final state h
@@ -141,96 +389,145 @@ struct LstmBwdArgs {
     DropCfg drop;
 };
 
-__global__ __launch_bounds__(64) void k_lstm_step_bwd(LstmBwdArgs p) {
-    const int lane = threadIdx.x;
-    const int ut = blockIdx.x, rt = blockIdx.y, dir = blockIdx.z;
-    const int s = p.step, B = p.B, H = p.H;
+__global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RB = (p.B + 63) >> 6, RT = (p.B + 15) >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ut = (slot / (RB * p.ndir)) * 8 + xcd;          // same XCD-aware map as the forward kernel
+    if (ut >= p.UT) return;
+    const int rem = slot % (RB * p.ndir);
+    const int rb = rem % RB, dir = rem / RB;
+    const int s = p.step, B = p.B, H = p.H, KB = p.KB4;
     const int frow = lane & 15, fq = lane >> 4;
     const int K4 = 4 * H;
-
-    // ---- A operand: dG of the step processed just before in the sweep (s+1) --
-    const int ab = rt * 16 + frow;
-    const bf16_t* arow = nullptr;
-    if (ab < B) {
-        const int len = p.lens[ab];
-        if (s + 1 < len) {
-            const int tn = dir ? (len - 2 - s) : (s + 1);
-            arow = p.dG + ((size_t)tn * B + ab) * p.lddg + (size_t)dir * K4;
-        }
-    }
-    const bf16x8* wf = (const bf16x8*)p.WhB + ((size_t)dir * p.UT + ut) * p.KB4 * 64 + lane;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int kb = 0; kb < p.KB4; ++kb) {
-        const int k = kb * 32 + fq * 8;
-        bf16x8 a = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (arow && k < K4) a = *(const bf16x8*)(arow + k);
-        bf16x8 b = wf[(size_t)kb * 64];
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-    }
-
-    const int u = ut * 16 + frow;
-    if (u >= H) return;
     const int NH = p.ndir * H;
+    const StepGeom G = step_geom(KB, 1, 0);
+
+    const int fb = (rb * 4 + (wave >> 1)) * 16 + (wave & 1) * 8 + (lane >> 3);       // row this lane fetches for
+    const int flen = (fb < B) ? p.lens[fb] : 0;
+    const bool compute = wave < 4;
+    const int rt = rb * 4 + (wave & 3);
+    const int b = rt * 16 + frow;
+    const int len = (b < B) ? p.lens[b] : 0;
+    const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
+    asm volatile("" :: "v"(flen), "v"(len) : "memory");
+
+    // state side: dG of the step processed just before in the sweep (s+1); rows without a successor
+    // step (last valid step, inactive, beyond B) read the all-zero slack block S
+    size_t trow = (size_t)p.S * B;
+    if (fb < B && s + 1 < flen) trow = (size_t)(dir ? (flen - 2 - s) : (s + 1)) * B + fb;
+    const bf16_t* srow = p.dG + trow * p.lddg + (size_t)dir * K4;
+    const uint4* wsrc = (const uint4*)p.WhB + ((size_t)dir * p.UT + ut) * KB * 64;
+    issue_chunk<1>(wsrc, 0, KB, srow, 0, lstm_smem, G, wave, lane);
+    if (G.nch > 1) issue_chunk<1>(wsrc, 0, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
+
+    // ---- epilogue operands (lane-native, coalesced), requested in the same round trip ----------
+    const bool active = compute && s >= 0 && s < len;
+    const int t = dir ? (len - 1 - s) : s;
+    const int u0 = ut * 16 + fq * 4;
+    const bool vec = (H & 3) == 0;
+    const int nu = min(4, H - u0);
+    const size_t su = (size_t)b * NH + dir * H + u0;          // state index [B][ndir*H]
+    float4 g4[4], c_t, cprev, dyv, dcin, dhf;
+    c_t = cprev = dyv = dcin = dhf = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = rt * 16 + fq * 4 + r;
-        if (b >= B) continue;
-        const int len = p.lens[b];
-        const size_t su = (size_t)b * NH + dir * H + u;          // state index [B][ndir*H]
-        if (s < 0) {
-            // pseudo-step -1: gradient into the initial state (decoder <- encoder seam)
-            if (len > 0) {
-                p.dh0[su] = acc[r];
-                p.dc0[su] = p.dc_carry[su];
-            } else {
-                p.dh0[su] = p.dh_final ? p.dh_final[su] : 0.f;
-                p.dc0[su] = p.dc_final ? p.dc_final[su] : 0.f;
-            }
-            continue;
+    for (int r = 0; r < 4; ++r) g4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t m = active ? ((size_t)t * B + b) : 0;
+    if (active && nu > 0) {
+        const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g4[r] = ((const float4*)p.Gs)[(tile * 4 + r) * 64 + lane];
+        c_t = ((const float4*)p.Cs)[tile * 64 + lane];
+        if (s > 0) cprev = ((const float4*)p.Cs)[native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 64 + lane];
+        else if (p.c0) cprev = ld4(p.c0 + su, vec, nu);
+        if (p.dY) dyv = ld4(p.dY + m * p.lddy + dir * p.H8 + u0, nu == 4, nu);
+        if (s == len - 1) {
+            if (p.dh_final) dhf = ld4(p.dh_final + su, vec, nu);
+            if (p.dc_final) dcin = ld4(p.dc_final + su, vec, nu);
+        } else {
+            dcin = ld4(p.dc_carry + su, vec, nu);
         }
-        if (s < len) {
-            const int t = dir ? (len - 1 - s) : s;
-            const size_t m = (size_t)t * B + b;
-            const size_t e = m * NH + dir * H + u;
-            float dh = acc[r];
-            if (p.dY) {
-                float g = p.dY[m * p.lddy + dir * p.H8 + u];
-                g *= drop_scale(p.drop, (unsigned long long)e);
-                dh += g;
-            }
-            const bool last = (s == len - 1);
-            if (last && p.dh_final) dh += p.dh_final[su];
-            float dc_in = last ? (p.dc_final ? p.dc_final[su] : 0.f) : p.dc_carry[su];
-            const float4 g4 = *(const float4*)(p.Gs + e * 4);
-            const float c_t = p.Cs[e];
-            float cprev;
-            if (s > 0) {
-                const int tp = dir ? (t + 1) : (t - 1);
-                cprev = p.Cs[((size_t)tp * B + b) * NH + dir * H + u];
-            } else {
-                cprev = p.c0 ? p.c0[su] : 0.f;
-            }
-            const float tc = tanhf_(c_t);
-            const float dct = dc_in + dh * g4.w * (1.f - tc * tc);
-            const float d_o = dh * tc * g4.w * (1.f - g4.w);
-            const float d_i = dct * g4.y * g4.x * (1.f - g4.x);
-            const float d_j = dct * g4.x * (1.f - g4.y * g4.y);
-            const float d_f = dct * cprev * g4.z * (1.f - g4.z);
-            ushort4 o;
-            o.x = f2bf(d_i); o.y = f2bf(d_j); o.z = f2bf(d_f); o.w = f2bf(d_o);
-            *(ushort4*)(p.dG + m * p.lddg + (size_t)dir * K4 + u * 4) = o;
-            p.dc_carry[su] = dct * g4.z;
-        } else if (s < p.S) {
-            const size_t m = (size_t)s * B + b;
-            *(ushort4*)(p.dG + m * p.lddg + (size_t)dir * K4 + u * 4) = make_ushort4(0, 0, 0, 0);
+    }
+
+    f32x4 accv[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int c = 0; c < G.nch; c += 2) {
+        dma_wait_all();
+        __syncthreads();
+        if (compute) {
+            for (int cc = c; cc < min(c + 2, G.nch); ++cc)
+                mma_chunk<1>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave, lane);
         }
+        if (c + 2 < G.nch) {
+            __syncthreads();
+            issue_chunk<1>(wsrc, 0, KB, srow, c + 2, lstm_smem, G, wave, lane);
+            if (c + 3 < G.nch) issue_chunk<1>(wsrc, 0, KB, srow, c + 3, lstm_smem + G.bufsz, G, wave, lane);
+        }
+    }
+    if (!compute) return;
+    const f32x4 acc = accv[0];
+
+    if (b >= B || nu <= 0) return;
+    if (s < 0) {
+        // pseudo-step -1: gradient into the initial state (decoder <- encoder seam)
+        float4 o_h, o_c;
+        if (len > 0) { o_h = make_float4(acc[0], acc[1], acc[2], acc[3]); o_c = ld4(p.dc_carry + su, vec, nu); }
+        else {
+            o_h = p.dh_final ? ld4(p.dh_final + su, vec, nu) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o_c = p.dc_final ? ld4(p.dc_final + su, vec, nu) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        st4(p.dh0 + su, o_h, vec, nu);
+        st4(p.dc0 + su, o_c, vec, nu);
+        return;
+    }
+    if (active) {
+        const size_t e0 = m * NH + dir * H + u0;
+        float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.dY && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e0, dsc);
+        const float ct[4] = {c_t.x, c_t.y, c_t.z, c_t.w}, cp[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
+        const float dy[4] = {dyv.x, dyv.y, dyv.z, dyv.w}, dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
+        const float dhfv[4] = {dhf.x, dhf.y, dhf.z, dhf.w};
+        bf16_t og[16]; float dcn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 g = g4[r];
+            const float dh = acc[r] + dhfv[r] + dy[r] * dsc[r];
+            const float tc = ftanh(ct[r]);
+            const float dct = dci[r] + dh * g.w * (1.f - tc * tc);
+            og[r * 4 + 3] = f2bf(dh * tc * g.w * (1.f - g.w));            // d_o
+            og[r * 4 + 0] = f2bf(dct * g.y * g.x * (1.f - g.x));          // d_i
+            og[r * 4 + 1] = f2bf(dct * g.x * (1.f - g.y * g.y));          // d_j
+            og[r * 4 + 2] = f2bf(dct * cp[r] * g.z * (1.f - g.z));        // d_f
+            dcn[r] = dct * g.z;
+        }
+        bf16_t* gp = p.dG + m * p.lddg + (size_t)dir * K4 + u0 * 4;
+        if (nu == 4) {
+            uint4 lo, hi;
+            lo.x = og[0] | ((unsigned)og[1] << 16); lo.y = og[2] | ((unsigned)og[3] << 16);
+            lo.z = og[4] | ((unsigned)og[5] << 16); lo.w = og[6] | ((unsigned)og[7] << 16);
+            hi.x = og[8] | ((unsigned)og[9] << 16); hi.y = og[10] | ((unsigned)og[11] << 16);
+            hi.z = og[12] | ((unsigned)og[13] << 16); hi.w = og[14] | ((unsigned)og[15] << 16);
+            ((uint4*)gp)[0] = lo; ((uint4*)gp)[1] = hi;
+        } else {
+            for (int i = 0; i < nu * 4; ++i) gp[i] = og[i];
+        }
+        st4(p.dc_carry + su, make_float4(dcn[0], dcn[1], dcn[2], dcn[3]), vec, nu);
+    } else if (s < p.S) {
+        bf16_t* gp = p.dG + ((size_t)s * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4;
+        if (nu == 4) { ((uint4*)gp)[0] = make_uint4(0, 0, 0, 0); ((uint4*)gp)[1] = make_uint4(0, 0, 0, 0); }
+        else { for (int i = 0; i < nu * 4; ++i) gp[i] = 0; }
     }
 }
 
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+static int set_big_lds(const void* fn) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return E2T_ERR_HIP; }
+    return E2T_OK;
+}
+
 extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext,
                                 void* Ydrop, float* Cs, float* Gs, const int32_t* lens, const float* c0,
                                 int step_begin, int step_end, void* stream) {
@@ -238,17 +535,23 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && d->ldy % 8 == 0 && d->ldy >= d->ndir * ((d->H + 7) / 8) * 8);
     E2T_CHECK_ARG(0 <= step_begin && step_begin <= step_end && step_end <= d->S);
+    static bool attr_done = false;
+    if (!attr_done) { if (int rc = set_big_lds((const void*)k_lstm_step_fwd)) return rc; attr_done = true; }
     LstmFwdArgs p{};
     p.Gx = Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
     p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
+    { const char* e = getenv("E2T_LSTM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    dim3 grid(p.UT, (d->B + 15) / 16, d->ndir);
+    const StepGeom G = step_geom(p.KB, 4, 4 * 256);
+    const size_t lds = ((size_t)G.nbuf * G.bufsz + 4 * 256) * 16;
+    dim3 grid(8 * ((p.UT + 7) / 8) * ((d->B + 63) / 64) * d->ndir);      // XCD-major tile map, see kernel
     for (int s = step_begin; s < step_end; ++s) {
         p.step = s;
-        hipLaunchKernelGGL(k_lstm_step_fwd, grid, dim3(64), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_lstm_step_fwd, grid, dim3(512), lds, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
@@ -262,6 +565,8 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
     E2T_CHECK_ARG((dh0 == nullptr) == (dc0 == nullptr));
+    static bool attr_done = false;
+    if (!attr_done) { if (int rc = set_big_lds((const void*)k_lstm_step_bwd)) return rc; attr_done = true; }
     LstmBwdArgs p{};
     p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
     p.dh_final = dh_final; p.dc_final = dc_final; p.dc_carry = dc_carry; p.dh0 = dh0; p.dc0 = dc0;
@@ -269,10 +574,12 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     p.lddg = lddg; p.lddy = lddy;
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    dim3 grid(p.UT, (d->B + 15) / 16, d->ndir);
+    const StepGeom G = step_geom(p.KB4, 1, 0);
+    const size_t lds = (size_t)G.nbuf * G.bufsz * 16;
+    dim3 grid(8 * ((p.UT + 7) / 8) * ((d->B + 63) / 64) * d->ndir);      // XCD-major tile map, see kernel
     for (int s = d->S - 1; s >= (dh0 ? -1 : 0); --s) {
         p.step = s;
-        hipLaunchKernelGGL(k_lstm_step_bwd, grid, dim3(64), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_lstm_step_bwd, grid, dim3(512), lds, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;

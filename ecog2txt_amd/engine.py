@@ -295,8 +295,6 @@ class _FFStack:
             ws['actT'].append(t)
             ws['dT'].append(_bf(self.sizes[i + 1], Mk, device=dev))
         ws['out'] = _f32(M, self.sizes[-1], device=dev)
-        ws['ones'] = _bf(8, Mk, device=dev)
-        ws['ones'][0, :M] = 1.0
         return ws
 
     def fwd(self, ws, x_ptr, src, train):
@@ -336,13 +334,13 @@ class _FFStack:
             for (r0, n, k0) in blocks:
                 lib.e2t_transpose_bf16(xp + 2 * k0, xld, M, n, ws['actT'][i].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
             if last:
+                # dW^T = d^T . x  [out][in]; the ones row of actT makes column `in` the bias gradient
                 e.gemm(ws['dT'][i].data_ptr(), Mk, ws['actT'][i].data_ptr(), Mk,
-                       st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin, Mk)
-                e.gemm(ws['ones'].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
-                       st.ptr('%s%d.b' % (self.prefix, i), st.g), fout, 1, fout, Mk)
+                       st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin + 1, Mk, splitk=True,
+                       last_col_out=st.ptr('%s%d.b' % (self.prefix, i), st.g))
             else:
                 e.gemm(ws['actT'][i].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
-                       st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk)
+                       st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk, splitk=True)
             kin = self.in_ld if i == 0 else r8(fin)
             if i > 0:
                 dp = ws['dpre'][i - 1]
@@ -391,11 +389,12 @@ class _Lstm:
         nd, Hh = self.ndir, self.H
         ws = dict(S=S, B=B, M=M, Mk=Mk)
         ws['Gx'] = _f32(M, self.N4, device=dev)
-        ws['Yext'] = _bf((S + 2) * B, self.ldy, device=dev)
+        ws['Yext'] = _bf((S + 3) * B, self.ldy, device=dev)       # block 0 = initial state, S+1.. = zero slack
         ws['Ydrop'] = _bf(M, self.ldy, device=dev)
-        ws['Cs'] = _f32(M, nd * Hh, device=dev)
-        ws['Gs'] = _f32(M, nd * Hh, 4, device=dev)
-        ws['dG'] = _bf(M, r8(self.N4), device=dev)
+        RT, UT = ceil_div(B, 16), ceil_div(Hh, 16)
+        ws['Cs'] = _f32(S, nd, RT, UT, 64, 4, device=dev)          # lane-native per-step saves (lstm.hip)
+        ws['Gs'] = _f32(S, nd, RT, UT, 4, 64, 4, device=dev)
+        ws['dG'] = _bf(M + B, r8(self.N4), device=dev)              # block S = zero slack (rows without successor)
         ws['dGT'] = _bf(self.N4, Mk, device=dev)
         ws['YT'] = _bf(nd, Hh, Mk, device=dev)
         ws['xT'] = _bf(self.D + 1, Mk, device=dev)
@@ -441,14 +440,14 @@ class _Lstm:
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
         e.gemm(ws['xT'].data_ptr(), Mk, ws['dGT'].data_ptr(), Mk, st.ptr(self.name + '.Wx', st.g), self.N4,
-               self.D + 1, self.N4, Mk)
+               self.D + 1, self.N4, Mk, splitk=True)
         for dd in range(nd):
             # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction)
             row_off = (2 * B if dd == 1 else 0) * self.ldy
             lib.e2t_transpose_bf16(ws['Yext'].data_ptr() + 2 * (row_off + dd * self.H8), self.ldy, M, Hh,
                                    ws['YT'][dd].data_ptr(), Mk, e.stream)
             e.gemm(ws['YT'][dd].data_ptr(), Mk, ws['dGT'].data_ptr() + 2 * dd * 4 * Hh * Mk, Mk,
-                   st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, Mk)
+                   st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, Mk, splitk=True)
         if d_in_ptr is not None:
             if d_in_bf16_mask is not None:
                 e.gemm(ws['dG'].data_ptr(), r8(self.N4), self.WxB.data_ptr(), r8(self.N4), d_in_ptr, d_in_ld, M, self.D,
@@ -532,11 +531,13 @@ class Seq2SeqEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
-             drop=None, mask_src=None, row_lens=None, alpha=1.0):
+             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None):
         ep = H.GemmEpilogue()
         ep.bias = bias
         ep.alpha = alpha
+        ep.last_col_out = last_col_out
         flags = (H.GEMM_RELU if relu else 0) | (H.GEMM_OUT_BF16 if out_bf16 else 0) | (H.GEMM_ACCUMULATE if accumulate else 0)
+        flags |= H.GEMM_SPLITK if splitk else 0
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
             ep.drop_rate, ep.drop_stream, ep.drop_ld = drop[0], drop[1], drop[2]
@@ -709,43 +710,80 @@ class Seq2SeqEngine:
         lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr() + 8, st)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ws, train=True):
+    def backward_stages(self, ws):
+        """[(callable, [(a,b) grad ranges finished by it])]: vocab projection + decoder first, then one
+        stage per encoder layer (top down); the last stage also covers the subject's conv front-end."""
+        store = self.store
+        nl = len(self.enc)
+        stages = []
+
+        def rng_of(names):
+            out = []
+            for nm in names:
+                a, b = store.seg_range(nm)
+                if out and out[-1][1] == a:
+                    out[-1][1] = b
+                else:
+                    out.append([a, b])
+            return [tuple(r) for r in out]
+        head = [n for n in store.order if n.startswith('proj') or n.startswith('dec.')]
+        stages.append((lambda train: self._bwd_head(ws, train), rng_of(head)))
+        for l in range(nl - 1, -1, -1):
+            names = [n for n in store.order if n.startswith('enc%d.' % l)]
+            if self.spec.aux_layer == l:
+                names = [n for n in store.order if n.startswith('aux')] + names
+            if l == 0:
+                names = names + ['conv%s.W' % ws['sid']]
+            stages.append((lambda train, l=l: self._bwd_enc(ws, l, train), rng_of(names)))
+        return stages
+
+    def backward(self, ws, train=True, after_stage=None):
+        ws['have_dy'] = [False] * len(self.enc)
+        for i, (fn, ranges) in enumerate(self.backward_stages(ws)):
+            fn(train)
+            if after_stage:
+                after_stage(i, ranges)
+
+    def _bwd_head(self, ws, train):
         s, store = self.spec, self.store
-        B, L, S, M, Md, Mk = ws['B'], ws['L'], ws['S'], ws['M'], ws['Md'], ws['Mk']
+        Md = ws['Md']
         st = self.stream
-        sid = ws['sid']
+        store.g.zero_()          # split-K partials and the embedding scatter meet in zeroed fp32 through atomics
         # vocabulary projection
         self.proj.bwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'], ws['dHd'].data_ptr(), r8(s.dec_rnn), False, train)
         # decoder BPTT (+ gradient into the encoder's final state)
         self.dec.bwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), r8(s.dec_rnn), train,
                      ws['de'].data_ptr(), self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
-        store.view('dec.emb', store.g).zero_()
         dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
         lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), Md, s.dec_embed,
                           store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), st)
-        # encoder, top layer first
+
+    def _bwd_enc(self, ws, l, train):
+        s, store = self.spec, self.store
+        M, Mk = ws['M'], ws['Mk']
+        st = self.stream
         nl = len(self.enc)
-        have_dy = [False] * nl
-        for l in range(nl - 1, -1, -1):
-            lay, lw = self.enc[l], ws['enc'][l]
-            if ws['use_aux'] and s.aux_layer == l:
-                self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, have_dy[l], train)
-                have_dy[l] = True
-            x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
-            dY = ws['dY'][l].data_ptr() if have_dy[l] else None
-            fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
-            if l > 0:
-                lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy, **fin)
-                have_dy[l - 1] = True
-            else:
-                keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
-                lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dEpre'].data_ptr(), self.F8,
-                        d_in_bf16_mask=(ws['E'].data_ptr(), self.F8), d_in_alpha=keep, **fin)
+        have_dy = ws['have_dy']
+        lay, lw = self.enc[l], ws['enc'][l]
+        if ws['use_aux'] and s.aux_layer == l:
+            self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, have_dy[l], train)
+            have_dy[l] = True
+        x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
+        dY = ws['dY'][l].data_ptr() if have_dy[l] else None
+        fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
+        if l > 0:
+            lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy, **fin)
+            have_dy[l - 1] = True
+            return
+        keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
+        lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dEpre'].data_ptr(), self.F8,
+                d_in_bf16_mask=(ws['E'].data_ptr(), self.F8), d_in_alpha=keep, **fin)
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
+        sid = ws['sid']
         lib.e2t_transpose_bf16(ws['dEpre'].data_ptr(), self.F8, M, s.enc_embed, ws['dEpreT'].data_ptr(), Mk, st)
         lib.e2t_transpose_bf16(ws['A'].data_ptr(), ws['Kc8'], M, ws['Kc'], ws['AT'].data_ptr(), Mk, st)
         self.gemm(ws['AT'].data_ptr(), Mk, ws['dEpreT'].data_ptr(), Mk, store.ptr('conv%s.W' % sid, store.g), s.enc_embed,
-                  ws['Kc'] + 1, s.enc_embed, Mk)
+                  ws['Kc'] + 1, s.enc_embed, Mk, splitk=True)
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self, sid=None):
@@ -783,32 +821,48 @@ class Seq2SeqEngine:
         return [tuple(r) for r in ranges]
 
     # ------------------------------------------------------------------ steps
-    def train_step(self, ws, use_graph=True, sync_grads=None):
-        """One optimisation step on the batch staged in ws['X'], ws['Y'], ws['auxT']."""
+    def train_step(self, ws, use_graph=True, sync=None):
+        """One optimisation step on the batch staged in ws['X'], ws['Y'], ws['auxT'].
+
+        sync: optional parallel.GradSync; each backward stage's gradient ranges are all-reduced
+        asynchronously right after the stage is enqueued, and Adam waits for all of them."""
         if self._packed != 'p':
             self.pack('p')
+        dp = sync is not None and sync.world > 1
+        self.grad_scale = sync.grad_scale if dp else 1.0
+
+        def after(i, ranges):
+            for a, b in ranges:
+                sync.allreduce_range(a, b)
         if not use_graph:
             self.forward(ws, train=True)
-            self.backward(ws, train=True)
-            if sync_grads:
-                sync_grads()
+            self.backward(ws, train=True, after_stage=after if dp else None)
+            if dp:
+                sync.wait()
             self.adam_step(ws['sid'])
             return
-        key = 'train_dp' if sync_grads else 'train'
+        key = 'train_dp' if dp else 'train'
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture
             self.forward(ws, train=True)
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
-            if sync_grads:
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
-                    self.forward(ws, train=True)
-                    self.backward(ws, train=True)
-                with torch.cuda.graph(g2):
+            if dp:
+                stages = self.backward_stages(ws)
+                graphs = []
+                for i, (fn, ranges) in enumerate(stages):
+                    gi = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gi):
+                        if i == 0:
+                            self.forward(ws, train=True)
+                            ws['have_dy'] = [False] * len(self.enc)
+                        fn(True)
+                    graphs.append((gi, ranges))
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
                     self.adam_step(ws['sid'])
-                g = (g1, g2)
+                g = (graphs, ga)
             else:
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
@@ -817,10 +871,14 @@ class Seq2SeqEngine:
                     self.adam_step(ws['sid'])
                 g = (g1,)
             ws['graph'][key] = g
-        g[0].replay()
-        if sync_grads:
-            sync_grads()
-            g[1].replay()
+        if not dp:
+            g[0].replay()
+            return
+        for gi, ranges in g[0]:
+            gi.replay()
+            after(0, ranges)
+        sync.wait()
+        g[1].replay()
 
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()

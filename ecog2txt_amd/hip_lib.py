@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip.so')
 
-GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT = 1, 2, 4, 8
+GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK = 1, 2, 4, 8, 16
 
 
 class Dropout(C.Structure):
@@ -21,7 +21,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('relu_bwd_src', C.c_void_p), ('ld_relu_bwd_src', C.c_int),
                 ('row_lens', C.c_void_p), ('rows_per_step', C.c_int), ('alpha', C.c_float), ('flags', C.c_int),
                 ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong), ('drop_step', C.c_void_p),
-                ('drop_stream', C.c_uint), ('drop_ld', C.c_int)]
+                ('drop_stream', C.c_uint), ('drop_ld', C.c_int), ('last_col_out', C.c_void_p)]
 
 
 class LstmDesc(C.Structure):

@@ -72,6 +72,7 @@ int e2t_decoder_tokens(const int32_t* y, int B, int L, int eos, int32_t* U, int3
 #define E2T_GEMM_OUT_BF16 2
 #define E2T_GEMM_ACCUMULATE 4      /* fp32 output only */
 #define E2T_GEMM_DROPOUT 8
+#define E2T_GEMM_SPLITK 16         /* plain fp32 product; C must be pre-zeroed (partials meet by atomics) */
 typedef struct e2t_gemm_epilogue {
     const float* bias;             /* [N] or NULL */
     const void* relu_bwd_src;      /* bf16 [M][ld]: out = src != 0 ? out : 0 (ReLU/dropout backward) */
@@ -81,6 +82,8 @@ typedef struct e2t_gemm_epilogue {
     float alpha;
     int flags;
     float drop_rate; unsigned long long drop_seed; const int32_t* drop_step; unsigned drop_stream; int drop_ld;
+    float* last_col_out;           /* fp32 [M] or NULL: column N-1 of the product is written here instead of C
+                                      (a ones row appended to B turns it into the bias gradient) */
 } e2t_gemm_epilogue;
 int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep /* host pointer or NULL */, void* stream);
@@ -98,12 +101,14 @@ typedef struct e2t_lstm_desc {
     float drop_rate; unsigned long long drop_seed; const int32_t* drop_step; unsigned drop_stream;
 } e2t_lstm_desc;
 /* Gx [S*B][ndir*H*4] fp32 (dir,unit,gate interleaved; bias folded in); WhF: e2t_pack_frag images
- * [ndir][4][UT][KB]; Yext bf16 [(S+2)*B][ldy] (time block t+1); Ydrop bf16 [S*B][ldy] or NULL;
- * Cs fp32 [S*B][ndir*H]; Gs fp32 [S*B][ndir*H][4]; c0 fp32 [B][ndir*H] or NULL.
+ * [ndir][4][UT][KB]; Yext bf16 [(S+3)*B][ldy] (time block t+1; block 0 = initial state, blocks S+1, S+2
+ * all-zero slack that no kernel writes); Ydrop bf16 [S*B][ldy] or NULL; Cs / Gs: lane-native per-step saves,
+ * S*ndir*ceil(B/16)*ceil(H/16)*64 float4 resp. x4 (layout in csrc/lstm.hip); c0 fp32 [B][ndir*H] or NULL.
  * Runs steps [step_begin, step_end). */
 int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
                      float* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
-/* BPTT over all S steps (+ pseudo-step -1 when dh0/dc0 are given).  dG bf16 [S*B][lddg] out. */
+/* BPTT over all S steps (+ pseudo-step -1 when dh0/dc0 are given).  dG bf16 [(S+1)*B][lddg] out
+ * (block S is all-zero slack that no kernel writes). */
 int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
                      const float* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
                      const float* dc_final, float* dc_carry, float* dh0, float* dc0, void* stream);

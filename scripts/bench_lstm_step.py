@@ -1,0 +1,62 @@
+"""Micro-benchmark: forward/backward recurrence of one encoder layer (S graph-captured step launches)."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec, ceil_div
+from ecog2txt_amd.hip_lib import lib
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+kw, B, T, L = bench.CONFIGS[cfg]
+spec = NetSpec(**kw)
+eng = Seq2SeqEngine(spec, seed=1)
+eng.init_params(0)
+ws = eng.workspace(401, B, T, L)
+eng.set_batch(ws, bench.synth_batch(kw, B, T, L, 1))
+eng.forward(ws, train=True); eng.backward(ws, train=True)
+torch.cuda.synchronize()
+S = ws['S']
+def timeit(fn, n, reps=20):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * n)
+lay, lw = eng.enc[1], ws['enc'][1]
+d = lay.desc(lw, True)
+def fwd():
+    lib.e2t_lstm_seq_fwd(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(), lw['Ydrop'].data_ptr(),
+                         lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, 0, S, eng.stream)
+def bwd():
+    lib.e2t_lstm_seq_bwd(C.byref(d), lay.WhB.data_ptr(), lw['dG'].data_ptr(), lw['dG'].shape[1], ws['dY'][1].data_ptr(), lay.ldy,
+                         lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None,
+                         lw['dc_carry'].data_ptr(), None, None, eng.stream)
+for ab in [int(x) for x in os.environ.get('ABLATIONS', '0').split(',')]:
+    os.environ['E2T_LSTM_ABLATE'] = str(ab)
+    print('ablate %3d: fwd %.2f us/step   bwd %.2f us/step' % (ab, timeit(fwd, S), timeit(bwd, S)), flush=True)
+# ---- per-phase timeline of ONE step (s_memtime stamps written by the kernel) ----
+if os.environ.get('TIMELINE'):
+    import numpy as np
+    dbg = torch.zeros(256 * 4 * 8, dtype=torch.int64, device='cuda')
+    os.environ['E2T_LSTM_ABLATE'] = '0'
+    os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
+    lib.e2t_lstm_seq_fwd(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(), lw['Ydrop'].data_ptr(),
+                         lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, 5, 6, eng.stream)
+    torch.cuda.synchronize()
+    del os.environ['E2T_LSTM_DBG']
+    t = dbg.cpu().numpy().reshape(-1, 8)
+    t = t[t[:, 0] > 0]
+    base = t[:, 0].min()
+    rel = (t - base) / 100.0            # s_memtime ticks at 100 MHz -> us
+    names = ['entry', 'lens ready', 'bulk issued', 'dma landed', 'barrier passed', 'mma done', 'math done', 'stores issued']
+    print('waves recorded', len(t))
+    for i, nme in enumerate(names):
+        print('  %-15s  min %.2f  median %.2f  max %.2f us' % (nme, rel[:, i].min(), np.median(rel[:, i]), rel[:, i].max()))
+    dd = np.diff(rel, axis=1)
+    print('  per-wave phase durations (median):', ' | '.join('%s %.2f' % (names[i + 1], np.median(dd[:, i])) for i in range(7)))

@@ -46,7 +46,7 @@ def test_gemm_nt_plain(hl, M, N, K):
     A = rng.standard_normal((M, K))
     Bm = rng.standard_normal((N, K))            # asymmetric operands catch transposed outputs
     a, b = dev_bf16(A), dev_bf16(Bm)
-    c = torch.full((M, N), 7.0, device='cuda')
+    c = torch.full((M, N), 7.0, dtype=torch.float32, device='cuda')
     hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N, K, None, st())
     torch.cuda.synchronize()
     want = round_bf16(A) @ round_bf16(Bm).T
@@ -147,7 +147,7 @@ def test_softmax_ce(hl):
     tg = torch.tensor(tgt, dtype=torch.int32, device='cuda')
     ln = torch.tensor(lens, dtype=torch.int32, device='cuda')
     ntok = torch.tensor([int(lens.sum())], dtype=torch.int32, device='cuda')
-    rl = torch.zeros(M, device='cuda'); cr = torch.zeros(M, device='cuda')
+    rl = torch.zeros(M, dtype=torch.float32, device='cuda'); cr = torch.zeros(M, dtype=torch.float32, device='cuda')
     pr = torch.zeros(M, dtype=torch.int32, device='cuda')
     dl = torch.zeros(M, r8(V), dtype=torch.bfloat16, device='cuda')
     hl.lib.e2t_softmax_ce(lg.data_ptr(), V, M, V, tg.data_ptr(), ln.data_ptr(), B, ntok.data_ptr(), 0.7, rl.data_ptr(),
@@ -183,3 +183,23 @@ def test_adam_ema_matches_oracle(hl):
     torch.cuda.synchronize()
     np.testing.assert_allclose(host(p), P['w'], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(host(ema), state['ema']['w'], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('M,N,K', [(101, 200, 8704), (401, 130, 2560), (5, 14, 1040), (130, 70, 40)])
+def test_gemm_splitk_and_bias_column(hl, M, N, K):
+    """Weight-gradient form: split-K partials meet by atomics in a zeroed C; the last column of the
+    product (B's ones row) goes to a separate bias-gradient vector."""
+    rng = np.random.default_rng(K + M)
+    A = rng.standard_normal((M, K))
+    Bm = rng.standard_normal((N + 1, K))
+    Bm[N] = 1.0
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    c = torch.zeros((M, N), dtype=torch.float32, device='cuda')
+    colv = torch.zeros(M, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue()
+    ep.alpha, ep.flags, ep.last_col_out = 1.0, hl.GEMM_SPLITK, colv.data_ptr()
+    hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N + 1, K, C.byref(ep), st())
+    torch.cuda.synchronize()
+    want = round_bf16(A) @ round_bf16(Bm).T
+    np.testing.assert_allclose(host(c), want[:, :N], rtol=1e-5, atol=2e-4 * np.sqrt(K))
+    np.testing.assert_allclose(host(colv), want[:, N], rtol=1e-5, atol=2e-4 * np.sqrt(K))

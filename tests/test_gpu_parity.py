@@ -1,10 +1,12 @@
 """Network-level parity: HIP path (through the C ABI) vs the bf16-emulating CPU oracle.
 
 Tolerances (stated per SURVEY.md 8d "within stated fp tolerance"):
- * losses: 2e-3 relative -- operands are bf16 on both sides at identical rounding points;
-   what remains is fp32-vs-fp64 accumulation and rare 1-ulp bf16 flips it causes.
- * gradients: 3e-2 of the tensor's max |g| (bf16 dG / dlogits quantisation noise is ~2^-9
-   per element and the flips are amplified through BPTT).
+ * losses: 2e-4 relative -- operands are bf16 on both sides at identical rounding points;
+   what remains is fp32-vs-fp64 accumulation and rare 1-ulp bf16 flips it causes
+   (measured on MI355X: 1e-6 .. 1e-5).
+ * gradients: 5e-3 of the tensor's max |g| (measured: 1e-6 .. 1.1e-3; the flips are
+   amplified through BPTT).  For scale, the bf16 path itself sits 3e-3 .. 8e-2 away from
+   the exact fp64 spec on the same tensors (scripts/diag_parity.py).
  * greedy word sequences: identical.
 """
 import numpy as np
@@ -16,8 +18,8 @@ from helpers import make_batch
 
 pytestmark = pytest.mark.gpu
 
-LOSS_RTOL = 2e-3
-GRAD_TOL = 3e-2
+LOSS_RTOL = 2e-4
+GRAD_TOL = 5e-3
 
 
 def build(spec_kw, B, T, L, seed=0, ragged=True, engine_seed=11):

@@ -14,7 +14,15 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 from oracle import seq2seq as O
 from helpers import tiny_spec, make_batch
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    """fp64 torch model; restore the default so other test modules are unaffected."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def tf_to_torch_lstm(kernel, bias, D, H, forget_bias):
