@@ -21,8 +21,9 @@
 //
 // Split-K (grid.y): weight-gradient GEMMs have K = S*B (8704) but only a few
 // dozen output tiles; splitting K fills the 256 CUs and shortens each block's
-// serial K loop.  Partial tiles are combined with fp32 atomics into a
-// pre-zeroed C.
+// serial K loop.  Partial tiles go to dense fp32 slabs in a caller-provided
+// workspace and are summed in fixed order by k_splitk_reduce (deterministic;
+// fp32 atomics were measured 5-10x slower: ~12 M atomics per GEMM).
 //
 // Used for every non-recurrent matmul of the path (reference rows: conv a6,
 // LSTM input projections a7, aux head a8, vocab projection a9 and all their
@@ -48,6 +49,7 @@ struct GemmArgs {
     DropCfg drop; int ld_logical;
     float* last_col_out;       // if set: column N-1 of the product goes to last_col_out[row] instead of C
     int splits;
+    float* slab;               // split-K partials [splits][M][N] fp32 (dense), reduced by k_splitk_reduce
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -154,44 +156,91 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
         compute(cur);
     }
 
-    // epilogue.  C/D map of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
+    // epilogue.  MFMA roles are (B-tile fragment, A-tile fragment), so D[i][j]: column j = lane&15 is the
+    // M row, rows (lane>>4)*4 + r are FOUR CONSECUTIVE N columns: every lane stores 16 B (fp32) / 8 B (bf16)
+    // per sub-tile instead of four scattered words, and bias / mask / dropout are fetched 4 at a time.
     const bool out_bf16 = p.flags & E2T_GEMM_OUT_BF16;
     const bool accum = p.flags & E2T_GEMM_ACCUMULATE;
     const bool relu = p.flags & E2T_GEMM_RELU;
     const bool dodrop = (p.flags & E2T_GEMM_DROPOUT) && p.drop.rate > 0.f;
     const bool atomic = p.splits > 1;
+    const int Nst = p.last_col_out ? p.N - 1 : p.N;                 // columns that go to C
+    const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
+    unsigned long long dkey = 0;
+    if (dodrop) dkey = p.drop.seed + (p.drop.step ? (unsigned long long)(*p.drop.step) : 0ull);
+    const unsigned dthresh = (unsigned)(p.drop.rate * 16777216.0f);
+    const float dkeep = dodrop ? 1.0f / (1.0f - p.drop.rate) : 1.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + wm + i * 16 + frow;
+        if (gm >= p.M) continue;
+        bool rowvalid = true;
+        if (p.lens) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gm = m0 + wm + i * 16 + fq * 4 + r;
-            if (gm >= p.M) continue;
-            bool rowvalid = true;
-            if (p.lens) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
+        for (int j = 0; j < 4; ++j) {
+            const int gn0 = n0 + wn + j * 16 + fq * 4;
+            if (gn0 >= p.N) continue;
+            float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + wn + j * 16 + frow;
-                if (gn >= p.N) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.last_col_out && gn == p.N - 1) {
-                    if (atomic) atomicAdd(p.last_col_out + gm, v); else p.last_col_out[gm] = v;
-                    continue;
-                }
-                if (atomic) { atomicAdd((float*)p.C + (size_t)gm * p.ldc + gn, v); continue; }
-                if (p.bias) v += p.bias[gn];
-                if (relu) v = fmaxf(v, 0.f);
-                if (p.mask_src) v = (p.mask_src[(size_t)gm * p.ld_mask + gn] & 0x7FFF) != 0 ? v : 0.f;   // kept & active
-                if (dodrop) v *= drop_scale(p.drop, (unsigned long long)gm * p.ld_logical + gn);
-                if (!rowvalid) v = 0.f;
-                if (out_bf16) {
-                    ((bf16_t*)p.C)[(size_t)gm * p.ldc + gn] = f2bf(v);
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (atomic) {
+                // split-K: dense partial slab (all N columns incl. the bias column); summed in fixed order later
+                float* c = p.slab + ((size_t)blockIdx.y * p.M + gm) * p.N + gn0;
+                const int nn = min(4, p.N - gn0);
+                if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int r = 0; r < nn; ++r) c[r] = v[r];
+                continue;
+            }
+            if (p.last_col_out && gn0 + 3 >= p.N - 1) p.last_col_out[gm] = v[p.N - 1 - gn0];
+            if (gn0 >= Nst) continue;
+            const int nv = min(4, Nst - gn0);
+            if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[gn0 + r]; }
+            if (relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            if (p.mask_src) {
+                const bf16_t* ms = p.mask_src + (size_t)gm * p.ld_mask + gn0;
+                for (int r = 0; r < nv; ++r) v[r] = (ms[r] & 0x7FFF) != 0 ? v[r] : 0.f;    // kept & active
+            }
+            if (dodrop) {
+                const unsigned long long e0 = (unsigned long long)gm * p.ld_logical + gn0;
+                if ((e0 & 3ull) == 0) {
+                    unsigned rr[4];
+                    const unsigned long long ctr = e0 >> 2;
+                    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), p.drop.stream, 0u, (unsigned)dkey, (unsigned)(dkey >> 32), rr);
+                    for (int r = 0; r < 4; ++r) v[r] *= ((rr[r] >> 8) >= dthresh) ? dkeep : 0.f;
                 } else {
-                    float* c = (float*)p.C + (size_t)gm * p.ldc + gn;
-                    *c = accum ? (*c + v) : v;
+                    for (int r = 0; r < nv; ++r) v[r] *= drop_scale(p.drop, e0 + r);
+                }
+            }
+            if (!rowvalid) { for (int r = 0; r < 4; ++r) v[r] = 0.f; }
+            if (out_bf16) {
+                bf16_t* c = (bf16_t*)p.C + (size_t)gm * p.ldc + gn0;
+                if (nv == 4 && (p.ldc & 3) == 0) *(ushort4*)c = make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+                else for (int r = 0; r < nv; ++r) c[r] = f2bf(v[r]);
+            } else {
+                float* c = (float*)p.C + (size_t)gm * p.ldc + gn0;
+                if (nv == 4 && vec_ok) {
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (accum) { const float4 old = *(const float4*)c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                    *(float4*)c = o;
+                } else {
+                    for (int r = 0; r < nv; ++r) c[r] = accum ? (c[r] + v[r]) : v[r];
                 }
             }
         }
     }
+}
+
+// C[m][n] (+)= sum_s slab[s][m][n] in fixed split order (deterministic); column N-1 -> last_col_out if set
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
+                                                        float* last_col_out, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = i / N, n = i - (size_t)m * N;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += slab[(size_t)s * M * N + i];
+    if (last_col_out && n == N - 1) { last_col_out[m] = acc; return; }
+    float* c = C + (size_t)m * ldc + n;
+    *c = accumulate ? (*c + acc) : acc;
 }
 
 extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -220,16 +269,24 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     }
     E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    if (ep && (ep->flags & E2T_GEMM_SPLITK)) {
-        // plain products only: partial sums meet in a pre-zeroed fp32 C through atomics
+    if (ep && (ep->flags & E2T_GEMM_SPLITK) && ep->splitk_ws) {
+        // plain products only: partial slabs in the caller's workspace, then one fixed-order reduction
         E2T_CHECK_ARG(!p.bias && !p.mask_src && !p.lens && !(p.flags & (E2T_GEMM_OUT_BF16 | E2T_GEMM_RELU | E2T_GEMM_DROPOUT)));
         const int nfull = K / BK, tiles = ntm * ntn;
-        int s = (768 + tiles - 1) / tiles;             // aim at ~3 workgroups per CU
-        if (s > nfull / 4) s = nfull / 4;              // keep >= 4 K tiles per split
+        int s = (512 + tiles - 1) / tiles;             // aim at ~2 workgroups per CU
+        if (s > nfull / 8) s = nfull / 8;              // keep >= 8 K tiles per split
+        const size_t per = (size_t)M * N * sizeof(float);
+        if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
         if (s < 1) s = 1;
         p.splits = s;
+        p.slab = (float*)ep->splitk_ws;
     }
     hipLaunchKernelGGL(k_gemm_nt, dim3(ntm * ntn, p.splits), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.splits > 1) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.slab, p.splits, M, N,
+                           (float*)C, ldc, p.last_col_out, (p.flags & E2T_GEMM_ACCUMULATE) ? 1 : 0);
+    }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
 }

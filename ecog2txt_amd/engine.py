@@ -499,6 +499,7 @@ class Seq2SeqEngine:
         self._pack_lists = {}
         self._ws = {}
         self._packed = None
+        self.splitk_ws = _f32(16 * 1024 * 1024, device=dev)          # 64 MiB of split-K partial slabs
         self.trainable = None         # None = everything; else set of segment names
 
     def init_params(self, seed=0):
@@ -537,7 +538,9 @@ class Seq2SeqEngine:
         ep.alpha = alpha
         ep.last_col_out = last_col_out
         flags = (H.GEMM_RELU if relu else 0) | (H.GEMM_OUT_BF16 if out_bf16 else 0) | (H.GEMM_ACCUMULATE if accumulate else 0)
-        flags |= H.GEMM_SPLITK if splitk else 0
+        if splitk:
+            flags |= H.GEMM_SPLITK
+            ep.splitk_ws, ep.splitk_ws_bytes = self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
             ep.drop_rate, ep.drop_stream, ep.drop_ld = drop[0], drop[1], drop[2]
@@ -748,7 +751,7 @@ class Seq2SeqEngine:
         s, store = self.spec, self.store
         Md = ws['Md']
         st = self.stream
-        store.g.zero_()          # split-K partials and the embedding scatter meet in zeroed fp32 through atomics
+        store.view('dec.emb', store.g).zero_()          # the embedding scatter-add accumulates by atomics
         # vocabulary projection
         self.proj.bwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'], ws['dHd'].data_ptr(), r8(s.dec_rnn), False, train)
         # decoder BPTT (+ gradient into the encoder's final state)

@@ -21,7 +21,8 @@ class GemmEpilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('relu_bwd_src', C.c_void_p), ('ld_relu_bwd_src', C.c_int),
                 ('row_lens', C.c_void_p), ('rows_per_step', C.c_int), ('alpha', C.c_float), ('flags', C.c_int),
                 ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong), ('drop_step', C.c_void_p),
-                ('drop_stream', C.c_uint), ('drop_ld', C.c_int), ('last_col_out', C.c_void_p)]
+                ('drop_stream', C.c_uint), ('drop_ld', C.c_int), ('last_col_out', C.c_void_p),
+                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_size_t)]
 
 
 class LstmDesc(C.Structure):

@@ -20,16 +20,18 @@ SHAPES = [  # (name, M, N, K, flags, out_bf16)
     ('square 4096        ', 4096, 4096, 4096, 0),
 ]
 st = torch.cuda.current_stream().cuda_stream
+wsbuf = torch.zeros(16 * 1024 * 1024, device='cuda')
 for name, M, N, K, flags in SHAPES:
     a = torch.randn(M, r8(K), device='cuda').to(torch.bfloat16)
     b = torch.randn(N, r8(K), device='cuda').to(torch.bfloat16)
     obf = bool(flags & H.GEMM_OUT_BF16)
     c = torch.zeros(M, r8(N), device='cuda', dtype=torch.bfloat16 if obf else torch.float32)
     ep = H.GemmEpilogue(); ep.alpha = 1.0; ep.flags = flags
+    ep.splitk_ws, ep.splitk_ws_bytes = wsbuf.data_ptr(), wsbuf.numel() * 4
     def run():
         lib.e2t_gemm_nt_bf16(a.data_ptr(), r8(K), b.data_ptr(), r8(K), c.data_ptr(), r8(N), M, N, r8(K), C.byref(ep), st)
     run(); torch.cuda.synchronize()
-    if not (flags & H.GEMM_SPLITK):
+    if True:
         ref = a.float() @ b.float().T
         err = (c.float()[:, :N] - ref).abs().max().item() / ref.abs().max().item()
     else:

@@ -194,10 +194,12 @@ def test_gemm_splitk_and_bias_column(hl, M, N, K):
     Bm = rng.standard_normal((N + 1, K))
     Bm[N] = 1.0
     a, b = dev_bf16(A), dev_bf16(Bm)
-    c = torch.zeros((M, N), dtype=torch.float32, device='cuda')
-    colv = torch.zeros(M, dtype=torch.float32, device='cuda')
+    c = torch.full((M, N), 3.0, dtype=torch.float32, device='cuda')      # must be overwritten, not accumulated
+    colv = torch.full((M,), 3.0, dtype=torch.float32, device='cuda')
     ep = hl.GemmEpilogue()
     ep.alpha, ep.flags, ep.last_col_out = 1.0, hl.GEMM_SPLITK, colv.data_ptr()
+    wsb = torch.zeros(8 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
     hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N + 1, K, C.byref(ep), st())
     torch.cuda.synchronize()
     want = round_bf16(A) @ round_bf16(Bm).T
