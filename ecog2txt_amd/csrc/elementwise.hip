@@ -201,6 +201,42 @@ __global__ __launch_bounds__(64) void k_pack_frag(const float* src, long sn, lon
     ((uint4*)dst)[((size_t)nt * KB + kb) * 64 + lane] = v;
 }
 
+// All operand images in ONE launch: a device table of descriptors, each owning a contiguous range of
+// 256-thread workgroups (prefix in `first_block`).  kind 0 = strided cast (one row x 256 columns per
+// workgroup), kind 1 = MFMA fragment image (4 fragments per workgroup).
+__global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, int ndesc, const float* base) {
+    // binary search for the descriptor that owns this workgroup (uniform)
+    int lo = 0, hi = ndesc - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1; }
+    const e2t_pack_desc d = descs[lo];
+    const int lb = bid - d.first_block;
+    const float* src = base + d.src_off;
+    bf16_t* dst = (bf16_t*)d.dst;
+    if (d.kind == 0) {
+        const int cb = (d.d1 + 255) / 256;                 // column blocks per row
+        const int r = lb / cb, c = (lb - r * cb) * 256 + threadIdx.x;
+        if (r < d.d0 && c < d.d1) dst[(size_t)r * d.ld + c] = f2bf(src[(size_t)r * d.s0 + (size_t)c * d.s1]);
+    } else {
+        const int KB = d.ld, lane = threadIdx.x & 63;
+        const int f = lb * 4 + (threadIdx.x >> 6);          // fragment index nt*KB + kb
+        const int NT = (d.d0 + 15) / 16;
+        if (f >= NT * KB) return;
+        const int nt = f / KB, kb = f - nt * KB;
+        const int n = nt * 16 + (lane & 15);
+        bf16_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kb * 32 + (lane >> 4) * 8 + j;
+            o[j] = (n < d.d0 && k < d.d1) ? f2bf(src[(size_t)n * d.s0 + (size_t)k * d.s1]) : (bf16_t)0;
+        }
+        uint4 v;
+        v.x = o[0] | ((unsigned)o[1] << 16); v.y = o[2] | ((unsigned)o[3] << 16);
+        v.z = o[4] | ((unsigned)o[5] << 16); v.w = o[6] | ((unsigned)o[7] << 16);
+        ((uint4*)dst)[(size_t)f * 64 + lane] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a9: decoder embedding gather (+FF dropout) and its scatter-add gradient
 // ---------------------------------------------------------------------------
@@ -292,11 +328,11 @@ __global__ void k_final_state(const bf16_t* Yext, int ldy, const float* Cs, cons
     if (len > 0) {
         const int t = d ? 0 : len - 1;             // time index of the direction's last processed step
         h = Yext[((size_t)(t + 1) * B + b) * ldy + d * H8 + u];
-        // lane-native c save (lstm.hip): processing step len-1, tile (rt, ut), lane (fq, frow), component u&3
+        // lane-native c save (lstm.hip): processing step len-1, tile (rt, ut), half (u&3)>>1, lane (fq, frow), component u&1
         const int RT = (B + 15) >> 4, UT = (H + 15) >> 4;
         const size_t tile = ((size_t)((len - 1) * 2 + d) * RT + (b >> 4)) * UT + (u >> 4);
         const int lane = (((u & 15) >> 2) << 4) + (b & 15);
-        c = Cs[(tile * 64 + lane) * 4 + (u & 3)];
+        c = Cs[((tile * 2 + ((u & 3) >> 1)) * 64 + lane) * 2 + (u & 1)];
     }
     h0[(size_t)b * ldh0 + r] = h;
     c0[(size_t)b * 2 * H + r] = c;
@@ -405,6 +441,11 @@ extern "C" int e2t_pack_frag(const float* src, long n_stride, long k_stride, int
     E2T_CHECK_ARG(src && dst && Nn > 0 && Kk > 0);
     const int NT = (Nn + 15) / 16, KB = (Kk + 31) / 32;
     hipLaunchKernelGGL(k_pack_frag, dim3(KB, NT), dim3(64), 0, ST, src, n_stride, k_stride, Nn, Kk, KB, (bf16_t*)dst);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_pack_batch(const e2t_pack_desc* descs_dev, int ndesc, int total_blocks, const float* base, void* stream) {
+    E2T_CHECK_ARG(descs_dev && base && ndesc > 0 && total_blocks > 0);
+    hipLaunchKernelGGL(k_pack_batch, dim3(total_blocks), dim3(256), 0, ST, descs_dev, ndesc, base);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 static DropCfg mk_drop(const e2t_dropout* d) {

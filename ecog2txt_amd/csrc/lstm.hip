@@ -47,7 +47,7 @@ extern __shared__ __attribute__((aligned(16))) uint4 lstm_smem[];
 //      u0 .. u0+3, u0 = ut*16 + fq*4.
 // Saved per-cell state is "lane-native", indexed by PROCESSING STEP s (not by time):
 //   Gs[((((s*ndir + dir)*RT + rt)*UT + ut)*4 + r)*64 + lane]  float4 = (i, j, f, o) of unit u0 + r
-//   Cs[ (((s*ndir + dir)*RT + rt)*UT + ut)*64 + lane ]         float4 = c of units u0 .. u0+3
+//   Cs[((((s*ndir + dir)*RT + rt)*UT + ut)*2 + half)*64 + lane]  float2 = c of units u0+2*half, u0+2*half+1
 // so every save/restore is a fully coalesced 1-KiB wave transaction and needs no time index.
 //
 // LDS image of one K chunk of `kch` k-blocks (32 k each), in 16-B units:
@@ -160,49 +160,67 @@ __device__ __forceinline__ bf16x8 state_frag(const uint4* ssec, const StepGeom& 
 }
 
 // One chunk of the recurrent product for this wave's 16-utterance tile: acc[g] += W_g(16 units x K) . state(K x 16).
-// Walks the chunk by k-block PAIRS with pure pointer increments (weights: +128 slots per pair and gate;
-// state: +128 slots per pair, even/odd k-block = swizzled position / position ^ 4) and requests the next
-// pair's fragments from LDS before the current pair's MFMAs.
-template <int NG>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NG], const uint4* buf, const StepGeom& G, int kc, int rtl, int lane) {
+// The K range of a tile is SPLIT between the two waves that share it (wave w and w+4: k-block pairs of equal
+// parity), so each SIMD runs two waves.  hipcc drains LDS reads (lgkmcnt(0)) at every loop back-edge, which
+// defeats a rolled software pipeline, so the wave requests ALL fragments of up to MAXP owned pairs first
+// (static register arrays, uniform guards), pays the LDS latency once, then issues its MFMAs back to back.
+// Chunks hold at most 16 k-blocks when K is chunked (8 pairs -> 4 per wave); single-chunk geometries with
+// more pairs take additional rounds.
+template <int NG, int MAXP>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NG], const uint4* buf, const StepGeom& G, int kc, int rtl, int khalf, int lane) {
     const int frow = lane & 15, fq = lane >> 4;
-    const uint4* wp = buf + lane;                                           // gate g at wp + g*kch*64
     const int gs = G.kch * 64;
-    const uint4* sp = buf + NG * gs + ((rtl * G.npair) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8;
+    const uint4* wbase = buf + lane;                                         // gate g at + g*kch*64, k-block i at + i*64
+    const uint4* sbase = buf + NG * gs + ((rtl * G.npair) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8;
     const int pe = fq ^ (frow & 7), po = pe ^ 4;
-    const int npr = kc >> 1;
-    uint4 se, so, we[NG], wo[NG];
-    if (npr > 0) {
-        se = sp[pe]; so = sp[po];
+    const int npr = kc >> 1;                                                 // full pairs in this chunk
+    for (int p0 = khalf; p0 < npr; p0 += 2 * MAXP) {
+        uint4 se[MAXP], so[MAXP], we[MAXP][NG], wo[MAXP][NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { we[g] = wp[g * gs]; wo[g] = wp[g * gs + 64]; }
-    }
-    for (int pp = 0; pp < npr; ++pp) {
-        uint4 nse = se, nso = so, nwe[NG], nwo[NG];
+        for (int q = 0; q < MAXP; ++q) {
+            const int pp = p0 + 2 * q;
+            if (pp < npr) {
+                se[q] = sbase[pp * 128 + pe]; so[q] = sbase[pp * 128 + po];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { nwe[g] = we[g]; nwo[g] = wo[g]; }
-        if (pp + 1 < npr) {
-            sp += 128; wp += 128;
-            nse = sp[pe]; nso = sp[po];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) { nwe[g] = wp[g * gs]; nwo[g] = wp[g * gs + 64]; }
+                for (int g = 0; g < NG; ++g) { we[q][g] = wbase[g * gs + pp * 128]; wo[q][g] = wbase[g * gs + pp * 128 + 64]; }
+            }
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&we[g], *(bf16x8*)&se, acc[g], 0, 0, 0);
+        for (int q = 0; q < MAXP; ++q) {
+            if (p0 + 2 * q < npr) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&wo[g], *(bf16x8*)&so, acc[g], 0, 0, 0);
-        se = nse; so = nso;
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&we[q][g], *(bf16x8*)&se[q], acc[g], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { we[g] = nwe[g]; wo[g] = nwo[g]; }
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&wo[q][g], *(bf16x8*)&so[q], acc[g], 0, 0, 0);
+            }
+        }
     }
-    if (kc & 1) {                                                            // odd tail k-block (even position of the last pair)
-        const uint4* wl = buf + lane + (size_t)(kc - 1) * 64;
-        const uint4 sl = (buf + NG * gs + ((rtl * G.npair + npr) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8)[pe];
+    if ((kc & 1) && (npr & 1) == khalf) {                                    // odd tail k-block (even position of pair npr)
+        const uint4 sl = sbase[npr * 128 + pe];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const uint4 w = wl[g * gs];
+            const uint4 w = wbase[g * gs + (kc - 1) * 64];
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&w, *(bf16x8*)&sl, acc[g], 0, 0, 0);
         }
+    }
+}
+
+// Reduce-scatter of the two K-half partial accumulators of a tile through LDS: wave half 0 ends up with the
+// full sums of cells r = 0,1 of every lane, wave half 1 with r = 2,3 (so the cell update is split too).
+// xbuf: [8 waves][NG*2 floats][64 lanes].  Returns sums as out[g][rr], rr = 0,1 <-> r = 2*khalf + rr.
+template <int NG>
+__device__ __forceinline__ void reduce_scatter(const f32x4 (&acc)[NG], float* xbuf, int wave, int khalf, int lane, float (&out)[NG][2]) {
+    float* mine = xbuf + (size_t)wave * (NG * 2 * 64) + lane;
+    const int send0 = khalf ? 0 : 2;                  // the cells the partner finishes
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { mine[(g * 2 + 0) * 64] = acc[g][send0]; mine[(g * 2 + 1) * 64] = acc[g][send0 + 1]; }
+    __syncthreads();
+    const float* theirs = xbuf + (size_t)(wave ^ 4) * (NG * 2 * 64) + lane;
+    const int keep0 = khalf ? 2 : 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        out[g][0] = acc[g][keep0] + theirs[(g * 2 + 0) * 64];
+        out[g][1] = acc[g][keep0 + 1] + theirs[(g * 2 + 1) * 64];
     }
 }
 
@@ -236,8 +254,8 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     const int s = p.step, B = p.B, H = p.H, KB = p.KB;
     const int frow = lane & 15, fq = lane >> 4;
     const int NH = p.ndir * H;
-    const StepGeom G = step_geom(KB, 4, 4 * 256);
-    uint4* gx_lds = lstm_smem + (size_t)G.nbuf * G.bufsz;          // [4 tiles][2 halves][2 chunk halves][64]
+    const StepGeom G = step_geom(KB, 4, 4 * 256 + 1024);
+    uint4* gx_lds = lstm_smem + (size_t)G.nbuf * G.bufsz;          // [4 tiles][2 halves][2 chunk halves][64]; then the exchange area
     long long ts[8];
 #define STAMP(i) do { if (p.dbg) ts[i] = clock64(); } while (0)
     STAMP(0);
@@ -246,8 +264,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     //      state / Gx rows of tile w>>1, row half w&1) and of the row it UPDATES (compute waves)
     const int fb = (rb * 4 + (wave >> 1)) * 16 + (wave & 1) * 8 + (lane >> 3);
     const int flen = (fb < B) ? p.lens[fb] : 0;
-    const bool compute = wave < 4;
-    const int rt = rb * 4 + (wave & 3);
+    const int rt = rb * 4 + (wave & 3);             // tile this wave multiplies (half of K) and updates (2 of 4 cells)
     const int b = rt * 16 + frow;
     const int len = (b < B) ? p.lens[b] : 0;
     const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
@@ -285,16 +302,16 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
         const int gu = ut * 16 + ch * 8 + (lane & 7);                   // unit whose 4 gates this lane moves
         dma16_to_lds(gxrow + (gu < H ? (size_t)gu * 4 : 0), lds_addr_of(gx_lds + (wave * 2 + ch) * 64));
     }
-    const int u0 = ut * 16 + fq * 4;                  // first of this lane's 4 units
-    const bool vec = (H & 3) == 0;
-    const int nu = min(4, H - u0);
-    const bool active = compute && s < len;
+    const int khalf = wave >> 2;                      // which K half this wave multiplies / which 2 cells it finishes
+    const int u0 = ut * 16 + fq * 4 + 2 * khalf;      // first of this lane's 2 units
+    const int nu = min(2, H - u0);
+    const bool active = s < len;
     const int t = dir ? (len - 1 - s) : s;
-    float4 cprev = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 cprev = make_float2(0.f, 0.f);
     const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
     if (active && nu > 0) {
-        if (s > 0) cprev = ((const float4*)p.Cs)[native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 64 + lane];
-        else if (p.c0) cprev = ld4(p.c0 + (size_t)b * NH + dir * H + u0, vec, nu);
+        if (s > 0) cprev = ((const float2*)p.Cs)[(native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 2 + khalf) * 64 + lane];
+        else if (p.c0) { const float* c = p.c0 + (size_t)b * NH + dir * H + u0; cprev.x = c[0]; if (nu > 1) cprev.y = c[1]; }
     }
     STAMP(2);
 
@@ -306,11 +323,9 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
         STAMP(3);
         __syncthreads();
         STAMP(4);
-        if (compute && !(p.ablate & 4)) {
-            for (int cc = c; cc < min(c + 2, G.nch); ++cc) {
-                const uint4* buf = lstm_smem + (size_t)(cc & 1) * G.bufsz;
-                mma_chunk<4>(acc, buf, G, min(G.kch, KB - cc * G.kch), wave, lane);
-            }
+        if (!(p.ablate & 4)) {
+            for (int cc = c; cc < min(c + 2, G.nch); ++cc)
+                mma_chunk<4, 4>(acc, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
         }
         if (c + 2 < G.nch) {
             __syncthreads();                         // everyone is done reading both buffers
@@ -318,58 +333,54 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
             if (c + 3 < G.nch) issue_chunk<4>(wsrc, wgs, KB, srow, c + 3, lstm_smem + G.bufsz, G, wave, lane);
         }
     }
+    float z[4][2];
+    reduce_scatter<4>(acc, (float*)(gx_lds + 4 * 256), wave, khalf, lane, z);
     STAMP(5);
-    if (!compute) return;                            // loader waves are done
 
-    // ---- lane-local cell update for (utterance b, units u0..u0+3) ------------------------------
+    // ---- lane-local cell update for (utterance b, units u0, u0+1) -------------------------------
     if (b >= B || nu <= 0) return;
     if (active) {
         const size_t m = (size_t)t * B + b;
-        const size_t e0 = m * NH + dir * H + u0;      // logical element index (dropout key)
-        float dsc[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.Ydrop && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e0, dsc);
-        float hv[4], cv[4], hd[4];
-        const float cp[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
-        const uint4* gxt = gx_lds + ((wave * 2 + (frow >> 3)) * 2) * 64 + (frow & 7) * 8;
+        const size_t e4 = m * NH + dir * H + (u0 - 2 * khalf);      // logical index of the lane's 4-unit group
+        float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.Ydrop && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e4, dsc4);
+        float hv[2], cv[2], hd[2];
+        const float cp[2] = {cprev.x, cprev.y};
+        const uint4* gxt = gx_lds + (((wave & 3) * 2 + (frow >> 3)) * 2) * 64 + (frow & 7) * 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cidx = fq * 4 + r;              // unit index within the tile
+        for (int rr = 0; rr < 2; ++rr) {
+            const int cidx = fq * 4 + 2 * khalf + rr;     // unit index within the tile
             uint4 raw = gxt[(cidx >> 3) * 64 + (cidx & 7)];
             const float4 gx = *(float4*)&raw;
-            const float gi = fsigmoid(acc[0][r] + gx.x);
-            const float gj = ftanh(acc[1][r] + gx.y);
-            const float gf = fsigmoid(acc[2][r] + gx.z + p.forget_bias);
-            const float go = fsigmoid(acc[3][r] + gx.w);
-            cv[r] = gf * cp[r] + gi * gj;
-            hv[r] = go * ftanh(cv[r]);
-            nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi, gj, gf, go);
-            hd[r] = hv[r] * dsc[r];
+            const float gi = fsigmoid(z[0][rr] + gx.x);
+            const float gj = ftanh(z[1][rr] + gx.y);
+            const float gf = fsigmoid(z[2][rr] + gx.z + p.forget_bias);
+            const float go = fsigmoid(z[3][rr] + gx.w);
+            cv[rr] = gf * cp[rr] + gi * gj;
+            hv[rr] = go * ftanh(cv[rr]);
+            if (rr < nu) nt_store_f4(p.Gs + ((tile * 4 + 2 * khalf + rr) * 64 + lane) * 4, gi, gj, gf, go);
+            hd[rr] = hv[rr] * (khalf ? dsc4[2 + rr] : dsc4[rr]);
         }
         STAMP(6);
-        ((float4*)p.Cs)[tile * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        ((float2*)p.Cs)[(tile * 2 + khalf) * 64 + lane] = make_float2(cv[0], cv[1]);
         bf16_t* yp = p.Yext + ((size_t)(t + 1) * B + b) * p.ldy + dir * p.H8 + u0;
         bf16_t* ydp = p.Ydrop ? p.Ydrop + m * p.ldy + dir * p.H8 + u0 : nullptr;
-        if (nu == 4) {
-            *(ushort4*)yp = make_ushort4(f2bf(hv[0]), f2bf(hv[1]), f2bf(hv[2]), f2bf(hv[3]));     // re-read next step: keep in L2
-            if (ydp) nt_store_bf4(ydp, f2bf(hd[0]), f2bf(hd[1]), f2bf(hd[2]), f2bf(hd[3]));
+        if (nu == 2) {
+            *(ushort2*)yp = make_ushort2(f2bf(hv[0]), f2bf(hv[1]));                // re-read next step: keep in L2
+            if (ydp) *(ushort2*)ydp = make_ushort2(f2bf(hd[0]), f2bf(hd[1]));
         } else {
-            for (int r = 0; r < nu; ++r) { yp[r] = f2bf(hv[r]); if (ydp) ydp[r] = f2bf(hd[r]); }
+            yp[0] = f2bf(hv[0]); if (ydp) ydp[0] = f2bf(hd[0]);
         }
         STAMP(7);
         if (p.dbg && lane == 0) {
-            long long* o = p.dbg + ((size_t)(blockIdx.x * 4 + wave)) * 8;
+            long long* o = p.dbg + ((size_t)(blockIdx.x * 8 + wave)) * 8;
             for (int i = 0; i < 8; ++i) o[i] = ts[i];
         }
     } else if (s < p.S) {
         // padded position s of this utterance: emit zeros (dynamic_rnn semantics)
         bf16_t* yp = p.Yext + ((size_t)(s + 1) * B + b) * p.ldy + dir * p.H8 + u0;
         bf16_t* ydp = p.Ydrop ? p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0 : nullptr;
-        if (nu == 4) {
-            *(ushort4*)yp = make_ushort4(0, 0, 0, 0);
-            if (ydp) *(ushort4*)ydp = make_ushort4(0, 0, 0, 0);
-        } else {
-            for (int r = 0; r < nu; ++r) { yp[r] = 0; if (ydp) ydp[r] = 0; }
-        }
+        for (int r = 0; r < nu; ++r) { yp[r] = 0; if (ydp) ydp[r] = 0; }
     }
 }
 
@@ -402,11 +413,10 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     const int frow = lane & 15, fq = lane >> 4;
     const int K4 = 4 * H;
     const int NH = p.ndir * H;
-    const StepGeom G = step_geom(KB, 1, 0);
+    const StepGeom G = step_geom(KB, 1, 256);
 
     const int fb = (rb * 4 + (wave >> 1)) * 16 + (wave & 1) * 8 + (lane >> 3);       // row this lane fetches for
     const int flen = (fb < B) ? p.lens[fb] : 0;
-    const bool compute = wave < 4;
     const int rt = rb * 4 + (wave & 3);
     const int b = rt * 16 + frow;
     const int len = (b < B) ? p.lens[b] : 0;
@@ -423,30 +433,31 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     if (G.nch > 1) issue_chunk<1>(wsrc, 0, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
 
     // ---- epilogue operands (lane-native, coalesced), requested in the same round trip ----------
-    const bool active = compute && s >= 0 && s < len;
+    const int khalf = wave >> 2;
+    const bool active = s >= 0 && s < len;
     const int t = dir ? (len - 1 - s) : s;
-    const int u0 = ut * 16 + fq * 4;
-    const bool vec = (H & 3) == 0;
-    const int nu = min(4, H - u0);
+    const int u0 = ut * 16 + fq * 4 + 2 * khalf;             // first of this lane's 2 units
+    const int nu = min(2, H - u0);
     const size_t su = (size_t)b * NH + dir * H + u0;          // state index [B][ndir*H]
-    float4 g4[4], c_t, cprev, dyv, dcin, dhf;
-    c_t = cprev = dyv = dcin = dhf = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) g4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g4[2];
+    float2 c_t, cprev, dyv, dcin, dhf;
+    c_t = cprev = dyv = dcin = dhf = make_float2(0.f, 0.f);
+    g4[0] = g4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld2 = [&](const float* q) { float2 v = make_float2(q[0], 0.f); if (nu > 1) v.y = q[1]; return v; };
     const size_t m = active ? ((size_t)t * B + b) : 0;
     if (active && nu > 0) {
         const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) g4[r] = ((const float4*)p.Gs)[(tile * 4 + r) * 64 + lane];
-        c_t = ((const float4*)p.Cs)[tile * 64 + lane];
-        if (s > 0) cprev = ((const float4*)p.Cs)[native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 64 + lane];
-        else if (p.c0) cprev = ld4(p.c0 + su, vec, nu);
-        if (p.dY) dyv = ld4(p.dY + m * p.lddy + dir * p.H8 + u0, nu == 4, nu);
+        for (int rr = 0; rr < 2; ++rr) g4[rr] = ((const float4*)p.Gs)[(tile * 4 + 2 * khalf + rr) * 64 + lane];
+        c_t = ((const float2*)p.Cs)[(tile * 2 + khalf) * 64 + lane];
+        if (s > 0) cprev = ((const float2*)p.Cs)[(native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 2 + khalf) * 64 + lane];
+        else if (p.c0) cprev = ld2(p.c0 + su);
+        if (p.dY) dyv = ld2(p.dY + m * p.lddy + dir * p.H8 + u0);
         if (s == len - 1) {
-            if (p.dh_final) dhf = ld4(p.dh_final + su, vec, nu);
-            if (p.dc_final) dcin = ld4(p.dc_final + su, vec, nu);
+            if (p.dh_final) dhf = ld2(p.dh_final + su);
+            if (p.dc_final) dcin = ld2(p.dc_final + su);
         } else {
-            dcin = ld4(p.dc_carry + su, vec, nu);
+            dcin = ld2(p.dc_carry + su);
         }
     }
 
@@ -454,68 +465,64 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     for (int c = 0; c < G.nch; c += 2) {
         dma_wait_all();
         __syncthreads();
-        if (compute) {
-            for (int cc = c; cc < min(c + 2, G.nch); ++cc)
-                mma_chunk<1>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave, lane);
-        }
+        for (int cc = c; cc < min(c + 2, G.nch); ++cc)
+            mma_chunk<1, 8>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
         if (c + 2 < G.nch) {
             __syncthreads();
             issue_chunk<1>(wsrc, 0, KB, srow, c + 2, lstm_smem, G, wave, lane);
             if (c + 3 < G.nch) issue_chunk<1>(wsrc, 0, KB, srow, c + 3, lstm_smem + G.bufsz, G, wave, lane);
         }
     }
-    if (!compute) return;
-    const f32x4 acc = accv[0];
+    float rec[1][2];
+    reduce_scatter<1>(accv, (float*)(lstm_smem + (size_t)G.nbuf * G.bufsz), wave, khalf, lane, rec);
 
     if (b >= B || nu <= 0) return;
     if (s < 0) {
         // pseudo-step -1: gradient into the initial state (decoder <- encoder seam)
-        float4 o_h, o_c;
-        if (len > 0) { o_h = make_float4(acc[0], acc[1], acc[2], acc[3]); o_c = ld4(p.dc_carry + su, vec, nu); }
+        float2 o_h, o_c;
+        if (len > 0) { o_h = make_float2(rec[0][0], rec[0][1]); o_c = ld2(p.dc_carry + su); }
         else {
-            o_h = p.dh_final ? ld4(p.dh_final + su, vec, nu) : make_float4(0.f, 0.f, 0.f, 0.f);
-            o_c = p.dc_final ? ld4(p.dc_final + su, vec, nu) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o_h = p.dh_final ? ld2(p.dh_final + su) : make_float2(0.f, 0.f);
+            o_c = p.dc_final ? ld2(p.dc_final + su) : make_float2(0.f, 0.f);
         }
-        st4(p.dh0 + su, o_h, vec, nu);
-        st4(p.dc0 + su, o_c, vec, nu);
+        p.dh0[su] = o_h.x; p.dc0[su] = o_c.x;
+        if (nu > 1) { p.dh0[su + 1] = o_h.y; p.dc0[su + 1] = o_c.y; }
         return;
     }
     if (active) {
-        const size_t e0 = m * NH + dir * H + u0;
-        float dsc[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.dY && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e0, dsc);
-        const float ct[4] = {c_t.x, c_t.y, c_t.z, c_t.w}, cp[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
-        const float dy[4] = {dyv.x, dyv.y, dyv.z, dyv.w}, dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
-        const float dhfv[4] = {dhf.x, dhf.y, dhf.z, dhf.w};
-        bf16_t og[16]; float dcn[4];
+        const size_t e4 = m * NH + dir * H + (u0 - 2 * khalf);
+        float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.dY && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e4, dsc4);
+        const float ct[2] = {c_t.x, c_t.y}, cp[2] = {cprev.x, cprev.y};
+        const float dy[2] = {dyv.x, dyv.y}, dci[2] = {dcin.x, dcin.y}, dhfv[2] = {dhf.x, dhf.y};
+        bf16_t og[8]; float dcn[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4 g = g4[r];
-            const float dh = acc[r] + dhfv[r] + dy[r] * dsc[r];
-            const float tc = ftanh(ct[r]);
-            const float dct = dci[r] + dh * g.w * (1.f - tc * tc);
-            og[r * 4 + 3] = f2bf(dh * tc * g.w * (1.f - g.w));            // d_o
-            og[r * 4 + 0] = f2bf(dct * g.y * g.x * (1.f - g.x));          // d_i
-            og[r * 4 + 1] = f2bf(dct * g.x * (1.f - g.y * g.y));          // d_j
-            og[r * 4 + 2] = f2bf(dct * cp[r] * g.z * (1.f - g.z));        // d_f
-            dcn[r] = dct * g.z;
+        for (int rr = 0; rr < 2; ++rr) {
+            const float4 g = g4[rr];
+            const float dh = rec[0][rr] + dhfv[rr] + dy[rr] * (khalf ? dsc4[2 + rr] : dsc4[rr]);
+            const float tc = ftanh(ct[rr]);
+            const float dct = dci[rr] + dh * g.w * (1.f - tc * tc);
+            og[rr * 4 + 3] = f2bf(dh * tc * g.w * (1.f - g.w));            // d_o
+            og[rr * 4 + 0] = f2bf(dct * g.y * g.x * (1.f - g.x));          // d_i
+            og[rr * 4 + 1] = f2bf(dct * g.x * (1.f - g.y * g.y));          // d_j
+            og[rr * 4 + 2] = f2bf(dct * cp[rr] * g.z * (1.f - g.z));       // d_f
+            dcn[rr] = dct * g.z;
         }
         bf16_t* gp = p.dG + m * p.lddg + (size_t)dir * K4 + u0 * 4;
-        if (nu == 4) {
-            uint4 lo, hi;
-            lo.x = og[0] | ((unsigned)og[1] << 16); lo.y = og[2] | ((unsigned)og[3] << 16);
-            lo.z = og[4] | ((unsigned)og[5] << 16); lo.w = og[6] | ((unsigned)og[7] << 16);
-            hi.x = og[8] | ((unsigned)og[9] << 16); hi.y = og[10] | ((unsigned)og[11] << 16);
-            hi.z = og[12] | ((unsigned)og[13] << 16); hi.w = og[14] | ((unsigned)og[15] << 16);
-            ((uint4*)gp)[0] = lo; ((uint4*)gp)[1] = hi;
+        if (nu == 2) {
+            uint4 v;
+            v.x = og[0] | ((unsigned)og[1] << 16); v.y = og[2] | ((unsigned)og[3] << 16);
+            v.z = og[4] | ((unsigned)og[5] << 16); v.w = og[6] | ((unsigned)og[7] << 16);
+            *(uint4*)gp = v;
         } else {
-            for (int i = 0; i < nu * 4; ++i) gp[i] = og[i];
+            for (int i = 0; i < 4; ++i) gp[i] = og[i];
         }
-        st4(p.dc_carry + su, make_float4(dcn[0], dcn[1], dcn[2], dcn[3]), vec, nu);
+        p.dc_carry[su] = dcn[0];
+        if (nu > 1) p.dc_carry[su + 1] = dcn[1];
     } else if (s < p.S) {
         bf16_t* gp = p.dG + ((size_t)s * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4;
-        if (nu == 4) { ((uint4*)gp)[0] = make_uint4(0, 0, 0, 0); ((uint4*)gp)[1] = make_uint4(0, 0, 0, 0); }
-        else { for (int i = 0; i < nu * 4; ++i) gp[i] = 0; }
+        if (nu == 2) *(uint4*)gp = make_uint4(0, 0, 0, 0);
+        else { for (int i = 0; i < 4; ++i) gp[i] = 0; }
     }
 }
 
@@ -546,8 +553,8 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    const StepGeom G = step_geom(p.KB, 4, 4 * 256);
-    const size_t lds = ((size_t)G.nbuf * G.bufsz + 4 * 256) * 16;
+    const StepGeom G = step_geom(p.KB, 4, 4 * 256 + 1024);
+    const size_t lds = ((size_t)G.nbuf * G.bufsz + 4 * 256 + 1024) * 16;
     dim3 grid(8 * ((p.UT + 7) / 8) * ((d->B + 63) / 64) * d->ndir);      // XCD-major tile map, see kernel
     for (int s = step_begin; s < step_end; ++s) {
         p.step = s;
@@ -574,8 +581,8 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     p.lddg = lddg; p.lddy = lddy;
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    const StepGeom G = step_geom(p.KB4, 1, 0);
-    const size_t lds = (size_t)G.nbuf * G.bufsz * 16;
+    const StepGeom G = step_geom(p.KB4, 1, 256);
+    const size_t lds = ((size_t)G.nbuf * G.bufsz + 256) * 16;
     dim3 grid(8 * ((p.UT + 7) / 8) * ((d->B + 63) / 64) * d->ndir);      // XCD-major tile map, see kernel
     for (int s = d->S - 1; s >= (dh0 ? -1 : 0); --s) {
         p.step = s;

@@ -392,7 +392,7 @@ class _Lstm:
         ws['Yext'] = _bf((S + 3) * B, self.ldy, device=dev)       # block 0 = initial state, S+1.. = zero slack
         ws['Ydrop'] = _bf(M, self.ldy, device=dev)
         RT, UT = ceil_div(B, 16), ceil_div(Hh, 16)
-        ws['Cs'] = _f32(S, nd, RT, UT, 64, 4, device=dev)          # lane-native per-step saves (lstm.hip)
+        ws['Cs'] = _f32(S, nd, RT, UT, 2, 64, 2, device=dev)       # lane-native per-step saves (lstm.hip)
         ws['Gs'] = _f32(S, nd, RT, UT, 4, 64, 4, device=dev)
         ws['dG'] = _bf(M + B, r8(self.N4), device=dev)              # block S = zero slack (rows without successor)
         ws['dGT'] = _bf(self.N4, Mk, device=dev)
@@ -496,7 +496,7 @@ class Seq2SeqEngine:
         self.dec = _Lstm(self, 'dec', 1, s.dec_embed, [(0, s.dec_embed, 0)], self.E8, s.dec_rnn, STREAM_DEC_OUT)
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
                              [(0, s.dec_rnn, 0)], r8(s.dec_rnn), STREAM_DEC_OUT + 1)
-        self._pack_lists = {}
+        self._pack_table = None
         self._ws = {}
         self._packed = None
         self.splitk_ws = _f32(16 * 1024 * 1024, device=dev)          # 64 MiB of split-K partial slabs
@@ -559,31 +559,46 @@ class Seq2SeqEngine:
 
     # ------------------------------------------------------------------ packing
     def pack(self, which='p'):
-        """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema')."""
+        """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema'):
+        ONE launch driven by a device-resident descriptor table (built once)."""
         src = getattr(self.store, which)
-        ops = self._pack_lists.get(which)
-        if ops is None:
+        if self._pack_table is None:
             ops = []
             st, s = self.store, self.spec
+            base = st.p          # offsets are relative, identical for p and ema
             for sid, Cc in s.channels.items():
                 Kc = s.decimation * Cc
-                ops.append(('cast', st.ptr('conv%s.W' % sid, src), 1, s.enc_embed, s.enc_embed, Kc, self.convT[sid], 0, 0))
+                ops.append(('cast', st.ptr('conv%s.W' % sid, base), 1, s.enc_embed, s.enc_embed, Kc, self.convT[sid], 0, 0))
             for lay in self.enc:
-                lay.pack_ops(ops, src)
+                lay.pack_ops(ops, base)
             if self.aux:
-                self.aux.pack_ops(ops, src)
-            ops.append(('cast', st.ptr('dec.emb', src), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
-            self.dec.pack_ops(ops, src)
-            self.proj.pack_ops(ops, src)
-            self._pack_lists[which] = ops
-        for op in ops:
-            if op[0] == 'cast':
-                _, sp, rs, cs, R, Cn, dst, k0, r0 = op
-                ld = dst.shape[-1]
-                lib.e2t_cast_pack(sp, rs, cs, R, Cn, dst.data_ptr() + 2 * (r0 * ld + k0), ld, self.stream)
-            else:
-                _, sp, ns, ks, Nn, Kk, dst = op
-                lib.e2t_pack_frag(sp, ns, ks, Nn, Kk, dst.data_ptr(), self.stream)
+                self.aux.pack_ops(ops, base)
+            ops.append(('cast', st.ptr('dec.emb', base), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
+            self.dec.pack_ops(ops, base)
+            self.proj.pack_ops(ops, base)
+            descs = (H.PackDesc * len(ops))()
+            nblk = 0
+            p0 = base.data_ptr()
+            for i, op in enumerate(ops):
+                d = descs[i]
+                d.first_block = nblk
+                if op[0] == 'cast':
+                    _, sp, rs, cs, R, Cn, dst, k0, r0 = op
+                    ld = dst.shape[-1]
+                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = 0, (sp - p0) // 4, rs, cs, R, Cn, ld
+                    d.dst = dst.data_ptr() + 2 * (r0 * ld + k0)
+                    nblk += R * ceil_div(Cn, 256)
+                else:
+                    _, sp, ns, ks, Nn, Kk, dst = op
+                    KB = ceil_div(Kk, 32)
+                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = 1, (sp - p0) // 4, ns, ks, Nn, Kk, KB
+                    d.dst = dst.data_ptr()
+                    nblk += ceil_div(ceil_div(Nn, 16) * KB, 4)
+            raw = bytes(descs)
+            self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._pack_table = (len(ops), nblk)
+        n, nblk = self._pack_table
+        lib.e2t_pack_batch(self._pack_dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
         self._packed = which
 
     def load_params(self, P):

@@ -31,6 +31,11 @@ class LstmDesc(C.Structure):
                 ('drop_step', C.c_void_p), ('drop_stream', C.c_uint)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [('kind', C.c_int), ('first_block', C.c_int), ('src_off', C.c_longlong), ('s0', C.c_longlong),
+                ('s1', C.c_longlong), ('d0', C.c_int), ('d1', C.c_int), ('ld', C.c_int), ('pad_', C.c_int), ('dst', C.c_void_p)]
+
+
 class AdamHyper(C.Structure):
     _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
                 ('ema_decay', C.c_float), ('grad_scale', C.c_float)]
@@ -53,6 +58,7 @@ SIGNATURES = {
     'e2t_transpose_bf16': [_p, _i, _i, _i, _p, _i, _p],
     'e2t_cast_pack': [_p, _l, _l, _i, _i, _p, _i, _p],
     'e2t_pack_frag': [_p, _l, _l, _i, _i, _p, _p],
+    'e2t_pack_batch': [_p, _i, _i, _p, _p],
     'e2t_lstm_seq_fwd': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     'e2t_lstm_seq_bwd': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'e2t_final_state': [_p, _i, _p, _p, _i, _i, _p, _i, _p, _p],

@@ -94,6 +94,17 @@ int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int l
 /* ---- weight packing: fp32 masters -> bf16 operand images (after every optimiser step) ---- */
 int e2t_cast_pack(const float* src, long row_stride, long col_stride, int R, int C, void* dst, int ld_dst, void* stream);
 int e2t_pack_frag(const float* src, long n_stride, long k_stride, int Nn, int Kk, void* dst, void* stream);
+/* every image in one launch: device table of descriptors (src = base + src_off) */
+typedef struct e2t_pack_desc {
+    int kind;            /* 0: dst[r][c] = bf16(src[r*s0 + c*s1]), r < d0, c < d1, leading dim ld
+                            1: MFMA fragment image of Bn[n][k] = src[n*s0 + k*s1], n < d0, k < d1, ld = ceil(d1/32) */
+    int first_block;     /* first 256-thread workgroup of this descriptor (exclusive prefix, ascending) */
+    long long src_off;   /* element offset into the fp32 base */
+    long long s0, s1;
+    int d0, d1, ld, pad_;
+    void* dst;
+} e2t_pack_desc;
+int e2t_pack_batch(const e2t_pack_desc* descs_dev, int ndesc, int total_blocks, const float* base, void* stream);
 
 /* ---- a7/a9: SequenceNetwork._encode_sequences (trainers.py:821-823) and the decoder RNN ---- */
 typedef struct e2t_lstm_desc {
