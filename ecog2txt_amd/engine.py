@@ -803,6 +803,25 @@ class Seq2SeqEngine:
         self.gemm(ws['AT'].data_ptr(), Mk, ws['dEpreT'].data_ptr(), Mk, store.ptr('conv%s.W' % sid, store.g), s.enc_embed,
                   ws['Kc'] + 1, s.enc_embed, Mk, splitk=True)
 
+    # ------------------------------------------------------------------ saliency (row a12)
+    def input_gradient(self, ws):
+        """d(loss)/d(encoder_inputs) [B,T,C] fp32 after forward()+backward(): dA = dEpre . W_conv^T, then the
+        im2row/time-reversal is undone (restore_and_get_saliencies, reference trainers.py:722-725)."""
+        s, sid, dev = self.spec, ws['sid'], self.device
+        Kc, Kc8, M = ws['Kc'], ws['Kc8'], ws['M']
+        if sid not in self.convB:
+            self.convB[sid] = _bf(Kc, self.F8, device=dev)
+        src = getattr(self.store, self._packed or 'p')
+        lib.e2t_cast_pack(self.store.ptr('conv%s.W' % sid, src), s.enc_embed, 1, Kc, s.enc_embed, self.convB[sid].data_ptr(),
+                          self.F8, self.stream)
+        if 'dA' not in ws:
+            ws['dA'] = _f32(M, Kc8, device=dev)
+            ws['dX'] = _f32(ws['B'], ws['T'], ws['C'], device=dev)
+        self.gemm(ws['dEpre'].data_ptr(), self.F8, self.convB[sid].data_ptr(), self.F8, ws['dA'].data_ptr(), Kc8, M, Kc, self.F8)
+        lib.e2t_conv_unpack_grad(ws['dA'].data_ptr(), Kc8, ws['lens'].data_ptr(), ws['B'], ws['T'], ws['C'], s.decimation,
+                                 ws['dX'].data_ptr(), self.stream)
+        return ws['dX']
+
     # ------------------------------------------------------------------ optimiser
     def adam_step(self, sid=None):
         """Adam + EMA on the shared body and (if given) subject `sid`'s conv; then re-pack operands."""
@@ -859,7 +878,9 @@ class Seq2SeqEngine:
                 sync.wait()
             self.adam_step(ws['sid'])
             return
-        key = 'train_dp' if dp else 'train'
+        # the captured Adam launches bake in the trainable ranges and the gradient scale
+        key = ('train_dp' if dp else 'train', tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
+               tuple(sorted(self.hyper.items())))
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture

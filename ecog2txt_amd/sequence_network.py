@@ -1,0 +1,354 @@
+"""`SequenceNetwork`: the MI355X backend object that `MultiSubjectTrainer.net` holds.
+
+Drop-in for `machine_learning.neural_networks.sequence_networks.SequenceNetwork` as the
+reference uses it (construction ecog2txt/trainers.py:126-135; `fit` :318/:355/:367 with the
+kwargs of :308-314 and :341-366; `restore_and_assess` :379-380; `restore_and_get_saliencies`
+:722-725; `get_weights_as_numpy_array` :699-700, :750-751; attributes read or written by the
+trainer: checkpoint_path :219, N_epochs :324/:351/:365, layer_sizes :385/:576,
+TEMPORALLY_CONVOLVE :386, EMA_decay :387, FF_dropout/RNN_dropout :572-573,
+assessment_epoch_interval :583, assessment_GPU :856, TARGETS_ARE_SEQUENCES :292).
+All device work goes through ecog2txt_amd.engine (hand-written HIP kernels); host code here is
+data staging, the epoch loop, metrics and checkpoint files."""
+import os
+import re
+
+import numpy as np
+
+from . import tfrecord
+from .toolbox import auto_attribute, wer_vector, MutableNamedTuple
+
+EMA_SUFFIX = '/ExponentialMovingAverage'        # trainers.py:467-468
+
+
+class AssessmentTuple(MutableNamedTuple):
+    """Per-partition results; the fields the trainer/plotters read (trainers.py:584-596, 610;
+    plotters.py:636)."""
+    __slots__ = ['decoder_accuracies', 'decoder_word_error_rates', 'decoder_confusions', 'accuracy',
+                 'word_error_rate', 'hypotheses', 'references', 'losses']
+
+
+def target_inds_to_sequences(hypotheses, targets_list):
+    """index rows -> text: join tokens, '_' -> ' ', drop <pad>/<EOS>, rstrip (trainers.py:952-963)."""
+    from . import pad_token, EOS_token
+    return [''.join(targets_list[i] for i in row).replace('_', ' ').replace(pad_token, '').replace(EOS_token, '').rstrip()
+            for row in hypotheses]
+
+
+def load_examples(subject, blocks):
+    """Parse the TFRecords of `blocks` into network-ready arrays using the subject's data manifests
+    (role of tfh.parse_protobuf_seq2seq_example, reference trainers.py:896-900, subjects.py:216-218)."""
+    dms = subject.data_manifests
+    out = []
+    for blk in sorted(blocks):
+        path = subject.tf_record_partial_path.format(blk)
+        for payload in tfrecord.tf_record_iterator(path):
+            raw = tfrecord.decode_example(payload)
+            ex = {}
+            for key, dm in dms.items():
+                v = raw[dm.sequence_type]
+                if dm.is_continuous:
+                    v = np.asarray(v, np.float32).reshape(-1, dm.num_features_raw)     # stored flattened (trainers.py:865)
+                ex[key] = dm.transform(v)
+            out.append(ex)
+    return out
+
+
+class SequenceNetwork:
+    @auto_attribute(CHECK_MANIFEST=True)
+    def __init__(self, manifest, EOS_token='<EOS>', pad_token='<pad>', OOV_token='<OOV>', training_GPUs=(0,),
+                 TARGETS_ARE_SEQUENCES=True, VERBOSE=True, layer_sizes=None, FF_dropout=None, RNN_dropout=None,
+                 TEMPORALLY_CONVOLVE=None, EMA_decay=None, beam_width=None, assessment_epoch_interval=None,
+                 tf_summaries_dir=None, N_epochs=None, temperature=None, N_cases=256, learning_rate=5e-4,
+                 max_hyp_length=20, seed=0, assessment_GPU=0, checkpoint_path='./model.ckpt', inputs_to_occlude=None,
+                 process_group=None):
+        self._engine = None
+        self._engine_key = None
+        self._epoch = 0
+        assert (self.beam_width or 1) == 1, 'only greedy decoding (beam_width 1, mocha-1_word_sequence.yaml:31) is implemented'
+
+    def vprint(self, *a, **k):
+        if self.VERBOSE:
+            print(*a, **k)
+
+    # ------------------------------------------------------------------ engine construction
+    def _spec_from(self, subjects):
+        from .engine import NetSpec
+        ls = self.layer_sizes
+        last = subjects[-1]
+        dms = last.data_manifests
+        aux_keys = [k for k in dms if re.fullmatch(r'encoder_\d+_targets', k)]
+        assert len(aux_keys) <= 1, 'one auxiliary encoder target is supported'
+        kw = {}
+        if aux_keys:
+            k = aux_keys[0]
+            layer = int(k.split('_')[1])
+            dm = dms[k]
+            dist = 'Gaussian' if dm.distribution == 'Gaussian' else 'categorical'
+            kw.update(aux_layer=layer, aux_hidden=list(ls.get('encoder_%d_projection' % layer, [])),
+                      aux_dim=int(dm.num_features), aux_dist=dist, aux_scale=float(dm.penalty_scale))
+            if not dm.num_features:
+                kw.update(aux_layer=None)
+        else:
+            kw.update(aux_layer=None)
+        N = {int(s.decimation_factor) if self.TEMPORALLY_CONVOLVE else 1 for s in subjects}
+        assert len(N) == 1, 'all subjects must share one decimation factor'
+        assert len(ls['encoder_embedding']) == 1 and len(ls['decoder_embedding']) == 1 and len(ls['decoder_rnn']) == 1
+        return NetSpec(channels={s.subnet_id: int(s.data_manifests['encoder_inputs'].num_features) for s in subjects},
+                       decimation=N.pop(), enc_embed=ls['encoder_embedding'][0], enc_rnn=list(ls['encoder_rnn']),
+                       dec_embed=ls['decoder_embedding'][0], dec_rnn=ls['decoder_rnn'][0],
+                       dec_proj_hidden=list(ls.get('decoder_projection', [])), vocab=int(dms['decoder_targets'].num_features),
+                       dec_scale=float(dms['decoder_targets'].penalty_scale), ff_dropout=float(self.FF_dropout),
+                       rnn_dropout=float(self.RNN_dropout), **kw)
+
+    def _get_engine(self, subjects, all_subject_ids=None):
+        from .engine import Seq2SeqEngine
+        spec = self._spec_from(subjects)
+        key = repr(spec)
+        if self._engine is None or self._engine_key != key:
+            dev = 'cuda:%d' % (self.training_GPUs[0] if self.training_GPUs else 0)
+            self._engine = Seq2SeqEngine(spec, device=dev, seed=self.seed, lr=self.learning_rate, ema_decay=self.EMA_decay or 0.0)
+            self._engine.init_params(self.seed)
+            self._engine_key = key
+        return self._engine
+
+    # ------------------------------------------------------------------ data staging
+    def _stage(self, subject, partition):
+        """All utterances of a partition as padded host arrays (static shapes => one hipGraph)."""
+        ex = load_examples(subject, subject.block_ids[partition])
+        if not ex:
+            return None
+        N = self._engine.spec.decimation
+        T = max(e['encoder_inputs'].shape[0] for e in ex)
+        T = -(-T // N) * N
+        L = min(max(len(e['decoder_targets']) for e in ex), self.max_hyp_length)
+        n = len(ex)
+        C = ex[0]['encoder_inputs'].shape[1]
+        X = np.zeros((n, T, C), np.float32)
+        Y = np.zeros((n, L), np.int32)
+        aux_key = next((k for k in ex[0] if re.fullmatch(r'encoder_\d+_targets', k)), None)
+        A = None
+        if aux_key is not None and self._engine.aux is not None:
+            a0 = np.asarray(ex[0][aux_key])
+            A = np.zeros((n, T) + a0.shape[1:], np.float32 if a0.dtype.kind == 'f' else np.int32)
+        for i, e in enumerate(ex):
+            x = e['encoder_inputs']
+            X[i, :x.shape[0]] = x
+            y = np.asarray(e['decoder_targets'])[:L]
+            Y[i, :len(y)] = y
+            if A is not None:
+                a = np.asarray(e[aux_key])[:T]
+                A[i, :a.shape[0]] = a if A.ndim == 3 else a.reshape(-1)
+        return dict(X=X, Y=Y, A=A, n=n, T=T, L=L)
+
+    def _batches(self, data, rng=None):
+        B = self.N_cases
+        order = np.arange(data['n']) if rng is None else rng.permutation(data['n'])
+        for i in range(0, data['n'], B):
+            yield order[i:i + B]
+
+    def _load_batch(self, eng, ws, data, idx):
+        import torch
+        B = ws['B']
+
+        def put(dst, src):
+            dst.zero_()
+            dst[:len(idx)].copy_(torch.from_numpy(np.ascontiguousarray(src[idx])))
+        put(ws['X'], data['X'])
+        put(ws['Y'], data['Y'])
+        if data['A'] is not None and eng.aux is not None:
+            put(ws['auxT'], data['A'])
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, subjects, _restore_epoch=None, train_vars_scope=None, reuse_vars_scope=None):
+        """Train for self.N_epochs epochs; assess every assessment_epoch_interval epochs on the last subject's
+        'training' and 'validation' partitions (EMA weights); checkpoint at the end."""
+        import torch
+        eng = self._get_engine(subjects)
+        start = 0
+        if _restore_epoch:
+            self._restore(eng, _restore_epoch, reuse_vars_scope)
+            start = _restore_epoch
+        names = self._tf_names(eng)
+        if train_vars_scope:
+            eng.trainable = {seg for seg, tf in names.items() if re.match(train_vars_scope, tf)}
+        else:
+            eng.trainable = None
+        sync = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            from .parallel import GradSync, broadcast_flat, shard_range
+            sync = GradSync(eng.store.g, self.process_group)
+            broadcast_flat([eng.store.p, eng.store.ema], group=self.process_group)
+            eng.pack('p')
+        staged = {s.subnet_id: {part: self._stage(s, part) for part in ('training', 'validation')} for s in subjects}
+        if sync is not None:       # shard utterances by rank
+            r, w = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            for sid, parts in staged.items():
+                d = parts['training']
+                lo, hi = shard_range(d['n'], r, w)
+                for k in ('X', 'Y', 'A'):
+                    if d[k] is not None:
+                        d[k] = d[k][lo:hi]
+                d['n'] = hi - lo
+        last = subjects[-1]
+        res = {p: AssessmentTuple(decoder_accuracies=[], decoder_word_error_rates=[], decoder_confusions=None, losses=[])
+               for p in ('training', 'validation')}
+        rng = np.random.default_rng(self.seed + start)
+        interval = self.assessment_epoch_interval or self.N_epochs
+        for epoch in range(self.N_epochs):
+            if epoch % interval == 0:
+                for part in res:
+                    a = self._assess(eng, last, staged[last.subnet_id][part])
+                    res[part].decoder_accuracies.append(a.accuracy)
+                    res[part].decoder_word_error_rates.append(a.word_error_rate)
+                    res[part].decoder_confusions = a.decoder_confusions
+                    res[part].hypotheses, res[part].references = a.hypotheses, a.references
+                self.vprint('epoch %4d  train acc %.3f WER %.3f | valid acc %.3f WER %.3f' % (
+                    start + epoch, res['training'].decoder_accuracies[-1], res['training'].decoder_word_error_rates[-1],
+                    res['validation'].decoder_accuracies[-1], res['validation'].decoder_word_error_rates[-1]))
+            iters = [(s.subnet_id, self._batches(staged[s.subnet_id]['training'], rng)) for s in subjects]
+            live = list(iters)
+            while live:                                   # round-robin over subjects (multi-task 'parallel' learning)
+                for item in list(live):
+                    sid, it = item
+                    idx = next(it, None)
+                    if idx is None:
+                        live.remove(item)
+                        continue
+                    d = staged[sid]['training']
+                    ws = eng.workspace(sid, self.N_cases, d['T'], d['L'])
+                    self._load_batch(eng, ws, d, idx)
+                    eng.train_step(ws, sync=sync)
+            res['training'].losses.append(eng.losses(ws))
+        self._epoch = start + self.N_epochs
+        self._save(eng, self._epoch)
+        for part in res:
+            res[part].decoder_accuracies = np.array(res[part].decoder_accuracies)
+            res[part].decoder_word_error_rates = np.array(res[part].decoder_word_error_rates)
+        return res
+
+    # ------------------------------------------------------------------ assessment (row a11)
+    def _assess(self, eng, subject, data):
+        import torch
+        out = AssessmentTuple()
+        if data is None:
+            out.accuracy = out.word_error_rate = float('nan')
+            return out
+        feats = list(subject.data_manifests['decoder_targets'].get_feature_list())
+        V = len(feats)
+        ws = eng.workspace(subject.subnet_id, self.N_cases, data['T'], data['L'])
+        hyps, refs, ncorrect, ntok = [], [], 0.0, 0
+        conf = np.zeros((V, V), np.int64) if V < 100 else None
+        for idx in self._batches(data):
+            self._load_batch(eng, ws, data, idx)
+            if eng._packed != 'ema':
+                eng.pack('ema')
+            eng.forward(ws, train=False, which='ema', with_aux=False)
+            torch.cuda.synchronize(eng.device)
+            nt = int(ws['ntok'].item())
+            ncorrect += float(ws['loss'][2].item()) * max(nt, 1)
+            ntok += nt
+            if conf is not None:
+                pred = ws['pred'].cpu().numpy().reshape(data['L'], -1)[:, :len(idx)].T
+                for b, i in enumerate(idx):
+                    y = data['Y'][i]
+                    for l in range(int((y != 0).sum())):
+                        conf[y[l], pred[b, l]] += 1
+            hyp = eng.greedy_decode(ws, which='ema').cpu().numpy()[:len(idx)]
+            hyps += target_inds_to_sequences(hyp, feats)
+            refs += target_inds_to_sequences(data['Y'][idx], feats)
+        eng.pack('p')
+        out.accuracy = ncorrect / max(ntok, 1)
+        out.word_error_rate = float(np.mean(wer_vector(refs, hyps))) if refs else float('nan')
+        out.decoder_confusions, out.hypotheses, out.references = conf, hyps, refs
+        return out
+
+    def restore_and_assess(self, subjects, restore_epoch, WRITE=False):
+        eng = self._get_engine(subjects)
+        self._restore(eng, restore_epoch, None)
+        last = subjects[-1]
+        return {part: self._assess(eng, last, self._stage(last, part)) for part in ('training', 'validation')}
+
+    def restore_and_get_saliencies(self, subjects, restore_epoch, data_partition='validation', assessment_type='norms'):
+        """Back-propagate the (penalty-weighted) loss into the inputs (reference trainers.py:703-732).
+        'norms' -> per-electrode RMS gradient [C]; 'sequences' -> [examples, T, C]."""
+        import torch
+        eng = self._get_engine(subjects)
+        self._restore(eng, restore_epoch, None)
+        subject = subjects[-1]
+        data = self._stage(subject, data_partition)
+        ws = eng.workspace(subject.subnet_id, self.N_cases, data['T'], data['L'])
+        eng.pack('ema')
+        chunks = []
+        for idx in self._batches(data):
+            self._load_batch(eng, ws, data, idx)
+            eng.forward(ws, train=False, which='ema')
+            eng.backward(ws, train=False)
+            g = eng.input_gradient(ws)
+            torch.cuda.synchronize(eng.device)
+            chunks.append(g[:len(idx)].cpu().numpy())
+        eng.pack('p')
+        G = np.concatenate(chunks, 0)
+        if assessment_type == 'sequences':
+            return G
+        return np.sqrt((G ** 2).mean(axis=(0, 1)))
+
+    # ------------------------------------------------------------------ checkpoints (rows a13)
+    def _tf_names(self, eng):
+        """segment name -> representative TF-style variable name (for the scope regexes of trainers.py:337-366)."""
+        out = {}
+        for seg in eng.store.order:
+            if seg.startswith('conv'):
+                out[seg] = 'seq2seq/subnet_%s/encoder_embedding' % seg[4:-2]
+            elif seg.startswith('enc'):
+                out[seg] = 'seq2seq/encoder_rnn_%s' % seg[3:].split('.')[0]
+            elif seg.startswith('aux'):
+                out[seg] = 'seq2seq/encoder_%s_projection' % eng.spec.aux_layer
+            elif seg == 'dec.emb':
+                out[seg] = 'seq2seq/decoder_embedding'
+            elif seg.startswith('dec.'):
+                out[seg] = 'seq2seq/decoder_rnn'
+            else:
+                out[seg] = 'seq2seq/decoder_projection'
+        return out
+
+    def _ckpt(self, epoch):
+        return '%s-%d' % (self.checkpoint_path, epoch)
+
+    def _save(self, eng, epoch):
+        import torch
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+            return
+        arrays = dict(eng.store.export_tf('p'))
+        arrays.update({k + EMA_SUFFIX: v for k, v in eng.store.export_tf('ema').items()})
+        arrays['__adam_m'] = eng.store.m.cpu().numpy()
+        arrays['__adam_v'] = eng.store.v.cpu().numpy()
+        arrays['__step'] = eng.step_t.cpu().numpy()
+        os.makedirs(os.path.dirname(self.checkpoint_path) or '.', exist_ok=True)
+        np.savez(self._ckpt(epoch) + '.npz', **arrays)
+        open(self._ckpt(epoch) + '.index', 'w').close()          # marker the trainer's restore_epoch scan looks for
+
+    def _restore(self, eng, epoch, reuse_vars_scope):
+        import torch
+        z = np.load(self._ckpt(epoch) + '.npz')
+        P = {k: z[k] for k in z.files if not k.startswith('__') and not k.endswith(EMA_SUFFIX)}
+        E = {k[:-len(EMA_SUFFIX)]: z[k] for k in z.files if k.endswith(EMA_SUFFIX)}
+        if reuse_vars_scope is not None:
+            # variables outside the reused scope keep their fresh initialisation (trainers.py:352-353)
+            cur_p, cur_e = eng.store.export_tf('p'), eng.store.export_tf('ema')
+            for k in list(P):
+                if not re.match(reuse_vars_scope, k) or k not in cur_p or cur_p[k].shape != P[k].shape:
+                    P[k], E[k] = cur_p.get(k, P[k]), cur_e.get(k, E[k])
+        have = eng.store.export_tf('p')
+        P = {k: P.get(k, have[k]) for k in have}
+        E = {k: E.get(k, P[k]) for k in have}
+        eng.store.import_tf(P, bufs=('p',))
+        eng.store.import_tf(E, bufs=('ema',))
+        if '__adam_m' in z.files and z['__adam_m'].shape[0] == eng.store.n and reuse_vars_scope in (None, 'seq2seq'):
+            eng.store.m.copy_(torch.from_numpy(z['__adam_m']))
+            eng.store.v.copy_(torch.from_numpy(z['__adam_v']))
+            eng.step_t.copy_(torch.from_numpy(z['__step']))
+        eng.pack('p')
+
+    def get_weights_as_numpy_array(self, full_var_name, epoch):
+        z = np.load(self._ckpt(epoch) + '.npz')
+        return z[full_var_name]

@@ -1,0 +1,106 @@
+"""End-to-end on the GPU through the reference-shaped boundary: README flow, transfer-learning
+schedules with regex scopes, checkpoint discovery, assessment, saliency."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ecog2txt_amd.data_generators import ECoGDataGenerator, SyntheticSpeechDataGenerator
+from experiment_fixture import make_experiment
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def small(tmp_path, monkeypatch):
+    monkeypatch.setattr(ECoGDataGenerator, 'text_dir', str(tmp_path))
+    monkeypatch.setattr(SyntheticSpeechDataGenerator, 'num_sentences', 6)
+    monkeypatch.setattr(SyntheticSpeechDataGenerator, 'trials_per_block', 24)
+    monkeypatch.setattr(SyntheticSpeechDataGenerator, 'max_words', 5)
+    return tmp_path
+
+
+def test_readme_flow_learns(small):
+    """README.md:72-102 usage, unchanged: construct, write records, parallel_transfer_learn.  Six sentences
+    with sentence-dependent ECoG must be learnt almost perfectly."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    path = make_experiment(small, subject_ids=(401,), epochs=60, interval=20)
+    ck = str(small / 'ck'); os.makedirs(ck)
+    tr = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False,
+                             SN_kwargs={'N_cases': 32, 'learning_rate': 3e-3, 'FF_dropout': 0.0, 'RNN_dropout': 0.1, 'EMA_decay': 0.9},
+                             DG_kwargs={'max_samples': 420})
+    for s in tr.ecog_subjects:
+        s.write_tf_records_maybe()
+    a = tr.parallel_transfer_learn()
+    wer = a['validation'].decoder_word_error_rates
+    acc = a['validation'].decoder_accuracies
+    assert len(wer) == 3 and wer[0] > 0.8
+    assert a['training'].losses[-1]['decoder'] < 0.5 * a['training'].losses[0]['decoder']
+    assert tr.restore_epoch == 60 and os.path.exists(os.path.join(ck, 'model.ckpt-60.index'))
+    assert os.path.exists(os.path.join(str(small), 'saved_results'))
+    # restore + assess reproduces a finished model; WER must be low
+    res = tr.assess_saved_model()
+    assert res['validation'].word_error_rate < 0.25, res['validation'].word_error_rate
+    assert res['validation'].accuracy > 0.8
+    assert res['validation'].decoder_confusions.shape == (23, 23)
+    # sizes recovered from the checkpoint by the reference's variable grammar
+    ls, ds, strides, ema = tr.recover_model_sizes()
+    assert ls['encoder_rnn'] == [32, 32] and ls['decoder_rnn'] == [64] and ls['encoder_embedding'] == [24]
+    assert ds['401']['encoder_inputs'] == 16 and ds[None]['decoder_targets'] == 23 and strides['401'] == [12] and ema
+    # saliency: gradient w.r.t. the inputs, per electrode and per sample
+    sal = tr.get_saliencies('decoder_saliency_map')
+    assert sal.shape == (16,) and np.isfinite(sal).all() and sal.max() > 0
+    seqs = tr.get_saliencies('decoder_saliency_map', assessment_type='sequences')
+    assert seqs.ndim == 3 and seqs.shape[2] == 16
+    w = tr.net.get_weights_as_numpy_array('seq2seq/subnet_401/encoder_embedding_16_24_0/weights/ExponentialMovingAverage', 60)
+    assert w.shape == (1, 12, 16, 24)
+
+
+def test_sequential_transfer_and_resume(small):
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    path = make_experiment(small, subject_ids=(400, 401), epochs=2, interval=1)
+    ck = str(small / 'ck'); os.makedirs(ck)
+    tr = MultiSubjectTrainer(path, [400, 401], checkpoint_dir=ck, VERBOSE=False, SN_kwargs={'N_cases': 32},
+                             DG_kwargs={'max_samples': 420})
+    for s in tr.ecog_subjects:
+        s.write_tf_records_maybe()
+    tr.sequential_transfer_learn(pretraining_epochs=1, training_epochs=2, posttraining_epochs=1)
+    assert tr.restore_epoch == 2 + 1 + 3
+    for e in (2, 3, 6):
+        assert os.path.exists(os.path.join(ck, 'model.ckpt-%d.index' % e))
+    # during subject 401's pre-training only its own sub-network may move
+    z2, z3, z6 = (np.load(os.path.join(ck, 'model.ckpt-%d.npz' % e)) for e in (2, 3, 6))
+    k_shared, k_own = 'seq2seq/decoder_rnn/cell_0/kernel', 'seq2seq/subnet_401/encoder_embedding_16_24_0/weights'
+    # a sub-network exists only in fits that include its subject (as in the reference's per-fit graph)
+    assert k_own not in z2.files and 'seq2seq/subnet_400/encoder_embedding_16_24_0/weights' in z2.files
+    assert np.array_equal(z2[k_shared], z3[k_shared])          # shared body restored and frozen during pre-training
+    assert not np.array_equal(z3[k_shared], z6[k_shared])      # ... and trained afterwards
+    assert not np.array_equal(z3[k_own], z6[k_own])
+    a = tr.parallel_transfer_learn(RESUME=True)
+    assert len(a['training'].decoder_accuracies) == tr.net.N_epochs
+
+
+def test_staged_backward_graphs_match_single_graph():
+    """The data-parallel step replays one hipGraph per backward stage; with a no-op exchange it must
+    reproduce the single-graph step."""
+    from test_gpu_parity import build, SPECS
+
+    class FakeSync:
+        world, grad_scale = 2, 1.0
+        def __init__(self): self.calls = []
+        def allreduce_range(self, a, b): self.calls.append((a, b))
+        def wait(self): pass
+    eng, ws, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+    eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+    fs = FakeSync()
+    for _ in range(3):
+        eng.train_step(ws, use_graph=True)
+        eng2.train_step(ws2, use_graph=True, sync=fs)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(eng.store.p.cpu().numpy(), eng2.store.p.cpu().numpy(), atol=1e-5)
+    # every parameter element was offered for reduction exactly once per step, in backward order
+    per_step = fs.calls[:len(fs.calls) // 3]
+    covered = sorted(per_step)
+    assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+    assert covered[-1][1] == eng.store.seg_range('conv401.W')[1]
