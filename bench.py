@@ -191,11 +191,25 @@ def main():
         torch.cuda.synchronize()
         us_per_launch = e0.elapsed_time(e1) * 1e3 / (reps * S)
         H = lay.H
-        flops_launch = 2 * B * H * 4 * H * 2
+        flops_launch = 2 * B * H * 4 * H * 2          # both directions: [B,H] x [H,4H], 2 flop per MAC
         ach = flops_launch / (us_per_launch * 1e-6) / 1e12
+        # HBM-side bytes per launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # passes, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes); a measured constant of this round, not live
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+                t = json.load(f)['k_lstm_step_fwd']
+            if args.config == 'cfg2' and B == 256:
+                traffic = t['hbm_read_bytes'] + t['hbm_write_bytes']
+        except Exception:
+            pass
+        # algorithmic HBM bytes of one step launch: Gx in, gates + c out, c_{t-1} in, h out (x2 dirs)
+        alg_bytes = 2 * B * H * (16 + 16 + 4 + 4 + 2 + 2)
         roof = dict(bound='mfma', kernel='k_lstm_step_fwd', achieved=round(ach, 3), peak=MFMA_BF16_PEAK_TFLOPS,
-                    unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 5), traffic=None,
-                    us_per_launch=round(us_per_launch, 3), flops_per_launch=flops_launch)
+                    unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 5), traffic=traffic,
+                    us_per_launch=round(us_per_launch, 3), flops_per_launch=flops_launch,
+                    algorithmic_hbm_bytes_per_launch=alg_bytes,
+                    note='latency-bound: one launch = one time step of one layer, 0.66 GFLOP; see DESIGN.md section 5')
 
     if rank == 0:
         utt = B * world * args.steps / el
