@@ -10,11 +10,13 @@
 // (nn.sequences_tools usage at ecog2txt/trainers.py:789-790, 806-807).
 // One workgroup per utterance, one wave per time row, 16-B coalesced loads.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_seq_lengths_f32(const float* x, int T, int C, int div, int* lens, int* lens_div) {
+__global__ __launch_bounds__(1024) void k_seq_lengths_f32(const float* x, int T, int C, int div, int* lens, int* lens_div) {
+    // one 16-wave workgroup per utterance, one wave per time row: 4096 waves in flight for B = 256
+    // (no atomics, no pre-zeroing: the result is written once, so the launch is replay-safe)
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* xb = x + (size_t)b * T * C;
     int cnt = 0;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += 16) {
         const float* row = xb + (size_t)t * C;
         bool nz = false;
         if ((C & 3) == 0) {
@@ -27,11 +29,12 @@ __global__ __launch_bounds__(256) void k_seq_lengths_f32(const float* x, int T, 
         }
         if (__any(nz)) cnt++;            // wave-uniform
     }
-    __shared__ int sc[4];
+    __shared__ int sc[16];
     if (lane == 0) sc[wave] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int n = sc[0] + sc[1] + sc[2] + sc[3];
+        int n = 0;
+        for (int i = 0; i < 16; ++i) n += sc[i];
         lens[b] = n;
         if (lens_div) lens_div[b] = (n + div - 1) / div;
     }
@@ -161,18 +164,44 @@ __global__ void k_decoder_tokens(const int* y, int B, int L, int eos, int* U, in
 // bf16 transpose through LDS: out[c][r] = in[r][c], r < R, c < Ccols; columns
 // R..ld_out-1 of every written output row are zero-filled (K padding for the GEMM).
 // ---------------------------------------------------------------------------
+// 64x64 tile per workgroup: 16-B global loads along the input rows, 2-B scatter into a padded LDS tile,
+// 16-B LDS reads along the transposed direction, 16-B global stores (needs ld_out % 8 == 0; falls back to
+// element stores otherwise).
 __global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* in, int ld_in, int R, int Ccols, bf16_t* out, int ld_out) {
-    __shared__ bf16_t tile[64][66];
+    __shared__ bf16_t tile[64][72];                    // [c][r], row pitch 144 B (16-B aligned, conflict-light)
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < Ccols) ? in[(size_t)r * ld_in + c] : (bf16_t)0;
+    const int tid = threadIdx.x;
+    const bool in_vec = (ld_in & 7) == 0 && (((uintptr_t)in) & 15) == 0;
+    // load: thread -> (row = tid/8 + 32*i, 8 columns starting at (tid%8)*8)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = (tid >> 3) + 32 * i, cl = (tid & 7) * 8;
+        const int r = r0 + rl, c = c0 + cl;
+        bf16_t v[8];
+        if (r < R && in_vec && c + 7 < Ccols) {
+            const uint4 q = *(const uint4*)(in + (size_t)r * ld_in + c);
+            v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+            v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (r < R && c + j < Ccols) ? in[(size_t)r * ld_in + c + j] : (bf16_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[cl + j][rl] = v[j];
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < Ccols && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][i];
+    // store: thread -> (out row c = tid/8 + 32*i, 8 consecutive r starting at (tid%8)*8)
+    const bool out_vec = (ld_out & 7) == 0 && (((uintptr_t)out) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cl = (tid >> 3) + 32 * i, rl = (tid & 7) * 8;
+        const int c = c0 + cl, r = r0 + rl;
+        if (c >= Ccols || r >= ld_out) continue;
+        if (out_vec && r + 7 < ld_out) {
+            *(uint4*)(out + (size_t)c * ld_out + r) = *(const uint4*)&tile[cl][rl];
+        } else {
+            for (int j = 0; j < 8 && r + j < ld_out; ++j) out[(size_t)c * ld_out + r + j] = tile[cl][rl + j];
+        }
     }
 }
 
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, floa
 
 extern "C" int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream) {
     E2T_CHECK_ARG(x && lens && B > 0 && T > 0 && C > 0 && div > 0);
-    hipLaunchKernelGGL(k_seq_lengths_f32, dim3(B), dim3(256), 0, ST, x, T, C, div, lens, lens_div);
+    hipLaunchKernelGGL(k_seq_lengths_f32, dim3(B), dim3(1024), 0, ST, x, T, C, div, lens, lens_div);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int div, int32_t* lens, int32_t* lens_div, void* stream) {

@@ -233,7 +233,7 @@ struct LstmFwdArgs {
     float* Gs;              // lane-native, see above
     const int* lens;        // [B]
     const float* c0;        // [B][ndir*H] or null
-    int S, B, H, H8, ndir, ldy, UT, KB, step, ablate;
+    int S, B, H, H8, ndir, ldy, UT, KB, step, ablate, rb_begin, rb_count;
     float forget_bias;
     DropCfg drop;
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
@@ -245,12 +245,12 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     // XCD-aware tile map: the dispatcher places workgroup id on XCD id % 8 (observed, speed only);
     // XCD x owns the unit tiles ut == x (mod 8) for every row block and direction, so its slice of
     // the W_h image (1/8 of it) stays resident in that XCD's L2 for all S steps of the sequence.
-    const int RB = (p.B + 63) >> 6, RT = (p.B + 15) >> 4;
+    const int RB = p.rb_count, RT = (p.B + 15) >> 4;            // this launch covers row blocks [rb_begin, rb_begin + rb_count)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ut = (slot / (RB * p.ndir)) * 8 + xcd;
     if (ut >= p.UT) return;
     const int rem = slot % (RB * p.ndir);
-    const int rb = rem % RB, dir = rem / RB;
+    const int rb = p.rb_begin + rem % RB, dir = rem / RB;
     const int s = p.step, B = p.B, H = p.H, KB = p.KB;
     const int frow = lane & 15, fq = lane >> 4;
     const int NH = p.ndir * H;
@@ -396,19 +396,19 @@ struct LstmBwdArgs {
     float* dc_carry;        // [B][ndir*H] workspace (in/out)
     float* dh0;             // [B][ndir*H] out, written when step == -1 (else untouched)
     float* dc0;             // [B][ndir*H] out, written when step == -1
-    int S, B, H, H8, ndir, lddg, lddy, UT, KB4, step;
+    int S, B, H, H8, ndir, lddg, lddy, UT, KB4, step, rb_begin, rb_count;
     DropCfg drop;
 };
 
 __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int RB = (p.B + 63) >> 6, RT = (p.B + 15) >> 4;
+    const int RB = p.rb_count, RT = (p.B + 15) >> 4;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ut = (slot / (RB * p.ndir)) * 8 + xcd;          // same XCD-aware map as the forward kernel
     if (ut >= p.UT) return;
     const int rem = slot % (RB * p.ndir);
-    const int rb = rem % RB, dir = rem / RB;
+    const int rb = p.rb_begin + rem % RB, dir = rem / RB;
     const int s = p.step, B = p.B, H = p.H, KB = p.KB4;
     const int frow = lane & 15, fq = lane >> 4;
     const int K4 = 4 * H;
@@ -555,7 +555,11 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     const StepGeom G = step_geom(p.KB, 4, 4 * 256 + 1024);
     const size_t lds = ((size_t)G.nbuf * G.bufsz + 4 * 256 + 1024) * 16;
-    dim3 grid(8 * ((p.UT + 7) / 8) * ((d->B + 63) / 64) * d->ndir);      // XCD-major tile map, see kernel
+    const int nrb = (d->B + 63) / 64;
+    p.rb_begin = d->rb_count > 0 ? d->rb_begin : 0;
+    p.rb_count = d->rb_count > 0 ? d->rb_count : nrb;
+    E2T_CHECK_ARG(p.rb_begin >= 0 && p.rb_begin + p.rb_count <= nrb);
+    dim3 grid(8 * ((p.UT + 7) / 8) * p.rb_count * d->ndir);      // XCD-major tile map, see kernel
     for (int s = step_begin; s < step_end; ++s) {
         p.step = s;
         hipLaunchKernelGGL(k_lstm_step_fwd, grid, dim3(512), lds, (hipStream_t)stream, p);
@@ -583,7 +587,11 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     const StepGeom G = step_geom(p.KB4, 1, 256);
     const size_t lds = ((size_t)G.nbuf * G.bufsz + 256) * 16;
-    dim3 grid(8 * ((p.UT + 7) / 8) * ((d->B + 63) / 64) * d->ndir);      // XCD-major tile map, see kernel
+    const int nrb = (d->B + 63) / 64;
+    p.rb_begin = d->rb_count > 0 ? d->rb_begin : 0;
+    p.rb_count = d->rb_count > 0 ? d->rb_count : nrb;
+    E2T_CHECK_ARG(p.rb_begin >= 0 && p.rb_begin + p.rb_count <= nrb);
+    dim3 grid(8 * ((p.UT + 7) / 8) * p.rb_count * d->ndir);      // XCD-major tile map, see kernel
     for (int s = d->S - 1; s >= (dh0 ? -1 : 0); --s) {
         p.step = s;
         hipLaunchKernelGGL(k_lstm_step_bwd, grid, dim3(512), lds, (hipStream_t)stream, p);

@@ -418,10 +418,16 @@ class _Lstm:
             e.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, M, self.N4, self.in_ld,
                    bias=self.bias_ptr(src))
             steps = (0, ws['S'])
-        d = self.desc(ws, train)
-        lib.e2t_lstm_seq_fwd(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
-                             ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
-                             c0.data_ptr() if c0 is not None else None, steps[0], steps[1], e.stream)
+        def launch(rb0, nrb, stream):
+            d = self.desc(ws, train)
+            d.rb_begin, d.rb_count = rb0, nrb
+            lib.e2t_lstm_seq_fwd(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
+                                 ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
+                                 c0.data_ptr() if c0 is not None else None, steps[0], steps[1], stream)
+        if steps[1] - steps[0] > 1:
+            e.run_chains(ws['B'], launch)
+        else:
+            launch(0, 0, e.stream)
 
     def bwd(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
             dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0):
@@ -431,11 +437,15 @@ class _Lstm:
         st = e.store
         M, Mk, S, B = ws['M'], ws['Mk'], ws['S'], ws['B']
         nd, Hh = self.ndir, self.H
-        d = self.desc(ws, train)
         p = lambda t: t.data_ptr() if t is not None else None
-        lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
-                             ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
-                             ws['dc_carry'].data_ptr(), p(dh0), p(dc0), e.stream)
+
+        def launch(rb0, nrb, stream):
+            d = self.desc(ws, train)
+            d.rb_begin, d.rb_count = rb0, nrb
+            lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
+                                 ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
+                                 ws['dc_carry'].data_ptr(), p(dh0), p(dc0), stream)
+        e.run_chains(B, launch)
         lib.e2t_transpose_bf16(ws['dG'].data_ptr(), r8(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
@@ -497,6 +507,8 @@ class Seq2SeqEngine:
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
                              [(0, s.dec_rnn, 0)], r8(s.dec_rnn), STREAM_DEC_OUT + 1)
         self._pack_table = None
+        self.chains = 1          # >1 measured slower: a step launch is bound by chip-level L2-miss traffic, not latency
+        self._side = []
         self._ws = {}
         self._packed = None
         self.splitk_ws = _f32(16 * 1024 * 1024, device=dev)          # 64 MiB of split-K partial slabs
@@ -556,6 +568,35 @@ class Seq2SeqEngine:
         d = H.Dropout()
         d.rate, d.seed, d.step, d.stream = rate, self.seed, self.step_t.data_ptr(), stream
         return d
+
+    # ------------------------------------------------------------------ concurrent row-block chains
+    def run_chains(self, B, launch):
+        """A recurrence is latency-bound and its 64-utterance row blocks never interact inside a layer, so the
+        S step launches are issued as up to `self.chains` independent chains on side streams (parallel branches
+        of the captured hipGraph): one chain's launch + memory latency overlaps another chain's work.
+        launch(rb_begin, rb_count, stream_handle)."""
+        nrb = ceil_div(B, 64)
+        n = max(1, min(self.chains, nrb))
+        cur = torch.cuda.current_stream(self.device)
+        if n == 1:
+            launch(0, nrb, cur.cuda_stream)
+            return
+        while len(self._side) < n:
+            self._side.append(torch.cuda.Stream(device=self.device))
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        base, rem = divmod(nrb, n)
+        lo = 0
+        for c in range(n):
+            cnt = base + (1 if c < rem else 0)
+            st = self._side[c]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                launch(lo, cnt, st.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(st)
+            cur.wait_event(done)
+            lo += cnt
 
     # ------------------------------------------------------------------ packing
     def pack(self, which='p'):

@@ -28,7 +28,7 @@ class GemmEpilogue(C.Structure):
 class LstmDesc(C.Structure):
     _fields_ = [('S', C.c_int), ('B', C.c_int), ('H', C.c_int), ('ndir', C.c_int), ('ldy', C.c_int),
                 ('forget_bias', C.c_float), ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong),
-                ('drop_step', C.c_void_p), ('drop_stream', C.c_uint)]
+                ('drop_step', C.c_void_p), ('drop_stream', C.c_uint), ('rb_begin', C.c_int), ('rb_count', C.c_int)]
 
 
 class PackDesc(C.Structure):

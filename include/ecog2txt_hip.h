@@ -112,6 +112,8 @@ typedef struct e2t_lstm_desc {
     int ldy;                       /* leading dim of Yext / Ydrop (>= ndir * roundup(H,8), multiple of 8) */
     float forget_bias;
     float drop_rate; unsigned long long drop_seed; const int32_t* drop_step; unsigned drop_stream;
+    int rb_begin, rb_count;        /* restrict the launches to utterance blocks [rb_begin, rb_begin+rb_count) of 64 rows
+                                      (rb_count 0 = all); disjoint ranges are independent and may run on different streams */
 } e2t_lstm_desc;
 /* Gx [S*B][ndir*H*4] fp32 (dir,unit,gate interleaved; bias folded in); WhF: e2t_pack_frag images
  * [ndir][4][UT][KB]; Yext bf16 [(S+3)*B][ldy] (time block t+1; block 0 = initial state, blocks S+1, S+2
