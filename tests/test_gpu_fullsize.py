@@ -1,0 +1,133 @@
+"""BASELINE.json sizes (cfg2: 256 electrodes x 400 samples, B = 256, 3 x biLSTM(400), decoder 800, V = 1806),
+where the oracle is too slow to be the checker: size-independent properties of the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cfg2():
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    kw, B, T, L = bench.CONFIGS['cfg2']
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=5)
+    eng.init_params(seed=0)
+    batch = bench.synth_batch(kw, B, T, L, seed=3)
+    # ragged: cut every utterance to its own length
+    rng = np.random.default_rng(0)
+    lens = rng.integers(240, T + 1, size=B)
+    lens[0] = T
+    for b in range(B):
+        batch['encoder_inputs'][b, lens[b]:] = 0
+        batch['encoder_targets'][b, lens[b]:] = 0
+    return eng, kw, B, T, L, batch, lens
+
+
+def run(eng, ws, batch, train=False):
+    eng.set_batch(ws, batch)
+    eng.forward(ws, train=train)
+    eng.backward(ws, train=train)
+    torch.cuda.synchronize()
+    return eng.losses(ws), eng.store.g.clone()
+
+
+def test_initial_loss_and_lengths(cfg2):
+    eng, kw, B, T, L, batch, lens = cfg2
+    ws = eng.workspace(401, B, T, L)
+    losses, g = run(eng, ws, batch)
+    np.testing.assert_array_equal(ws['lens'].cpu().numpy(), lens)
+    np.testing.assert_array_equal(ws['lens_d'].cpu().numpy(), -(-lens // 12))
+    assert abs(losses['decoder'] - np.log(1806)) < 0.15          # near-uniform softmax at initialisation
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+def test_deterministic_and_permutation_invariant(cfg2):
+    """Same batch twice -> identical losses; permuting the utterances permutes nothing in the (mean) losses and
+    leaves the gradient unchanged up to fp32 summation order."""
+    eng, kw, B, T, L, batch, lens = cfg2
+    ws = eng.workspace(401, B, T, L)
+    l1, g1 = run(eng, ws, batch, train=True)
+    l2, g2 = run(eng, ws, batch, train=True)
+    assert l1 == l2
+    perm = np.random.default_rng(1).permutation(B)
+    pb = {k: (v[perm] if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+    l3, g3 = run(eng, ws, pb, train=False)
+    l0, g0 = run(eng, ws, batch, train=False)
+    assert abs(l3['decoder'] - l0['decoder']) < 2e-5 and abs(l3['aux'] - l0['aux']) < 2e-5
+    scale = float(g0.abs().max())
+    assert float((g3 - g0).abs().max()) < 2e-3 * scale
+
+
+def test_extra_zero_padding_changes_nothing(cfg2):
+    """Utterances are delimited by their zero padding (trainers.py:806-807): 24 more padded samples (two more
+    encoder steps) must not change losses or gradients."""
+    eng, kw, B, T, L, batch, lens = cfg2
+    ws = eng.workspace(401, B, T, L)
+    l0, g0 = run(eng, ws, batch)
+    pad = lambda a: np.concatenate([a, np.zeros((a.shape[0], 24) + a.shape[2:], a.dtype)], 1)
+    pb = dict(batch, encoder_inputs=pad(batch['encoder_inputs']), encoder_targets=pad(batch['encoder_targets']))
+    ws2 = eng.workspace(401, B, T + 24, L)
+    l1, g1 = run(eng, ws2, pb)
+    assert abs(l1['decoder'] - l0['decoder']) < 1e-6 and abs(l1['aux'] - l0['aux']) < 1e-6
+    assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max()) + 1e-9
+
+
+def test_loss_scale_linearity(cfg2):
+    """Gradients are linear in the penalty scales (trainers.py:98-102): doubling the decoder scale with the aux
+    scale at zero doubles every gradient (up to bf16 rounding of the scaled dlogits)."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    eng, kw, B, T, L, batch, lens = cfg2
+    gs = []
+    for sc in (1.0, 2.0):
+        e2 = Seq2SeqEngine(NetSpec(**dict(kw, dec_scale=sc, aux_scale=0.0)), device='cuda:0', seed=5)
+        e2.store.p.copy_(eng.store.p)
+        e2.pack('p')
+        ws = e2.workspace(401, 64, T, L)
+        sub = {k: (v[:64] if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+        _, g = run(e2, ws, sub)
+        gs.append(g)
+    # powers of two commute with bf16 rounding exactly
+    assert float((gs[1] - 2 * gs[0]).abs().max()) <= 1e-6 * float(gs[1].abs().max())
+
+
+def test_greedy_matches_teacher_forcing_on_its_own_output(cfg2):
+    eng, kw, B, T, L, batch, lens = cfg2
+    ws = eng.workspace(401, B, T, L)
+    eng.set_batch(ws, batch)
+    hyp = eng.greedy_decode(ws, which='p').cpu().numpy()
+    assert hyp.shape == (B, L) and hyp.min() >= 0 and hyp.max() < 1806
+    Y = hyp.copy()
+    for b in range(B):
+        if 1 not in Y[b]:
+            Y[b, -1] = 1
+        else:
+            Y[b, np.argmax(Y[b] == 1) + 1:] = 0
+    eng.set_batch(ws, dict(batch, decoder_targets=Y))
+    eng.forward(ws, train=False)
+    torch.cuda.synchronize()
+    pred = ws['pred'].cpu().numpy().reshape(L, B).T
+    valid = (Y != 0) & (Y == hyp)            # slots where an <EOS> was forced in are not greedy outputs
+    assert valid.mean() > 0.8 and (pred[valid] == Y[valid]).mean() > 0.999
+
+
+@pytest.mark.parametrize('name', ['cfg4', 'cfg5'])
+def test_other_baseline_configs_step(name):
+    """cfg4 (H=1024, 4 layers, decoder 2048) and cfg5 (1024 electrodes x 2000 samples) at reduced batch: a few
+    optimisation steps run, stay finite and reduce the loss on a repeated batch."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    kw, B, T, L = bench.CONFIGS[name]
+    B = 64
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=2, lr=2e-3)
+    eng.init_params(seed=0)
+    ws = eng.workspace(401, B, T, L)
+    eng.set_batch(ws, bench.synth_batch(kw, B, T, L, seed=1))
+    first = None
+    for i in range(6):
+        eng.train_step(ws)
+        if i == 0:
+            first = eng.losses(ws)
+    last = eng.losses(ws)
+    assert np.isfinite(last['total']) and last['decoder'] < first['decoder']
