@@ -81,7 +81,16 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_addr
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(m) : "memory");
 }
+// same, with the sc1 cache policy: bypasses the CU's L1, so data another workgroup published with
+// write-through (sc1 / agent-scope atomic) stores during THIS launch is seen (cdna_hip_programming.md G16, R1)
+__device__ __forceinline__ void dma16_to_lds_sc1(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(m) : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dma_wait_all_but2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 
 // wave-level reductions (64 lanes) via shuffles
 __device__ __forceinline__ float wave_max(float v) {

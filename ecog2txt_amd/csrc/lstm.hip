@@ -61,7 +61,7 @@ __device__ __forceinline__ size_t native_tile(int s, int dir, int rt, int ut, in
 }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fsigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * fast_rcp(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float ftanh(float x) { return fmaf(-2.0f, fast_rcp(__expf(2.0f * x) + 1.0f), 1.0f); }   // explicit fma: every kernel rounds alike
 
 __device__ __forceinline__ float drop_scale_k(float rate, unsigned long long key, unsigned stream, unsigned long long idx) {
     if (rate <= 0.0f) return 1.0f;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
             const float gj = ftanh(z[1][rr] + gx.y);
             const float gf = fsigmoid(z[2][rr] + gx.z + p.forget_bias);
             const float go = fsigmoid(z[3][rr] + gx.w);
-            cv[rr] = gf * cp[rr] + gi * gj;
+            cv[rr] = fmaf(gf, cp[rr], gi * gj);           // explicit: identical rounding in the step and persistent kernels
             hv[rr] = go * ftanh(cv[rr]);
             if (rr < nu) nt_store_f4(p.Gs + ((tile * 4 + 2 * khalf + rr) * 64 + lane) * 4, gi, gj, gf, go);
             hd[rr] = hv[rr] * (khalf ? dsc4[2 + rr] : dsc4[rr]);
@@ -383,6 +383,223 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
         for (int r = 0; r < nu; ++r) { yp[r] = 0; if (ydp) ydp[r] = 0; }
     }
 }
+
+// ---------------------------------------------------------------------------
+// Persistent forward recurrence: ONE launch runs all S steps of a layer (both directions).
+// Ownership as in k_lstm_step_fwd (workgroup = 16 units x 64 utterances x direction) but with 4 waves at ONE
+// wave per SIMD, so a wave may hold 512 registers:
+//   * weight-stationary in REGISTERS: the wave keeps the W_h fragments of its 16 units, all four gates, the whole
+//     K range (4 x KB x 4 registers) for the entire sequence; there is no LDS image and no workgroup barrier;
+//   * h is handed from step to step through a small double-buffered exchange array `hx` laid out in MFMA operand
+//     order and indexed by STEP PARITY (the state of an utterance at step s+1 is what its row produced at step s,
+//     whatever its time index), so a consumer load instruction is one contiguous KiB (fragment-layout loads
+//     from the row-major output array touch 16 cache lines per 16 lanes and are L1-tag bound: 2.4 us vs 0.5 us)
+//     and a cluster's working set (51 KiB per buffer at H=400) lives in its XCD's L2.  Loads use the sc1 policy
+//     (bypass the CU's L1: other CUs wrote the data during this launch).  Step 0 reads the initial state from the
+//     row-major array.  The row-major, time-indexed copy for the next layer / BPTT is written off the critical path;
+//   * two accumulator sets reproduce the K-halves of the launch-per-step kernel (pairs of k-blocks of equal
+//     parity), so the sums are bit-identical to it; the lane then owns all FOUR gate sums of 4 consecutive units;
+//   * c lives in registers across steps (still saved per step for BPTT);
+//   * h_t is exchanged between the workgroups of a "cluster" (the UT unit tiles that share a row block and a
+//     direction) through global memory: write-through (agent-scope = sc1) stores, the wave drains them and then
+//     raises its own flag word; consumers poll the cluster's flag words (bounded spin) before loading.  The protocol
+//     is placement-independent; clusters are laid on XCDs (workgroup id % 8 = XCC id, read back from
+//     HW_REG_XCC_ID by scripts/probes/xchg_probe.hip) only for speed: a same-XCD hand-off costs ~0.7 us
+//     (store, ack, atomic / poll, load), a cross-XCD one ~1.2 us;
+//   * everything that is not on the h_t -> h_{t+1} critical path (gate / cell saves, the Philox mask and the
+//     dropped copy for the next layer, the Gx prefetch of the next step) is issued AFTER the publish and runs
+//     while the other workgroups' stores are in flight.
+// All workgroups must be co-resident (one per CU: checked on the host against the CU count); every spin is
+// bounded and raises err[0] instead of hanging.
+// ---------------------------------------------------------------------------
+struct LstmPersistArgs {
+    LstmFwdArgs a;
+    bf16_t* hx;             // [2 step parities][ndir][4*ceil(B/64)][KB][64 lanes][8]  h exchange, MFMA operand order; pad lanes stay zero
+    unsigned* counters;     // [clusters][E2T_PERSIST_FLAG_STRIDE] per-producer-wave step flags, zeroed before the launch
+    int* err;               // [1] set to 1 if a bounded spin gave up
+};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define E2T_PERSIST_FLAG_STRIDE 128      // >= 4 waves x 26 unit tiles (H <= 416)
+
+template <int KB>        // k-blocks of 32 over H8: compile-time, so every fragment sits in a fixed register
+__global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa) {
+    const LstmFwdArgs& p = pa.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int B = p.B, H = p.H, S = p.S;
+    const int RB = (B + 63) >> 6, RT = (B + 15) >> 4;
+    const int ncl = RB * p.ndir;
+    const int cl = blockIdx.x % ncl, ut = blockIdx.x / ncl;      // cluster-major ids: cluster c sits on XCD c % 8
+    if (ut >= p.UT) return;
+    const int rb = cl % RB, dir = cl / RB;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int NH = p.ndir * H;
+    const int rt = rb * 4 + wave;
+    const int b = rt * 16 + frow;
+    const int bc = min(b, B - 1);
+    const int len = (b < B) ? p.lens[b] : 0;
+    const int u0 = ut * 16 + fq * 4;                              // this lane's 4 consecutive units (H % 4 == 0)
+    const bool own = (b < B) && (u0 < H);
+    const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
+    constexpr int npr = KB >> 1;
+
+    // ---- once: W_h fragments of (dir, ut): [gate][k-block] ----
+    bf16x8 W[KB][4];
+    {
+        const uint4* wsrc = (const uint4*)p.WhF + ((size_t)(dir * 4) * p.UT + ut) * KB * 64 + lane;
+        const size_t wgs = (size_t)p.UT * KB * 64;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const uint4 v = wsrc[g * wgs + (size_t)kb * 64]; W[kb][g] = *(const bf16x8*)&v; }
+    }
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};                          // c of this lane's 4 cells, carried in registers
+    if (own && len > 0 && p.c0) { const float4 c = *(const float4*)(p.c0 + (size_t)b * NH + dir * H + u0); cst[0] = c.x; cst[1] = c.y; cst[2] = c.z; cst[3] = c.w; }
+    // Gx of the lane's 4 units at its utterance's time index: 64 contiguous bytes.  Prefetched one step ahead by
+    // LDS-DMA into a wave-private double buffer ([buffer][r][lane] float4) -- no registers are involved, so the
+    // compiler cannot pull the wait for it into the critical path; it is covered by the next step's state wait.
+    uint4* gxl = lstm_smem + (size_t)wave * (2 * 4 * 64);
+    auto gx_load = [&](int s) {
+        const bool act = own && s < len;
+        int tt = act ? (dir ? (len - 1 - s) : s) : 0;
+        if (p.ablate & 32) tt &= 1;
+        const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s & 1) * 4 + r) * 64));
+    };
+    gx_load(0);
+    unsigned* flags = pa.counters + (size_t)cl * E2T_PERSIST_FLAG_STRIDE;
+    long long pts[8];
+    const long long t_entry = p.dbg ? wall_clock64() : 0;
+#define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)      // 100 MHz, chip-wide
+
+    for (int s = 0; s < S; ++s) {
+        PSTAMP(0);
+        // ---- wait until every wave of the cluster has published h of step s-1 ----
+        if (s > 0 && !(p.ablate & 8)) {
+            // every producer wave of the cluster owns one flag word (= number of steps it has published); plain
+            // write-through stores, no read-modify-write: 100 same-address device-scope atomics per step serialise
+            // at ~70 ns each (measured: 7 us per step).  Bounded spin: never hang the GPU; once any wave has given
+            // up (err set) nobody waits any more, so a broken launch drains in milliseconds.
+            const int nfl = 4 * p.UT;
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+                for (int i = lane; i < nfl; i += 64) ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 1023) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1 << 18)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        PSTAMP(1);
+        // ---- h_{t-1} fragments of this lane's utterance (MFMA B operand: k = kb*32 + fq*8 .. +8) ----
+        const bool active = s < len;
+        const int t = dir ? (len - 1 - s) : s;
+        u32x4 st[KB];
+        if (s == 0) {
+            // initial state from the row-major array: block 0 (forward), the all-zero slack block S+1 (backward);
+            // rows that are inactive or beyond B read block 0 (finite, result discarded)
+            size_t tau = 0, srb = bc;
+            if (active && dir == 1) { tau = (size_t)S + 1; srb = 0; }
+            const bf16_t* src = p.Yext + (tau * B + srb) * p.ldy + dir * p.H8 + fq * 8;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(st[kb]) : "v"(src), "i"(kb * 64) : "memory");
+        } else {
+            const bf16_t* src = pa.hx + ((((size_t)((s - 1) & 1) * p.ndir + dir) * (RB * 4) + rt) * KB * 64 + lane) * 8;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)         // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));             // uses stay behind the wait
+        PSTAMP(2);
+
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < npr; ++pp) {                           // k-block pairs; parity = the K half of the step kernel
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp][g], *(bf16x8*)&st[2 * pp], acc[pp & 1][g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp + 1][g], *(bf16x8*)&st[2 * pp + 1], acc[pp & 1][g], 0, 0, 0);
+        }
+        if (KB & 1) {                                                // odd tail k-block: the half that owns pair index npr
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[npr & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[KB - 1][g], *(bf16x8*)&st[KB - 1], acc[npr & 1][g], 0, 0, 0);
+        }
+        PSTAMP(3);
+
+        // ---- lane-local cell update for (utterance b, units u0..u0+3): critical part ----
+        float gi[4], gj[4], gf[4], go[4], hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint4 graw = gxl[((s & 1) * 4 + r) * 64 + lane];
+            const float gxv[4] = {__uint_as_float(graw.x), __uint_as_float(graw.y), __uint_as_float(graw.z), __uint_as_float(graw.w)};
+            gi[r] = fsigmoid((acc[0][0][r] + acc[1][0][r]) + gxv[0]);
+            gj[r] = ftanh((acc[0][1][r] + acc[1][1][r]) + gxv[1]);
+            gf[r] = fsigmoid((acc[0][2][r] + acc[1][2][r]) + gxv[2] + p.forget_bias);
+            go[r] = fsigmoid((acc[0][3][r] + acc[1][3][r]) + gxv[3]);
+            const float cv = fmaf(gf[r], cst[r], gi[r] * gj[r]);
+            hv[r] = go[r] * ftanh(cv);
+            if (active) cst[r] = cv;
+        }
+        unsigned long long hb = 0ull;
+        if (active) hb = (unsigned long long)f2bf(hv[0]) | ((unsigned long long)f2bf(hv[1]) << 16) | ((unsigned long long)f2bf(hv[2]) << 32) | ((unsigned long long)f2bf(hv[3]) << 48);
+        if (own && active && s + 1 < S) {
+            // write-through store into the exchange buffer: unit u0 sits in k-block ut/2, k-group (ut&1)*2 + fq/2,
+            // half (fq&1) of the 16-B lane slot; the consumers of the next step load it with sc1
+            unsigned long long* hp = (unsigned long long*)(pa.hx + ((((size_t)(s & 1) * p.ndir + dir) * (RB * 4) + rt) * KB + (ut >> 1)) * 512
+                                                           + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4);
+            if (p.ablate & 4) *hp = hb; else __hip_atomic_store(hp, hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        PSTAMP(4);
+        // ---- publish: drain this wave's stores, then raise this wave's flag ----
+        if (s + 1 < S) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && !(p.ablate & 64)) __hip_atomic_store(flags + ut * 4 + wave, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        PSTAMP(5);
+        // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
+        if (own) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
+            size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
+            if (p.ablate & 32) blk = 1 + (blk & 1);
+            *(unsigned long long*)(p.Yext + (blk * B + b) * p.ldy + dir * p.H8 + u0) = hb;
+        }
+        if (own && !(p.ablate & 1)) {
+            if (active) {
+                const size_t m = (size_t)((p.ablate & 32) ? (t & 1) : t) * B + b;
+                const size_t tile = native_tile((p.ablate & 32) ? (s & 1) : s, dir, rt, ut, p.ndir, RT, p.UT);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi[r], gj[r], gf[r], go[r]);
+                ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
+                ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
+                if (p.Ydrop) {
+                    float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
+                    nt_store_bf4(p.Ydrop + m * p.ldy + dir * p.H8 + u0, f2bf(hv[0] * dsc4[0]), f2bf(hv[1] * dsc4[1]), f2bf(hv[2] * dsc4[2]), f2bf(hv[3] * dsc4[3]));
+                }
+            } else if (p.Ydrop) {
+                *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
+            }
+        }
+        if (s + 1 < S && !(p.ablate & 2)) gx_load(s + 1);
+        PSTAMP(6);
+        if (p.dbg && s == S / 2 && lane == 0)
+            for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
+        if (p.dbg && s == 0 && lane == 0) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = wall_clock64() - t_entry;   // prologue + step 0
+    }
+    if (p.dbg && lane == 0) p.dbg[(size_t)(gridDim.x * 4) * 8 + (size_t)blockIdx.x * 4 + wave] = wall_clock64() - t_entry;
+#undef PSTAMP
+}
+
+__global__ void k_zero_u32(unsigned* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0; }
 
 struct LstmBwdArgs {
     const bf16_t* WhB;      // [ndir][UT][KB4][64][8]  fragment-packed W_h^T operand (K = 4H gate columns)
@@ -564,6 +781,43 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
         p.step = s;
         hipLaunchKernelGGL(k_lstm_step_fwd, grid, dim3(512), lds, (hipStream_t)stream, p);
     }
+    E2T_LAUNCH_CHECK();
+    return E2T_OK;
+}
+
+extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop,
+                                           float* Cs, float* Gs, const int32_t* lens, const float* c0, void* hx,
+                                           uint32_t* counters, int32_t* err, int num_cus, void* stream) {
+    E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens && hx && counters && err);
+    E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
+    E2T_CHECK_ARG(d->H % 2 == 0 && d->ldy % 8 == 0 && d->ldy >= d->ndir * ((d->H + 7) / 8) * 8);
+    LstmPersistArgs pa{};
+    LstmFwdArgs& p = pa.a;
+    p.Gx = Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
+    p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
+    p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
+    p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
+    p.forget_bias = d->forget_bias;
+    p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
+    pa.hx = (bf16_t*)hx; pa.counters = counters; pa.err = err;
+    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    { const char* e = getenv("E2T_LSTM_ABLATE"); p.ablate = e ? atoi(e) : 0; }      // diagnostics only
+    const int ncl = ((d->B + 63) / 64) * d->ndir;
+    const int nwg = ncl * p.UT;
+    // every workgroup must be resident at once (1 per CU), and the W_h fragments of a unit tile must fit the
+    // wave's registers (13 k-blocks x 4 gates x 4 registers)
+    if (p.KB > 13 || d->H % 4 != 0 || nwg > num_cus) {
+        e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
+        return E2T_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_zero_u32, dim3((ncl * E2T_PERSIST_FLAG_STRIDE + 255) / 256), dim3(256), 0, (hipStream_t)stream, counters, ncl * E2T_PERSIST_FLAG_STRIDE);
+#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist<K>, dim3(nwg), dim3(256), 4 * 2 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
+    switch (p.KB) {
+        E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)
+        E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10)
+        E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13)
+    }
+#undef E2T_PERSIST_CASE
     E2T_LAUNCH_CHECK();
     return E2T_OK;
 }

@@ -17,6 +17,7 @@ MultiSubjectTrainer.recover_model_sizes (trainers.py:444-554).
 from dataclasses import dataclass, field, asdict
 from typing import Dict, List, Optional
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -383,6 +384,12 @@ class _Lstm:
     def bias_ptr(self, src):
         return self.eng.store.ptr(self.name + '.Wx', src, self.D * self.N4)
 
+    def persistent_ok(self, B, num_cus):
+        """One workgroup per CU for the whole layer, and the W_h fragments of a unit tile fit a wave's registers
+        (mirrors the check in e2t_lstm_seq_fwd_persistent)."""
+        nwg = ceil_div(B, 64) * self.ndir * self.UT
+        return nwg <= num_cus and self.KB <= 13 and self.H % 4 == 0
+
     def alloc(self, S, B):
         dev = self.eng.device
         M, Mk = S * B, r8(S * B)
@@ -400,6 +407,8 @@ class _Lstm:
         ws['xT'] = _bf(self.D + 1, Mk, device=dev)
         ws['xT'][self.D, :M] = 1.0
         ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
+        ws['counters'] = torch.zeros(ceil_div(B, 64) * nd * 128, dtype=torch.int32, device=dev)
+        ws['hx'] = _bf(2, nd, 4 * ceil_div(B, 64), self.KB, 64, 8, device=dev)     # in-launch h exchange (persistent recurrence)
         return ws
 
     def desc(self, ws, train):
@@ -418,6 +427,15 @@ class _Lstm:
             e.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, M, self.N4, self.in_ld,
                    bias=self.bias_ptr(src))
             steps = (0, ws['S'])
+        if e.persistent and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
+            # whole sequence in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_fwd_persist)
+            d = self.desc(ws, train)
+            lib.e2t_lstm_seq_fwd_persistent(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
+                                            ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
+                                            c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(), ws['counters'].data_ptr(),
+                                            e.sync_err.data_ptr(), e.num_cus, e.stream)
+            return
+
         def launch(rb0, nrb, stream):
             d = self.desc(ws, train)
             d.rb_begin, d.rb_count = rb0, nrb
@@ -507,6 +525,9 @@ class Seq2SeqEngine:
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
                              [(0, s.dec_rnn, 0)], r8(s.dec_rnn), STREAM_DEC_OUT + 1)
         self._pack_table = None
+        self.persistent = os.environ.get('E2T_PERSISTENT', '1') != '0'
+        self.num_cus = H.load().e2t_device_cus(self.device.index or 0)
+        self.sync_err = _i32(1, device=dev)      # raised by a bounded in-kernel wait that gave up (persistent recurrence)
         self.chains = 1          # >1 measured slower: a step launch is bound by chip-level L2-miss traffic, not latency
         self._side = []
         self._ws = {}
@@ -962,6 +983,8 @@ class Seq2SeqEngine:
 
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()
+        if int(self.sync_err.item()) != 0:
+            raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results invalid)')
         out = dict(decoder=float(v[0]), accuracy=float(v[2]))
         if ws.get('use_aux'):
             out['aux'] = float(v[1])

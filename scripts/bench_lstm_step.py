@@ -37,13 +37,46 @@ def bwd():
     lib.e2t_lstm_seq_bwd(C.byref(d), lay.WhB.data_ptr(), lw['dG'].data_ptr(), lw['dG'].shape[1], ws['dY'][1].data_ptr(), lay.ldy,
                          lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None,
                          lw['dc_carry'].data_ptr(), None, None, eng.stream)
+cnt = torch.zeros(4096, dtype=torch.int32, device='cuda'); err = torch.zeros(1, dtype=torch.int32, device='cuda')
+def fwd_p():
+    lib.e2t_lstm_seq_fwd_persistent(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(), lw['Ydrop'].data_ptr(),
+                                    lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, lw['hx'].data_ptr(), cnt.data_ptr(),
+                                    err.data_ptr(), eng.num_cus, eng.stream)
+if lay.persistent_ok(B, eng.num_cus):
+    for ab in [int(x) for x in os.environ.get('PABLATIONS', '0').split(',')]:
+        os.environ['E2T_LSTM_ABLATE'] = str(ab)
+        print('persistent fwd (ablate %d): %.2f us/step (S=%d), err=%d' % (ab, timeit(fwd_p, S), S, int(err.item())), flush=True)
+    os.environ['E2T_LSTM_ABLATE'] = '0'
+    if os.environ.get('TIMELINE'):
+        import numpy as np
+        dbg = torch.zeros(256 * 8 * 8 + 2048, dtype=torch.int64, device='cuda')
+        os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
+        os.environ['E2T_LSTM_ABLATE'] = os.environ.get('TL_ABLATE', '0')
+        fwd_p(); torch.cuda.synchronize()
+        os.environ['E2T_LSTM_ABLATE'] = '0'
+        del os.environ['E2T_LSTM_DBG']
+        raw = dbg.cpu().numpy()
+        nw = 4 * ceil_div(B, 64) * lay.ndir * lay.UT
+        tot = raw[nw * 8: nw * 8 + nw] / 100.0
+        first = raw[:nw * 8].reshape(-1, 8)[:, 7] / 100.0
+        print('  whole kernel per wave: min %.1f med %.1f max %.1f us; prologue+step0: med %.1f max %.1f us' % (tot.min(), np.median(tot), tot.max(), np.median(first), first.max()))
+        t = raw[:nw * 8].reshape(-1, 8)[:, :7]
+        t = t[t[:, 0] > 0]
+        rel = (t - t[:, :1]) / 100.0
+        names = ['step top', 'poll done', 'state landed', 'mma done', 'h stored', 'published', 'side work issued']
+        print('  persistent step %d, %d waves; time since step top (us):' % (S // 2, len(t)))
+        for i, nme in enumerate(names):
+            print('    %-20s min %.2f  median %.2f  max %.2f' % (nme, rel[:, i].min(), np.median(rel[:, i]), rel[:, i].max()))
+        dd = np.diff(rel, axis=1)
+        print('    phase durations: ' + ' | '.join('%s: min %.1f med %.1f p90 %.1f max %.1f' % (names[i + 1], dd[:, i].min(), np.median(dd[:, i]), np.percentile(dd[:, i], 90), dd[:, i].max()) for i in range(6)))
+        print('    spread of step-top across waves: %.2f us (100 MHz wall clock: values are us)' % ((t[:, 0].max() - t[:, 0].min()) / 100.0))
 for ab in [int(x) for x in os.environ.get('ABLATIONS', '0').split(',')]:
     os.environ['E2T_LSTM_ABLATE'] = str(ab)
     print('ablate %3d: fwd %.2f us/step   bwd %.2f us/step' % (ab, timeit(fwd, S), timeit(bwd, S)), flush=True)
 # ---- per-phase timeline of ONE step (s_memtime stamps written by the kernel) ----
 if os.environ.get('TIMELINE'):
     import numpy as np
-    dbg = torch.zeros(256 * 4 * 8, dtype=torch.int64, device='cuda')
+    dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device='cuda')
     os.environ['E2T_LSTM_ABLATE'] = '0'
     os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
     lib.e2t_lstm_seq_fwd(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(), lw['Ydrop'].data_ptr(),
