@@ -615,6 +615,7 @@ struct LstmBwdArgs {
     float* dc0;             // [B][ndir*H] out, written when step == -1
     int S, B, H, H8, ndir, lddg, lddy, UT, KB4, step, rb_begin, rb_count;
     DropCfg drop;
+    long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
 };
 
 __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
@@ -744,6 +745,242 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// Persistent backward recurrence (BPTT over all S steps of a layer in ONE launch).
+// The recurrent product dh_rec = dG_{s+1} . W_h^T has K = 4H, so the per-step hand-off between CUs is 4x the
+// forward's and a 64-utterance x 16-unit patch would pull 200 KiB per step into every CU.  Tiling here:
+//   workgroup = 16 utterances x 64 units (4 unit tiles) x direction, 4 waves at one wave per SIMD;
+//   MFMA phase : wave q holds K-QUARTER q of W_h^T for all 4 unit tiles in registers (4 x KQ x 4 registers) and
+//                loads only its quarter of the 16 dG rows (KQ KiB per step, one contiguous KiB per instruction from
+//                the step-parity exchange buffer `dgx` in MFMA operand order, sc1);
+//   reduction  : the 4 partial 16x16 tiles per unit tile go through LDS (one barrier), summed as (P0+P1)+(P2+P3);
+//   cell phase : wave w finishes unit tile ug*4 + w: lane (frow, fq) = utterance rt*16+frow, units u0..u0+3.
+// Everything that does not depend on dh_rec -- the saved gates and cells, dY, the Philox mask, tanh(c) and the
+// gate-derivative factors -- is fetched by LDS-DMA one step ahead and folded into 7 factors per cell after the
+// publish, so the critical path per step is: poll, KQ loads, 4*KQ MFMAs, LDS reduce, ~12 FMAs per cell, store, ack.
+// The hand-off protocol is the forward kernel's (per-wave flag words, bounded spins, err[0] on timeout); dc is
+// carried in registers; the row-major time-indexed dG for the weight-gradient GEMMs is written off the critical
+// path.  The summation order differs from k_lstm_step_bwd (4 K-quarters vs 2 interleaved halves), so results
+// agree with it to fp32 round-off, not bit for bit.
+// ---------------------------------------------------------------------------
+struct LstmBwdPersistArgs {
+    LstmBwdArgs a;
+    bf16_t* dgx;            // [2 step parities][ndir][RT][4*KQ][64 lanes][8]  dG exchange, MFMA operand order; zero-filled once
+    unsigned* flags;        // [clusters = RT*ndir][E2T_PERSIST_BWD_FLAG_STRIDE] per-producer-wave step counts, zeroed per launch
+    int* err;
+};
+#define E2T_PERSIST_BWD_FLAG_STRIDE 32      // >= 4 waves x 7 unit groups (H <= 416)
+#define E2T_BWD_PRE16 (6 * 64)              // 16-B units of one prefetch buffer: Gs 4 KiB, Cs 1 KiB, dY 1 KiB
+
+template <int KQ>
+__global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs pa) {
+    const LstmBwdArgs& p = pa.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int B = p.B, H = p.H, S = p.S, KB4 = p.KB4;
+    const int RT = (B + 15) >> 4, UG = (p.UT + 3) >> 2;
+    const int ncl = RT * p.ndir;
+    const int cl = blockIdx.x % ncl, ug = blockIdx.x / ncl;      // cluster-major ids: cluster c sits on XCD c % 8
+    if (ug >= UG) return;
+    const int rt = cl % RT, dir = cl / RT;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int NH = p.ndir * H, K4 = 4 * H;
+    const int b = rt * 16 + frow;
+    const int bc = min(b, B - 1);
+    const int len = (b < B) ? p.lens[b] : 0;
+    const int ut = ug * 4 + wave;                                 // unit tile this wave finishes
+    const bool tile_ok = ut < p.UT;
+    const int u0 = ut * 16 + fq * 4;
+    const bool own = (b < B) && tile_ok && (u0 < H);
+    const int u0c = own ? u0 : 0;
+    const size_t su = (size_t)bc * NH + dir * H + u0c;            // state index [B][ndir*H]
+    const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
+    constexpr int KBP = 4 * KQ;
+
+    // ---- once: W_h^T fragments: K quarter `wave` for the 4 unit tiles of this group ----
+    bf16x8 W[4][KQ];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int utu = ug * 4 + u, kb = wave * KQ + i;
+            if (utu < p.UT && kb < KB4) v = ((const uint4*)p.WhB)[(((size_t)dir * p.UT + utu) * KB4 + kb) * 64 + lane];
+            W[u][i] = *(bf16x8*)&v;
+        }
+    uint4* pre = lstm_smem + (size_t)wave * (2 * E2T_BWD_PRE16);              // wave-private prefetch double buffer
+    float4* part = (float4*)(lstm_smem + 4 * 2 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
+    unsigned* flags = pa.flags + (size_t)cl * E2T_PERSIST_BWD_FLAG_STRIDE;
+
+    // operands of step s that do not depend on the recurrence, by LDS-DMA into buffer s&1 (full exec, clamped addresses)
+    const unsigned pre_lds = lds_addr_of(lstm_smem) + (unsigned)wave * (2 * E2T_BWD_PRE16 * 16);    // LDS byte address (integer math:
+    auto prefetch = [&](int s) {                                                                     //  no generic->LDS casts in the loop)
+        if (!tile_ok) return;
+        const unsigned dst = pre_lds + (unsigned)(s & 1) * (E2T_BWD_PRE16 * 16);
+        const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dma16_to_lds(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, dst + r * 1024);
+        if (s > 0) dma16_to_lds(p.Cs + native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 256 + lane * 4, dst + 4 * 1024);
+        if (p.dY) {
+            const int t = (s < len) ? (dir ? (len - 1 - s) : s) : 0;
+            dma16_to_lds(p.dY + ((size_t)t * B + bc) * p.lddy + dir * p.H8 + u0c, dst + 5 * 1024);
+        }
+    };
+    // factors of step s (see the cell backward below): f_add = dh_final + dy*mask, k1..k5, f; c_t is carried
+    float ct[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
+    float f_add[4], k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f_add[r] = k1[r] = k2[r] = k3[r] = k4[r] = k5[r] = k6[r] = 0.f;
+    auto precompute = [&](int s) {
+        if (!own) return;
+        const uint4* src = pre + (s & 1) * E2T_BWD_PRE16;
+        float cp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            const float2* cs = (const float2*)(src + 4 * 64);
+            const float2 a = cs[lane], c = cs[64 + lane];
+            cp[0] = a.x; cp[1] = a.y; cp[2] = c.x; cp[3] = c.y;
+        } else if (p.c0) {
+            const float4 c = *(const float4*)(p.c0 + su);
+            cp[0] = c.x; cp[1] = c.y; cp[2] = c.z; cp[3] = c.w;
+        }
+        if (s < len) {
+            const int t = dir ? (len - 1 - s) : s;
+            const size_t m = (size_t)t * B + b;
+            float dhf[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f}, dsc4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (s == len - 1) {               // the utterance's last time step: gradients into the final state
+                if (p.dh_final) { const float4 v = *(const float4*)(p.dh_final + su); dhf[0] = v.x; dhf[1] = v.y; dhf[2] = v.z; dhf[3] = v.w; }
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.dc_final) v = *(const float4*)(p.dc_final + su);
+                dcc[0] = v.x; dcc[1] = v.y; dcc[2] = v.z; dcc[3] = v.w;
+            }
+            if (p.dY) {
+                const uint4 raw = src[5 * 64 + lane];
+                dy[0] = __uint_as_float(raw.x); dy[1] = __uint_as_float(raw.y); dy[2] = __uint_as_float(raw.z); dy[3] = __uint_as_float(raw.w);
+                if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint4 raw = src[r * 64 + lane];
+                const float gi = __uint_as_float(raw.x), gj = __uint_as_float(raw.y), gf = __uint_as_float(raw.z), go = __uint_as_float(raw.w);
+                const float tc = ftanh(ct[r]);
+                f_add[r] = dhf[r] + dy[r] * dsc4[r];
+                k1[r] = go * (1.f - tc * tc);             // d c_t     += dh  * k1
+                k2[r] = tc * go * (1.f - go);             // d o (pre) =  dh  * k2
+                k3[r] = gj * gi * (1.f - gi);             // d i (pre) =  dct * k3
+                k4[r] = gi * (1.f - gj * gj);             // d j (pre) =  dct * k4
+                k5[r] = cp[r] * gf * (1.f - gf);          // d f (pre) =  dct * k5
+                k6[r] = gf;                               // d c_{t-1} =  dct * f
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ct[r] = cp[r];        // c_t of step s-1 is c_{t-1} of step s, active or not
+    };
+
+    // ---- prologue: operands of the first step (s = S-1) ----
+    prefetch(S - 1);
+    if (own) {
+        const size_t tile = native_tile(S - 1, dir, rt, ut, p.ndir, RT, p.UT);
+        const float2 a = ((const float2*)p.Cs)[(tile * 2 + 0) * 64 + lane], c = ((const float2*)p.Cs)[(tile * 2 + 1) * 64 + lane];
+        ct[0] = a.x; ct[1] = a.y; ct[2] = c.x; ct[3] = c.y;
+    }
+    dma_wait_all();
+    precompute(S - 1);
+    long long pts[8];
+#define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)
+
+    for (int k = 0; k < S; ++k) {
+        const int s = S - 1 - k;
+        PSTAMP(0);
+        const bool active = s < len;
+        f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (k > 0) {
+            // ---- wait until every producer wave of the cluster has published step s+1 ----
+            const int nfl = 4 * UG;
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+                for (int i = lane; i < nfl; i += 64) ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)k);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 1023) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1 << 18)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            PSTAMP(1);
+            // ---- this wave's K quarter of the 16 dG rows of step s+1 (rows without a successor step hold zeros) ----
+            u32x4 st[KQ];
+            const bf16_t* src = pa.dgx + (((((size_t)((s + 1) & 1) * p.ndir + dir) * RT + rt) * KBP + wave * KQ) * 64 + lane) * 8;
+#pragma unroll
+            for (int i = 0; i < KQ; ++i)            // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[i]) : "v"(src + (i >> 2) * 2048), "i"((i & 3) * 1024) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) asm volatile("" : "+v"(st[i]));
+            PSTAMP(2);
+            if (s > 0) prefetch(s - 1);             // lands while this step computes; drained by the publish wait
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KQ; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[u][i], *(bf16x8*)&st[i], acc[u], 0, 0, 0);
+            // ---- reduce the 4 K-quarter partials of every unit tile through LDS ----
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[(u * 4 + wave) * 64 + lane] = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+            __syncthreads();
+            const float4 p0 = part[(wave * 4 + 0) * 64 + lane], p1 = part[(wave * 4 + 1) * 64 + lane];
+            const float4 p2 = part[(wave * 4 + 2) * 64 + lane], p3 = part[(wave * 4 + 3) * 64 + lane];
+            rec = (f32x4){(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)};
+        } else if (s > 0) {
+            prefetch(s - 1);
+        }
+        PSTAMP(3);
+        // ---- cell backward for (utterance b, units u0..u0+3): the part that needs dh_rec ----
+        uint4 og0 = make_uint4(0u, 0u, 0u, 0u), og1 = make_uint4(0u, 0u, 0u, 0u);      // (i,j,f,o) x units 0,1 / units 2,3
+        if (own && active) {
+            bf16_t og[16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dh = rec[r] + f_add[r];
+                const float dct = fmaf(dh, k1[r], dcc[r]);
+                og[r * 4 + 0] = f2bf(dct * k3[r]);
+                og[r * 4 + 1] = f2bf(dct * k4[r]);
+                og[r * 4 + 2] = f2bf(dct * k5[r]);
+                og[r * 4 + 3] = f2bf(dh * k2[r]);
+                dcc[r] = dct * k6[r];
+            }
+            og0 = make_uint4(og[0] | ((unsigned)og[1] << 16), og[2] | ((unsigned)og[3] << 16), og[4] | ((unsigned)og[5] << 16), og[6] | ((unsigned)og[7] << 16));
+            og1 = make_uint4(og[8] | ((unsigned)og[9] << 16), og[10] | ((unsigned)og[11] << 16), og[12] | ((unsigned)og[13] << 16), og[14] | ((unsigned)og[15] << 16));
+        }
+        if (s > 0) {
+            if (own) {
+                // exchange copy for the next step's consumers: gate columns u0*4 .. u0*4+15 = k-block ut*2 + fq/2,
+                // k-groups (fq&1)*2 and +1; padded positions publish zeros.  Write-through (sc1) stores.
+                u32x4* hp = (u32x4*)(pa.dgx + (((((size_t)(s & 1) * p.ndir + dir) * RT + rt) * KBP + ut * 2 + (fq >> 1)) * 64 + (fq & 1) * 32 + frow) * 8);
+                const u32x4 v0 = (u32x4){og0.x, og0.y, og0.z, og0.w}, v1 = (u32x4){og1.x, og1.y, og1.z, og1.w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:256 sc1" :: "v"(hp), "v"(v0), "v"(v1) : "memory");
+            }
+            PSTAMP(4);
+            // ---- publish: drain this wave's stores (and the prefetch DMA), then raise this wave's flag ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags + ug * 4 + wave, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        PSTAMP(5);
+        // ---- off the critical path: row-major dG for the weight-gradient GEMMs, factors of the next step ----
+        if (own) {
+            const int t = dir ? (len - 1 - s) : s;
+            uint4* gp = (uint4*)(p.dG + ((size_t)(active ? t : s) * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4);
+            gp[0] = og0; gp[1] = og1;
+        }
+        if (s > 0) precompute(s - 1);
+        PSTAMP(6);
+        if (p.dbg && s == S / 2 && lane == 0)
+            for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
+    }
+#undef PSTAMP
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 static int set_big_lds(const void* fn) {
@@ -850,6 +1087,44 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
         p.step = s;
         hipLaunchKernelGGL(k_lstm_step_bwd, grid, dim3(512), lds, (hipStream_t)stream, p);
     }
+    E2T_LAUNCH_CHECK();
+    return E2T_OK;
+}
+
+extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY,
+                                           int lddy, const float* Gs, const float* Cs, const int32_t* lens,
+                                           const float* c0, const float* dh_final, const float* dc_final, void* dgx,
+                                           uint32_t* flags, int32_t* err, int num_cus, void* stream) {
+    E2T_CHECK_ARG(d && WhB && dG && Gs && Cs && lens && dgx && flags && err);
+    E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
+    E2T_CHECK_ARG(lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
+    LstmBwdPersistArgs pa{};
+    LstmBwdArgs& p = pa.a;
+    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
+    p.dh_final = dh_final; p.dc_final = dc_final;
+    p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir;
+    p.lddg = lddg; p.lddy = lddy;
+    p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
+    p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
+    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    pa.dgx = (bf16_t*)dgx; pa.flags = flags; pa.err = err;
+    const int ncl = ((d->B + 15) / 16) * d->ndir;
+    const int nwg = ncl * ((p.UT + 3) / 4);
+    const int KQ = (p.KB4 + 3) / 4;
+    // every workgroup must be resident at once (1 per CU); a K quarter of W_h^T for 4 unit tiles must fit a wave's registers
+    if (KQ > 13 || d->H % 4 != 0 || nwg > num_cus) {
+        e2t_set_error("persistent BPTT not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
+        return E2T_ERR_ARG;
+    }
+    const size_t lds = (size_t)(4 * 2 * E2T_BWD_PRE16 + 16 * 64) * 16;
+    hipLaunchKernelGGL(k_zero_u32, dim3((ncl * E2T_PERSIST_BWD_FLAG_STRIDE + 255) / 256), dim3(256), 0, (hipStream_t)stream, flags, ncl * E2T_PERSIST_BWD_FLAG_STRIDE);
+#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_bwd_persist<K>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
+    switch (KQ) {
+        E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)
+        E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10)
+        E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13)
+    }
+#undef E2T_PERSIST_CASE
     E2T_LAUNCH_CHECK();
     return E2T_OK;
 }

@@ -390,6 +390,11 @@ class _Lstm:
         nwg = ceil_div(B, 64) * self.ndir * self.UT
         return nwg <= num_cus and self.KB <= 13 and self.H % 4 == 0
 
+    def persistent_bwd_ok(self, B, num_cus):
+        """Mirrors the check in e2t_lstm_seq_bwd_persistent (16-utterance x 64-unit workgroups, one per CU)."""
+        nwg = ceil_div(B, 16) * self.ndir * ceil_div(self.UT, 4)
+        return nwg <= num_cus and ceil_div(self.KB4, 4) <= 13 and self.H % 4 == 0
+
     def alloc(self, S, B):
         dev = self.eng.device
         M, Mk = S * B, r8(S * B)
@@ -407,7 +412,8 @@ class _Lstm:
         ws['xT'] = _bf(self.D + 1, Mk, device=dev)
         ws['xT'][self.D, :M] = 1.0
         ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
-        ws['counters'] = torch.zeros(ceil_div(B, 64) * nd * 128, dtype=torch.int32, device=dev)
+        ws['counters'] = torch.zeros(max(ceil_div(B, 64) * 128, ceil_div(B, 16) * 32) * nd, dtype=torch.int32, device=dev)
+        ws['dgx'] = _bf(2, nd, ceil_div(B, 16), 4 * ceil_div(self.KB4, 4), 64, 8, device=dev)   # in-launch dG exchange (persistent BPTT)
         ws['hx'] = _bf(2, nd, 4 * ceil_div(B, 64), self.KB, 64, 8, device=dev)     # in-launch h exchange (persistent recurrence)
         return ws
 
@@ -427,7 +433,7 @@ class _Lstm:
             e.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, M, self.N4, self.in_ld,
                    bias=self.bias_ptr(src))
             steps = (0, ws['S'])
-        if e.persistent and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
+        if e.persistent_fwd and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
             # whole sequence in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_fwd_persist)
             d = self.desc(ws, train)
             lib.e2t_lstm_seq_fwd_persistent(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
@@ -463,7 +469,15 @@ class _Lstm:
             lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
                                  ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
                                  ws['dc_carry'].data_ptr(), p(dh0), p(dc0), stream)
-        e.run_chains(B, launch)
+        if e.persistent_bwd and dh0 is None and self.persistent_bwd_ok(B, e.num_cus):
+            # whole BPTT sweep in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_bwd_persist)
+            d = self.desc(ws, train)
+            lib.e2t_lstm_seq_bwd_persistent(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
+                                            ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final),
+                                            p(dc_final), ws['dgx'].data_ptr(), ws['counters'].data_ptr(),
+                                            e.sync_err.data_ptr(), e.num_cus, e.stream)
+        else:
+            e.run_chains(B, launch)
         lib.e2t_transpose_bf16(ws['dG'].data_ptr(), r8(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
@@ -525,7 +539,9 @@ class Seq2SeqEngine:
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
                              [(0, s.dec_rnn, 0)], r8(s.dec_rnn), STREAM_DEC_OUT + 1)
         self._pack_table = None
-        self.persistent = os.environ.get('E2T_PERSISTENT', '1') != '0'
+        mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
+        self.persistent = mode != '0'
+        self.persistent_fwd, self.persistent_bwd = mode in ('1', 'fwd'), mode in ('1', 'bwd')
         self.num_cus = H.load().e2t_device_cus(self.device.index or 0)
         self.sync_err = _i32(1, device=dev)      # raised by a bounded in-kernel wait that gave up (persistent recurrence)
         self.chains = 1          # >1 measured slower: a step launch is bound by chip-level L2-miss traffic, not latency

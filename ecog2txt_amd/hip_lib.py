@@ -62,6 +62,7 @@ SIGNATURES = {
     'e2t_lstm_seq_fwd': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     'e2t_lstm_seq_fwd_persistent': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_lstm_seq_bwd': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'e2t_lstm_seq_bwd_persistent': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_final_state': [_p, _i, _p, _p, _i, _i, _p, _i, _p, _p],
     'e2t_embed_fwd': [_p, _i, _p, _i, _i, _i, _p, _i, C.POINTER(Dropout), _p],
     'e2t_embed_bwd': [_p, _i, _p, _i, _i, _p, _i, C.POINTER(Dropout), _p],

@@ -70,6 +70,25 @@ if lay.persistent_ok(B, eng.num_cus):
         dd = np.diff(rel, axis=1)
         print('    phase durations: ' + ' | '.join('%s: min %.1f med %.1f p90 %.1f max %.1f' % (names[i + 1], dd[:, i].min(), np.median(dd[:, i]), np.percentile(dd[:, i], 90), dd[:, i].max()) for i in range(6)))
         print('    spread of step-top across waves: %.2f us (100 MHz wall clock: values are us)' % ((t[:, 0].max() - t[:, 0].min()) / 100.0))
+def bwd_p():
+    lib.e2t_lstm_seq_bwd_persistent(C.byref(d), lay.WhB.data_ptr(), lw['dG'].data_ptr(), lw['dG'].shape[1], ws['dY'][1].data_ptr(), lay.ldy,
+                                    lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None,
+                                    lw['dgx'].data_ptr(), cnt.data_ptr(), err.data_ptr(), eng.num_cus, eng.stream)
+if lay.persistent_bwd_ok(B, eng.num_cus):
+    print('persistent bwd: %.2f us/step (S=%d), err=%d' % (timeit(bwd_p, S), S, int(err.item())), flush=True)
+    if os.environ.get('TIMELINE'):
+        import numpy as np
+        dbg = torch.zeros(256 * 8 * 8 + 2048, dtype=torch.int64, device='cuda')
+        os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
+        bwd_p(); torch.cuda.synchronize()
+        del os.environ['E2T_LSTM_DBG']
+        nw = 4 * ceil_div(B, 16) * lay.ndir * ceil_div(lay.UT, 4)
+        t = dbg.cpu().numpy()[:nw * 8].reshape(-1, 8)[:, :7]
+        t = t[t[:, 0] > 0]
+        rel = (t - t[:, :1]) / 100.0
+        names = ['step top', 'poll done', 'state landed', 'mma+reduce done', 'dG exchange stored', 'published', 'side work done']
+        dd = np.diff(rel, axis=1)
+        print('  persistent bwd step %d, %d waves; phase durations (us): ' % (S // 2, len(t)) + ' | '.join('%s: min %.1f med %.1f p90 %.1f max %.1f' % (names[i + 1], dd[:, i].min(), np.median(dd[:, i]), np.percentile(dd[:, i], 90), dd[:, i].max()) for i in range(6)))
 for ab in [int(x) for x in os.environ.get('ABLATIONS', '0').split(',')]:
     os.environ['E2T_LSTM_ABLATE'] = str(ab)
     print('ablate %3d: fwd %.2f us/step   bwd %.2f us/step' % (ab, timeit(fwd, S), timeit(bwd, S)), flush=True)
