@@ -160,56 +160,68 @@ def main():
     losses = eng.losses(ws)
     assert np.isfinite(losses['total']), losses
 
-    # ---- roofline of the dominant kernel family: the fused recurrent step (MFMA-bound) ----
-    # Forward recurrence of one encoder layer = S launches of k_lstm_step_fwd on the bench stream,
-    # bracketed by HIP events on THAT stream; algorithmic flops per launch = 2 dirs * B * H * 4H * 2.
+    # ---- roofline of the dominant kernel (rocprofv3: k_gemm_nt, 47% of the step's kernel time; its largest instance is
+    #      the input projection of an encoder layer, Gx[S*B][8H] = Ydrop[S*B][2H] . Wx^T + b, 10% of the step) ----
+    # Measured live: `reps` launches captured in a hipGraph on the bench stream, bracketed by HIP events on THAT
+    # stream.  Algorithmic flops per launch = 2*M*N*K; algorithmic HBM bytes = A + B (bf16) + C (fp32).
     roof = None
+    extra = {}
     if rank == 0:
+        import ctypes as C
+        from ecog2txt_amd.hip_lib import lib
         S = ceil_div(T, spec.decimation)
         lay, lw = eng.enc[1], ws['enc'][1]
         x = ws['enc'][0]['Ydrop'].data_ptr()
-        reps = 20
-        stream = torch.cuda.current_stream()
-        import ctypes as C
-        from ecog2txt_amd.hip_lib import lib
-        d = lay.desc(lw, True)
-        def run_steps():
-            lib.e2t_lstm_seq_fwd(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(),
-                                 lw['Ydrop'].data_ptr(), lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(),
-                                 None, 0, S, torch.cuda.current_stream().cuda_stream)
-        gr = torch.cuda.CUDAGraph()
-        run_steps(); torch.cuda.synchronize()
-        with torch.cuda.graph(gr):
-            run_steps()
-        gr.replay(); torch.cuda.synchronize()
-        stream = torch.cuda.current_stream()          # graph replays are enqueued on this stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(reps):
-            gr.replay()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        us_per_launch = e0.elapsed_time(e1) * 1e3 / (reps * S)
-        H = lay.H
-        flops_launch = 2 * B * H * 4 * H * 2          # both directions: [B,H] x [H,4H], 2 flop per MAC
-        ach = flops_launch / (us_per_launch * 1e-6) / 1e12
-        # HBM-side bytes per launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # passes, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes); a measured constant of this round, not live
+
+        def time_graph(fn, reps):
+            fn(); torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(reps):
+                    fn()
+            gr.replay(); torch.cuda.synchronize()
+            stream = torch.cuda.current_stream()          # graph replays are enqueued on this stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(5):
+                gr.replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / (5 * reps)
+
+        M, N, K = S * B, lay.N4, lay.D                    # K is zero-padded to lay.in_ld (a multiple of the 64-wide K tile)
+        us = time_graph(lambda: eng.gemm(x, lay.in_ld, lay.WxT.data_ptr(), lay.in_ld, lw['Gx'].data_ptr(), lay.N4, M, lay.N4,
+                                         lay.in_ld, bias=lay.bias_ptr(eng.store.p)), 20)
+        flops = 2 * M * N * K
+        ach = flops / (us * 1e-6) / 1e12
+        alg_bytes = 2 * M * K + 2 * N * K + 4 * M * N
+        # HBM-side bytes per launch of THIS instance from the committed PMC run (profiles/r01b_pmc_gemm_gx.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/roofline_gemm.py, FETCH_SIZE x2 as
+        # MI355X_MICROARCH.md prescribes); a measured constant of this round, not live
         traffic = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-                t = json.load(f)['k_lstm_step_fwd']
+            with open(os.path.join(ROOT, 'profiles', 'r01b_pmc_gemm_gx.json')) as f:
+                t = json.load(f)['k_gemm_nt']
             if args.config == 'cfg2' and B == 256:
                 traffic = t['hbm_read_bytes'] + t['hbm_write_bytes']
         except Exception:
             pass
-        # algorithmic HBM bytes of one step launch: Gx in, gates + c out, c_{t-1} in, h out (x2 dirs)
-        alg_bytes = 2 * B * H * (16 + 16 + 4 + 4 + 2 + 2)
-        roof = dict(bound='mfma', kernel='k_lstm_step_fwd', achieved=round(ach, 3), peak=MFMA_BF16_PEAK_TFLOPS,
-                    unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 5), traffic=traffic,
-                    us_per_launch=round(us_per_launch, 3), flops_per_launch=flops_launch,
-                    algorithmic_hbm_bytes_per_launch=alg_bytes,
-                    note='latency-bound: one launch = one time step of one layer, 0.66 GFLOP; see DESIGN.md section 5')
+        roof = dict(bound='mfma', kernel='k_gemm_nt', instance='encoder input projection M=%d N=%d K=%d (bias epilogue, fp32 out)' % (M, N, K),
+                    achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    traffic=traffic, us_per_launch=round(us, 2), flops_per_launch=flops, algorithmic_hbm_bytes_per_launch=alg_bytes)
+        # the recurrences (second largest share): one persistent launch per layer and direction pair, time per step
+        d = lay.desc(lw, True)
+        if eng.persistent_fwd and lay.persistent_ok(B, eng.num_cus):
+            us_f = time_graph(lambda: lay.fwd(lw, x, ws['lens_d'], eng.store.p, True, steps=(0, S)), 3) / S
+            extra['lstm_fwd_us_per_step'] = round(us_f, 3)
+        if eng.persistent_bwd and lay.persistent_bwd_ok(B, eng.num_cus):
+            us_b = time_graph(lambda: lib.e2t_lstm_seq_bwd_persistent(
+                C.byref(d), lay.WhB.data_ptr(), lw['dG'].data_ptr(), lw['dG'].shape[1], ws['dY'][1].data_ptr(), lay.ldy,
+                lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None, lw['dgx'].data_ptr(),
+                lw['counters'].data_ptr(), eng.sync_err.data_ptr(), eng.num_cus, eng.stream), 3) / S
+            extra['lstm_bwd_us_per_step'] = round(us_b, 3)
+        extra['lstm_step_flops'] = 2 * B * lay.H * 4 * lay.H * 2      # both directions, one time step of one layer
+        assert int(eng.sync_err.item()) == 0
 
     if rank == 0:
         utt = B * world * args.steps / el
@@ -223,7 +235,7 @@ def main():
                                   spec.dec_rnn, spec.vocab, L), global_batch=B * world, parallelism='dp%d' % world,
                                hipgraph=not args.no_graph),
                    recurrent_gemm_tflops=round(rec, 3), recurrent_gemm_frac_of_peak=round(rec / MFMA_BF16_PEAK_TFLOPS / world, 5),
-                   final_loss=round(losses['total'], 4), roofline=roof)
+                   final_loss=round(losses['total'], 4), recurrence=extra, roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(spec_kw, T, L)
         print(json.dumps(out))

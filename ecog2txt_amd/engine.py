@@ -30,6 +30,13 @@ PAD_ID, EOS_ID, OOV_ID = 0, 1, 2          # trainers.py:191-196
 STREAM_CONV, STREAM_ENC, STREAM_DEC_EMB, STREAM_DEC_OUT, STREAM_AUX = 1, 10, 20, 21, 30
 
 
+def rk(x):
+    """Leading dimension of anything that serves as a GEMM K dimension: a multiple of the 64-wide K tile, zero
+    padded, so that k_gemm_nt never takes its register-staged K-tail path (measured: 98 -> 75 us on the encoder
+    input projection, scripts/bench_gemm_variants.py)."""
+    return (x + 63) // 64 * 64
+
+
 def r8(x):
     return (x + 7) // 8 * 8
 
@@ -257,9 +264,9 @@ class _FFStack:
         self.nl = len(sizes) - 1
         self.WT, self.WB = [], []
         for i in range(self.nl):
-            kin = in_ld if i == 0 else r8(sizes[i])
+            kin = in_ld if i == 0 else rk(sizes[i])
             self.WT.append(_bf(sizes[i + 1], kin, device=dev))          # B operand of the forward GEMM
-            self.WB.append(_bf(kin, r8(sizes[i + 1]), device=dev))      # B operand of the input-gradient GEMM
+            self.WB.append(_bf(kin, rk(sizes[i + 1]), device=dev))      # B operand of the input-gradient GEMM
 
     def pack_ops(self, ops, src):
         st = self.eng.store
@@ -284,13 +291,13 @@ class _FFStack:
 
     def alloc(self, M):
         dev = self.eng.device
-        Mk = r8(M)
+        Mk = rk(M)
         ws = dict(M=M, Mk=Mk, act=[], actT=[], dT=[], dpre=[])
         for i in range(self.nl):
             fin = self.sizes[i]
             if i > 0:
-                ws['act'].append(_bf(M, r8(fin), device=dev))            # hidden activation i-1
-                ws['dpre'].append(_bf(M, r8(fin), device=dev))
+                ws['act'].append(_bf(M, rk(fin), device=dev))            # hidden activation i-1
+                ws['dpre'].append(_bf(M, rk(fin), device=dev))
             t = _bf(fin + 1, Mk, device=dev)
             t[fin, :M] = 1.0                                             # ones row => bias gradient for free
             ws['actT'].append(t)
@@ -305,32 +312,32 @@ class _FFStack:
         for i in range(self.nl):
             last = i == self.nl - 1
             fout = self.sizes[i + 1]
-            kin = self.in_ld if i == 0 else r8(self.sizes[i])
+            kin = self.in_ld if i == 0 else rk(self.sizes[i])
             if last:
                 e.gemm(cur, ld, self.WT[i].data_ptr(), kin, ws['out'].data_ptr(), fout, M, fout, kin,
                        bias=self.bias_ptr(i, src))
             else:
                 o = ws['act'][i]
-                e.gemm(cur, ld, self.WT[i].data_ptr(), kin, o.data_ptr(), r8(fout), M, fout, kin,
+                e.gemm(cur, ld, self.WT[i].data_ptr(), kin, o.data_ptr(), rk(fout), M, fout, kin,
                        bias=self.bias_ptr(i, src), relu=True, out_bf16=True,
                        drop=(e.spec.ff_dropout if train else 0.0, self.stream0 + i, fout))
-                cur, ld = o.data_ptr(), r8(fout)
+                cur, ld = o.data_ptr(), rk(fout)
         return ws['out']
 
     def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train):
-        """d_out: bf16 [M][r8(out)] gradient of the final linear output.  Writes weight grads
+        """d_out: bf16 [M][rk(out)] gradient of the final linear output.  Writes weight grads
         into the store and the input gradient (fp32) into d_in_ptr."""
         e = self.eng
         st = e.store
         M, Mk = ws['M'], ws['Mk']
-        d, ldd = d_out.data_ptr(), r8(self.sizes[-1])
+        d, ldd = d_out.data_ptr(), rk(self.sizes[-1])
         keep = 1.0 / (1.0 - e.spec.ff_dropout) if (train and e.spec.ff_dropout > 0) else 1.0
         for i in range(self.nl - 1, -1, -1):
             last = i == self.nl - 1
             fin, fout = self.sizes[i], self.sizes[i + 1]
             # transposes (K-contiguous operands for the weight-gradient GEMM)
             lib.e2t_transpose_bf16(d, ldd, M, fout, ws['dT'][i].data_ptr(), Mk, e.stream)
-            xp, xld = (x_ptr, self.in_ld) if i == 0 else (ws['act'][i - 1].data_ptr(), r8(fin))
+            xp, xld = (x_ptr, self.in_ld) if i == 0 else (ws['act'][i - 1].data_ptr(), rk(fin))
             blocks = self.in_blocks if i == 0 else [(0, fin, 0)]
             for (r0, n, k0) in blocks:
                 lib.e2t_transpose_bf16(xp + 2 * k0, xld, M, n, ws['actT'][i].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
@@ -342,14 +349,14 @@ class _FFStack:
             else:
                 e.gemm(ws['actT'][i].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
                        st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk, splitk=True)
-            kin = self.in_ld if i == 0 else r8(fin)
+            kin = self.in_ld if i == 0 else rk(fin)
             if i > 0:
                 dp = ws['dpre'][i - 1]
-                e.gemm(d, ldd, self.WB[i].data_ptr(), r8(fout), dp.data_ptr(), r8(fin), M, fin, r8(fout),
-                       out_bf16=True, alpha=keep, mask_src=(ws['act'][i - 1].data_ptr(), r8(fin)))
-                d, ldd = dp.data_ptr(), r8(fin)
+                e.gemm(d, ldd, self.WB[i].data_ptr(), rk(fout), dp.data_ptr(), rk(fin), M, fin, rk(fout),
+                       out_bf16=True, alpha=keep, mask_src=(ws['act'][i - 1].data_ptr(), rk(fin)))
+                d, ldd = dp.data_ptr(), rk(fin)
             else:
-                e.gemm(d, ldd, self.WB[0].data_ptr(), r8(fout), d_in_ptr, d_in_ld, M, kin, r8(fout),
+                e.gemm(d, ldd, self.WB[0].data_ptr(), rk(fout), d_in_ptr, d_in_ld, M, kin, rk(fout),
                        accumulate=accumulate)
 
 
@@ -361,11 +368,11 @@ class _Lstm:
             eng, name, ndir, D, in_blocks, in_ld, Hh, stream
         dev = eng.device
         self.H8 = r8(Hh)
-        self.ldy = ndir * self.H8
+        self.ldy = rk(ndir * self.H8)
         self.N4 = ndir * 4 * Hh
         self.UT, self.KB, self.KB4 = ceil_div(Hh, 16), ceil_div(self.H8, 32), ceil_div(4 * Hh, 32)
         self.WxT = _bf(self.N4, in_ld, device=dev)
-        self.WxB = _bf(in_ld, r8(self.N4), device=dev)
+        self.WxB = _bf(in_ld, rk(self.N4), device=dev)
         self.WhF = _bf(ndir, 4, self.UT, self.KB, 64, 8, device=dev)
         self.WhB = _bf(ndir, self.UT, self.KB4, 64, 8, device=dev)
 
@@ -397,7 +404,7 @@ class _Lstm:
 
     def alloc(self, S, B):
         dev = self.eng.device
-        M, Mk = S * B, r8(S * B)
+        M, Mk = S * B, rk(S * B)
         nd, Hh = self.ndir, self.H
         ws = dict(S=S, B=B, M=M, Mk=Mk)
         ws['Gx'] = _f32(M, self.N4, device=dev)
@@ -406,7 +413,7 @@ class _Lstm:
         RT, UT = ceil_div(B, 16), ceil_div(Hh, 16)
         ws['Cs'] = _f32(S, nd, RT, UT, 2, 64, 2, device=dev)       # lane-native per-step saves (lstm.hip)
         ws['Gs'] = _f32(S, nd, RT, UT, 4, 64, 4, device=dev)
-        ws['dG'] = _bf(M + B, r8(self.N4), device=dev)              # block S = zero slack (rows without successor)
+        ws['dG'] = _bf(M + B, rk(self.N4), device=dev)              # block S = zero slack (rows without successor)
         ws['dGT'] = _bf(self.N4, Mk, device=dev)
         ws['YT'] = _bf(nd, Hh, Mk, device=dev)
         ws['xT'] = _bf(self.D + 1, Mk, device=dev)
@@ -466,19 +473,19 @@ class _Lstm:
         def launch(rb0, nrb, stream):
             d = self.desc(ws, train)
             d.rb_begin, d.rb_count = rb0, nrb
-            lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
+            lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                  ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
                                  ws['dc_carry'].data_ptr(), p(dh0), p(dc0), stream)
         if e.persistent_bwd and dh0 is None and self.persistent_bwd_ok(B, e.num_cus):
             # whole BPTT sweep in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_bwd_persist)
             d = self.desc(ws, train)
-            lib.e2t_lstm_seq_bwd_persistent(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), r8(self.N4), dY_ptr, lddy,
+            lib.e2t_lstm_seq_bwd_persistent(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                             ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final),
                                             p(dc_final), ws['dgx'].data_ptr(), ws['counters'].data_ptr(),
                                             e.sync_err.data_ptr(), e.num_cus, e.stream)
         else:
             e.run_chains(B, launch)
-        lib.e2t_transpose_bf16(ws['dG'].data_ptr(), r8(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
+        lib.e2t_transpose_bf16(ws['dG'].data_ptr(), rk(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
         e.gemm(ws['xT'].data_ptr(), Mk, ws['dGT'].data_ptr(), Mk, st.ptr(self.name + '.Wx', st.g), self.N4,
@@ -492,11 +499,11 @@ class _Lstm:
                    st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, Mk, splitk=True)
         if d_in_ptr is not None:
             if d_in_bf16_mask is not None:
-                e.gemm(ws['dG'].data_ptr(), r8(self.N4), self.WxB.data_ptr(), r8(self.N4), d_in_ptr, d_in_ld, M, self.D,
-                       r8(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
+                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
+                       rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
             else:
-                e.gemm(ws['dG'].data_ptr(), r8(self.N4), self.WxB.data_ptr(), r8(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                       r8(self.N4))
+                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
+                       rk(self.N4))
 
 
 class Seq2SeqEngine:
@@ -516,9 +523,9 @@ class Seq2SeqEngine:
         assert all(h % 2 == 0 for h in s.enc_rnn) and s.dec_rnn % 2 == 0, 'hidden sizes must be even'
         assert s.dec_rnn == 2 * s.enc_rnn[-1], 'decoder state = concat(fwd, bwd) encoder state (App. D2)'
         dev = self.device
-        self.F8 = r8(s.enc_embed)
+        self.F8 = rk(s.enc_embed)
         # conv operand per subject: B operand [F][Kc8]; input-gradient operand [Kc8][F8] made on demand
-        self.convT = {sid: _bf(s.enc_embed, r8(s.decimation * Cc), device=dev) for sid, Cc in s.channels.items()}
+        self.convT = {sid: _bf(s.enc_embed, rk(s.decimation * Cc), device=dev) for sid, Cc in s.channels.items()}
         self.convB = {}
         self.enc = []
         for l, Hh in enumerate(s.enc_rnn):
@@ -526,18 +533,18 @@ class Seq2SeqEngine:
                 D, blocks, ld = s.enc_embed, [(0, s.enc_embed, 0)], self.F8
             else:
                 Hp = s.enc_rnn[l - 1]
-                D, blocks, ld = 2 * Hp, [(0, Hp, 0), (Hp, Hp, r8(Hp))], 2 * r8(Hp)
+                D, blocks, ld = 2 * Hp, [(0, Hp, 0), (Hp, Hp, r8(Hp))], rk(2 * r8(Hp))
             self.enc.append(_Lstm(self, 'enc%d' % l, 2, D, blocks, ld, Hh, STREAM_ENC + l))
         self.aux = None
         if s.aux_layer is not None:
             Hk = s.enc_rnn[s.aux_layer]
             self.aux = _FFStack(self, 'aux', [2 * Hk] + list(s.aux_hidden) + [s.aux_dim],
-                                [(0, Hk, 0), (Hk, Hk, r8(Hk))], 2 * r8(Hk), STREAM_AUX)
-        self.E8 = r8(s.dec_embed)
+                                [(0, Hk, 0), (Hk, Hk, r8(Hk))], rk(2 * r8(Hk)), STREAM_AUX)
+        self.E8 = rk(s.dec_embed)
         self.emb = _bf(s.vocab, self.E8, device=dev)
         self.dec = _Lstm(self, 'dec', 1, s.dec_embed, [(0, s.dec_embed, 0)], self.E8, s.dec_rnn, STREAM_DEC_OUT)
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
-                             [(0, s.dec_rnn, 0)], r8(s.dec_rnn), STREAM_DEC_OUT + 1)
+                             [(0, s.dec_rnn, 0)], rk(s.dec_rnn), STREAM_DEC_OUT + 1)
         self._pack_table = None
         mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
         self.persistent = mode != '0'
@@ -692,8 +699,8 @@ class Seq2SeqEngine:
         s, dev = self.spec, self.device
         Cc, N = s.channels[sid], s.decimation
         S = ceil_div(T, N)
-        M, Mk = S * B, r8(S * B)
-        Kc, Kc8 = N * Cc, r8(N * Cc)
+        M, Mk = S * B, rk(S * B)
+        Kc, Kc8 = N * Cc, rk(N * Cc)
         ws = dict(sid=sid, B=B, T=T, L=L, S=S, M=M, Mk=Mk, C=Cc, Kc=Kc, Kc8=Kc8)
         ws['X'] = _f32(B, T, Cc, device=dev)
         ws['Y'] = _i32(B, L, device=dev)
@@ -712,7 +719,7 @@ class Seq2SeqEngine:
             ws['tlens'], ws['tlens_d'], ws['nval'] = _i32(B, device=dev), _i32(B, device=dev), _i32(1, device=dev)
             ws['At'] = _i32(M, device=dev) if cat else _f32(M, s.aux_dim, device=dev)
             ws['aux'] = self.aux.alloc(M)
-            ws['dP'] = _bf(M, r8(s.aux_dim), device=dev)
+            ws['dP'] = _bf(M, rk(s.aux_dim), device=dev)
             ws['aux_rowloss'] = _f32(M, device=dev)
         Md = L * B
         ws['Md'] = Md
@@ -722,8 +729,8 @@ class Seq2SeqEngine:
         ws['dec'] = self.dec.alloc(L, B)
         ws['c0'] = _f32(B, s.dec_rnn, device=dev)
         ws['proj'] = self.proj.alloc(Md)
-        ws['dlogits'] = _bf(Md, r8(s.vocab), device=dev)
-        ws['dHd'] = _f32(Md, r8(s.dec_rnn), device=dev)
+        ws['dlogits'] = _bf(Md, rk(s.vocab), device=dev)
+        ws['dHd'] = _f32(Md, self.dec.ldy, device=dev)
         ws['de'] = _f32(Md, self.E8, device=dev)
         ws['dh0'], ws['dc0'] = _f32(B, s.dec_rnn, device=dev), _f32(B, s.dec_rnn, device=dev)
         ws['rowloss'], ws['correct'] = _f32(Md, device=dev), _f32(Md, device=dev)
@@ -782,12 +789,12 @@ class Seq2SeqEngine:
             if cat:
                 lib.e2t_softmax_ce(out.data_ptr(), s.aux_dim, M, s.aux_dim, ws['At'].data_ptr(), ws['tlens_d'].data_ptr(), B,
                                    ws['nval'].data_ptr(), s.aux_scale, ws['aux_rowloss'].data_ptr(), None, None,
-                                   ws['dP'].data_ptr(), r8(s.aux_dim), st)
+                                   ws['dP'].data_ptr(), rk(s.aux_dim), st)
                 lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0, ws['loss'].data_ptr() + 4, st)
             else:
                 lib.e2t_mse(out.data_ptr(), s.aux_dim, ws['At'].data_ptr(), M, s.aux_dim, ws['tlens_d'].data_ptr(), B,
                             ws['nval'].data_ptr(), s.aux_scale, ws['aux_rowloss'].data_ptr(), ws['dP'].data_ptr(),
-                            r8(s.aux_dim), st)
+                            rk(s.aux_dim), st)
                 lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0 / s.aux_dim,
                                 ws['loss'].data_ptr() + 4, st)
         # decoder (teacher forced)
@@ -801,7 +808,7 @@ class Seq2SeqEngine:
         logits = self.proj.fwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), src, train)
         lib.e2t_softmax_ce(logits.data_ptr(), s.vocab, Md, s.vocab, ws['Tg'].data_ptr(), ws['dlens'].data_ptr(), B,
                            ws['ntok'].data_ptr(), s.dec_scale, ws['rowloss'].data_ptr(), ws['pred'].data_ptr(),
-                           ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), r8(s.vocab), st)
+                           ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), rk(s.vocab), st)
         lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr(), st)
         lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr() + 8, st)
 
@@ -846,9 +853,9 @@ class Seq2SeqEngine:
         st = self.stream
         store.view('dec.emb', store.g).zero_()          # the embedding scatter-add accumulates by atomics
         # vocabulary projection
-        self.proj.bwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'], ws['dHd'].data_ptr(), r8(s.dec_rnn), False, train)
+        self.proj.bwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train)
         # decoder BPTT (+ gradient into the encoder's final state)
-        self.dec.bwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), r8(s.dec_rnn), train,
+        self.dec.bwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
                      ws['de'].data_ptr(), self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
         dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
         lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), Md, s.dec_embed,
@@ -1052,12 +1059,12 @@ class Seq2SeqEngine:
         for i in range(pr.nl):
             last = i == pr.nl - 1
             fout = pr.sizes[i + 1]
-            kin = pr.in_ld if i == 0 else r8(pr.sizes[i])
+            kin = pr.in_ld if i == 0 else rk(pr.sizes[i])
             if last:
                 self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, pw['out'].data_ptr() + 4 * l * B * fout, fout, B, fout, kin,
                           bias=pr.bias_ptr(i, src))
             else:
-                o = pw['act'][i].data_ptr() + 2 * l * B * r8(fout)
-                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, o, r8(fout), B, fout, kin, bias=pr.bias_ptr(i, src),
+                o = pw['act'][i].data_ptr() + 2 * l * B * rk(fout)
+                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, o, rk(fout), B, fout, kin, bias=pr.bias_ptr(i, src),
                           relu=True, out_bf16=True)
-                cur, ld = o, r8(fout)
+                cur, ld = o, rk(fout)
