@@ -5,8 +5,11 @@
 // is ever needed; callers that hold an operand in the other orientation run
 // e2t_transpose_bf16 first (DESIGN.md "GEMM orientation").
 //
-// Tile: 128 x 128 x 64 per 256-thread workgroup (4 waves as 2x2, each wave a
-// 64x64 patch = 4x4 MFMA 16x16x32 tiles, 64 fp32 accumulators per lane).
+// Tile: TBM x TBN x 64 per workgroup of WM x WN waves (template).  Two instances:
+//   128 x 128, 4 waves as 2x2 (64x64 per wave, 64 fp32 accumulators per lane), 2 workgroups per CU -- small /
+//              split-K products; needs 64 B/clk of LDS-DMA per CU at MFMA peak, which IS the CU's fill rate;
+//   256 x 256, 8 waves as 2x4 (128x64 per wave, 128 accumulators), 1 workgroup per CU, 128 KiB of LDS -- large
+//              products: 128 flop per staged byte, so the DMA hides behind the MFMAs.
 // Staging: direct-to-LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave
 // instruction), two LDS buffers, ONE barrier per K tile: tile t+1 is in flight
 // while tile t is multiplied.  LDS image per operand: [128 rows][8 x 16-B
@@ -30,9 +33,8 @@
 // weight/input gradients; SURVEY.md 2.3 K2,K3,K7,K8).
 #include "common.h"
 #include "ecog2txt_hip.h"
+#include <stdlib.h>
 
-#define BM 128
-#define BN 128
 #define BK 64
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -54,8 +56,17 @@ struct GemmArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
 
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
-    __shared__ uint4 smem[4 * BM * 8];       // [buf][A|B][128 rows][8 chunks] = 64 KiB, ONE object
+extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
+
+// RICH = false drops the ReLU / mask / dropout epilogue: with 32 accumulator tiles per wave the full epilogue body is too
+// large for hipcc to unroll, and a rolled loop indexes the accumulators dynamically (= scratch memory, 4x slower kernel).
+template <int BM, int BN, int WM, int WN, bool RICH>
+__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void k_gemm_nt(GemmArgs p) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int STAGE = (BM + BN) * 8;         // 16-B units per stage: [A: BM rows | B: BN rows][8 chunks]
+    constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
+    constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;      // DMA instructions per wave and operand (8 rows each)
+    uint4* smem = gemm_smem;                     // [2 stages][STAGE], ONE object
 
     // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): each XCD walks a
     // contiguous run of tiles so an A row-panel is re-read from that XCD's own L2.
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
 
     // K range of this split (in full 64-wide tiles; the zero-filled tail belongs to the last split)
     const int nfull = p.K / BK;
@@ -81,48 +92,50 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
     const int t1 = min(nfull, t0 + per);
     const bool my_tail = has_tail && (blockIdx.y == p.splits - 1);
 
-    f32x4 acc[4][4];
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // DMA map: wave w, instruction i (0..3) fills rows (w*4+i)*8 .. +8 of an operand tile;
+    // DMA map: wave w, instruction i fills rows (w*I+i)*8 .. +8 of an operand tile;
     // lane -> (row = base + lane/8, physical chunk = lane%8), source chunk = physical ^ (row&7).
     const int drow = lane >> 3, dpc = lane & 7;
     auto issue = [&](int t, int buf) {
         const int k0 = t * BK;
-        uint4* sa = smem + buf * 2048;
-        uint4* sb = sa + 1024;
+        uint4* sa = smem + buf * STAGE;
+        uint4* sb = sa + BM * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rb = (wave * 4 + i) * 8;
+        for (int i = 0; i < IA; ++i) {
+            const int rb = (wave * IA + i) * 8;
             const int r = rb + drow;
-            const int c = dpc ^ (r & 7);
-            const int gm = min(m0 + r, p.M - 1), gn = min(n0 + r, p.N - 1);
-            dma16_to_lds(p.A + (size_t)gm * p.lda + k0 + c * 8, lds_addr_of(sa + rb * 8));
-            dma16_to_lds(p.B + (size_t)gn * p.ldb + k0 + c * 8, lds_addr_of(sb + rb * 8));
+            const int gm = min(m0 + r, p.M - 1);
+            dma16_to_lds(p.A + (size_t)gm * p.lda + k0 + (dpc ^ (r & 7)) * 8, lds_addr_of(sa + rb * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int rb = (wave * IB + i) * 8;
+            const int r = rb + drow;
+            const int gn = min(n0 + r, p.N - 1);
+            dma16_to_lds(p.B + (size_t)gn * p.ldb + k0 + (dpc ^ (r & 7)) * 8, lds_addr_of(sb + rb * 8));
         }
     };
     const int frow = lane & 15, fq = lane >> 4;
     auto compute = [&](int buf) {
-        const uint4* sa = smem + buf * 2048;
-        const uint4* sb = sa + 1024;
+        const uint4* sa = smem + buf * STAGE;
+        const uint4* sb = sa + BM * 8;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[TI], fb[TJ];
             const int ch = kb * 4 + fq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint4 va = sa[swz(wm + i * 16 + frow, ch)];
-                uint4 vb = sb[swz(wn + i * 16 + frow, ch)];
-                fa[i] = *(bf16x8*)&va;
-                fb[i] = *(bf16x8*)&vb;
-            }
+            for (int i = 0; i < TI; ++i) { uint4 va = sa[swz(wm + i * 16 + frow, ch)]; fa[i] = *(bf16x8*)&va; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TJ; ++j) { uint4 vb = sb[swz(wn + j * 16 + frow, ch)]; fb[j] = *(bf16x8*)&vb; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     };
@@ -142,14 +155,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
         const int srow = tid >> 3, schunk = tid & 7;
         const int kk = nfull * BK + schunk * 8;
         const bool kin = kk < p.K;
-        uint4* sa = smem + cur * 2048;
-        uint4* sb = sa + 1024;
+        uint4* sa = smem + cur * STAGE;
+        uint4* sb = sa + BM * 8;
         const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            const int gm = m0 + r, gn = n0 + r;
+        for (int i = 0; i < BM / (NT / 8); ++i) {
+            const int r = srow + (NT / 8) * i, gm = m0 + r;
             sa[swz(r, schunk)] = (kin && gm < p.M) ? *(const uint4*)(p.A + (size_t)gm * p.lda + kk) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < BN / (NT / 8); ++i) {
+            const int r = srow + (NT / 8) * i, gn = n0 + r;
             sb[swz(r, schunk)] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
         }
         __syncthreads();
@@ -170,14 +186,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
     if (dodrop) dkey = p.drop.seed + (p.drop.step ? (unsigned long long)(*p.drop.step) : 0ull);
     const unsigned dthresh = (unsigned)(p.drop.rate * 16777216.0f);
     const float dkeep = dodrop ? 1.0f / (1.0f - p.drop.rate) : 1.0f;
+    // the bias of this lane's 4 columns per column tile: fetched once, not per row tile (a dependent global load per
+    // (i, j) in the store loop cost 30 us on the encoder input projection)
+    float bias4[TJ][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < TJ; ++j) {
+        const int gn0 = n0 + wn + j * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[j][r] = (p.bias && gn0 + r < Nst) ? p.bias[gn0 + r] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
         const int gm = m0 + wm + i * 16 + frow;
         if (gm >= p.M) continue;
         bool rowvalid = true;
         if (p.lens) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TJ; ++j) {
             const int gn0 = n0 + wn + j * 16 + fq * 4;
             if (gn0 >= p.N) continue;
             float v[4];
@@ -194,13 +219,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs p) {
             if (p.last_col_out && gn0 + 3 >= p.N - 1) p.last_col_out[gm] = v[p.N - 1 - gn0];
             if (gn0 >= Nst) continue;
             const int nv = min(4, Nst - gn0);
-            if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[gn0 + r]; }
-            if (relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
-            if (p.mask_src) {
+            for (int r = 0; r < 4; ++r) v[r] += bias4[j][r];
+            if (RICH && relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            if (RICH && p.mask_src) {
                 const bf16_t* ms = p.mask_src + (size_t)gm * p.ld_mask + gn0;
                 for (int r = 0; r < nv; ++r) v[r] = (ms[r] & 0x7FFF) != 0 ? v[r] : 0.f;    // kept & active
             }
-            if (dodrop) {
+            if (RICH && dodrop) {
                 const unsigned long long e0 = (unsigned long long)gm * p.ld_logical + gn0;
                 if ((e0 & 3ull) == 0) {
                     unsigned rr[4];
@@ -268,6 +293,16 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
         E2T_CHECK_ARG(!((p.flags & E2T_GEMM_OUT_BF16) && (p.flags & E2T_GEMM_ACCUMULATE)));
     }
     E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
+    // tile choice: 256x256 when it fills the chip (>= 1 tile per CU ... ) and plain (no split-K); E2T_GEMM_TILE=128|256 overrides
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("E2T_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+    const bool want_split = ep && (ep->flags & E2T_GEMM_SPLITK) && ep->splitk_ws;
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
+    bool big = !want_split && !rich && t256 >= 192 && K >= 256;
+    if (forced == 128) big = false;
+    if (forced == 256 && !want_split && !rich) big = true;
+    const int BM = big ? 256 : 128, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     if (ep && (ep->flags & E2T_GEMM_SPLITK) && ep->splitk_ws) {
         // plain products only: partial slabs in the caller's workspace, then one fixed-order reduction
@@ -281,7 +316,14 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
         p.splits = s;
         p.slab = (float*)ep->splitk_ws;
     }
-    hipLaunchKernelGGL(k_gemm_nt, dim3(ntm * ntn, p.splits), dim3(256), 0, (hipStream_t)stream, p);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
+        if (e1 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e1)); return E2T_ERR_HIP; }
+        attr_done = true;
+    }
+    if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false>), dim3(ntm * ntn, p.splits), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     if (p.splits > 1) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.slab, p.splits, M, N,
