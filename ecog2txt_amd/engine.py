@@ -460,9 +460,9 @@ class _Lstm:
         else:
             launch(0, 0, e.stream)
 
-    def bwd(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
-            dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0):
-        """BPTT + weight gradients + input gradient.  d_in_bf16_mask=(src_ptr, ld): emit the input
+    def bwd_rec(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
+                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0):
+        """BPTT + input gradient (the critical path of the backward pass).  d_in_bf16_mask=(src_ptr, ld): emit the input
         gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue)."""
         e = self.eng
         st = e.store
@@ -485,6 +485,21 @@ class _Lstm:
                                             e.sync_err.data_ptr(), e.num_cus, e.stream)
         else:
             e.run_chains(B, launch)
+        if d_in_ptr is not None:
+            if d_in_bf16_mask is not None:
+                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
+                       rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
+            else:
+                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
+                       rk(self.N4))
+
+    def bwd_weights(self, ws, x_ptr):
+        """dW_x (+ bias) and dW_h from the dG of bwd_rec: operand transposes + split-K GEMMs.  Nothing downstream
+        of the recurrence depends on it, so the engine runs it on a side stream under the next layer's BPTT."""
+        e = self.eng
+        st = e.store
+        M, Mk, B = ws['M'], ws['Mk'], ws['B']
+        nd, Hh = self.ndir, self.H
         lib.e2t_transpose_bf16(ws['dG'].data_ptr(), rk(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
@@ -497,13 +512,10 @@ class _Lstm:
                                    ws['YT'][dd].data_ptr(), Mk, e.stream)
             e.gemm(ws['YT'][dd].data_ptr(), Mk, ws['dGT'].data_ptr() + 2 * dd * 4 * Hh * Mk, Mk,
                    st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, Mk, splitk=True)
-        if d_in_ptr is not None:
-            if d_in_bf16_mask is not None:
-                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
-                       rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
-            else:
-                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                       rk(self.N4))
+
+    def bwd(self, ws, x_ptr, *args, **kw):
+        self.bwd_rec(ws, x_ptr, *args, **kw)
+        self.bwd_weights(ws, x_ptr)
 
 
 class Seq2SeqEngine:
@@ -556,6 +568,10 @@ class Seq2SeqEngine:
         self._ws = {}
         self._packed = None
         self.splitk_ws = _f32(16 * 1024 * 1024, device=dev)          # 64 MiB of split-K partial slabs
+        self.splitk_ws_side = _f32(16 * 1024 * 1024, device=dev)     # ... of the side stream (weight-gradient branch)
+        self._on_side = False
+        self._wstream = None
+        self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
         self.trainable = None         # None = everything; else set of segment names
 
     def init_params(self, seed=0):
@@ -596,7 +612,8 @@ class Seq2SeqEngine:
         flags = (H.GEMM_RELU if relu else 0) | (H.GEMM_OUT_BF16 if out_bf16 else 0) | (H.GEMM_ACCUMULATE if accumulate else 0)
         if splitk:
             flags |= H.GEMM_SPLITK
-            ep.splitk_ws, ep.splitk_ws_bytes = self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4
+            wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
+            ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
             ep.drop_rate, ep.drop_stream, ep.drop_ld = drop[0], drop[1], drop[2]
@@ -814,8 +831,12 @@ class Seq2SeqEngine:
 
     # ------------------------------------------------------------------ backward
     def backward_stages(self, ws):
-        """[(callable, [(a,b) grad ranges finished by it])]: vocab projection + decoder first, then one
-        stage per encoder layer (top down); the last stage also covers the subject's conv front-end."""
+        """[(main, side, [(a,b) grad ranges finished by the stage])].  The critical path of the backward pass is
+        head -> BPTT(top) -> dX -> BPTT(next) -> ...; the weight gradients of a layer (operand transposes + split-K
+        GEMMs, ~as long as a BPTT sweep) depend only on that layer's dG, so stage k runs BPTT + input gradient of
+        layer l on the main stream and the weight gradients of layer l+1 on a side stream (a parallel branch of the
+        captured hipGraph).  The persistent recurrence is latency-bound and leaves most MFMA cycles (and 30-50 CUs)
+        idle; the GEMM workgroups co-reside with it (register / LDS budgets add up to less than a CU)."""
         store = self.store
         nl = len(self.enc)
         stages = []
@@ -830,20 +851,47 @@ class Seq2SeqEngine:
                     out.append([a, b])
             return [tuple(r) for r in out]
         head = [n for n in store.order if n.startswith('proj') or n.startswith('dec.')]
-        stages.append((lambda train: self._bwd_head(ws, train), rng_of(head)))
+        stages.append((lambda train: self._bwd_head(ws, train), None, rng_of(head)))
+        enc_names = lambda l: [n for n in store.order if n.startswith('enc%d.' % l)]
+        aux_names = [n for n in store.order if n.startswith('aux')]
         for l in range(nl - 1, -1, -1):
-            names = [n for n in store.order if n.startswith('enc%d.' % l)]
-            if self.spec.aux_layer == l:
-                names = [n for n in store.order if n.startswith('aux')] + names
-            if l == 0:
-                names = names + ['conv%s.W' % ws['sid']]
-            stages.append((lambda train, l=l: self._bwd_enc(ws, l, train), rng_of(names)))
+            names = list(aux_names) if self.spec.aux_layer == l else []       # the aux head's own gradients: main stream
+            side = None
+            if l < nl - 1:
+                names = names + enc_names(l + 1)
+                side = (lambda train, l=l: self._bwd_enc_weights(ws, l + 1))
+            stages.append((lambda train, l=l: self._bwd_enc_rec(ws, l, train), side, rng_of(names)))
+        stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
         return stages
+
+    def run_stage(self, main, side, train):
+        """main on the current stream, side (if any) on the side stream, joined at the end."""
+        if side is None or not self.overlap:
+            main(train)
+            if side is not None:
+                side(train)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(device=self.device)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        self._wstream.wait_event(fork)
+        main(train)
+        with torch.cuda.stream(self._wstream):
+            self._on_side = True
+            try:
+                side(train)
+            finally:
+                self._on_side = False
+            join = torch.cuda.Event()
+            join.record(self._wstream)
+        cur.wait_event(join)
 
     def backward(self, ws, train=True, after_stage=None):
         ws['have_dy'] = [False] * len(self.enc)
-        for i, (fn, ranges) in enumerate(self.backward_stages(ws)):
-            fn(train)
+        for i, (main, side, ranges) in enumerate(self.backward_stages(ws)):
+            self.run_stage(main, side, train)
             if after_stage:
                 after_stage(i, ranges)
 
@@ -861,10 +909,9 @@ class Seq2SeqEngine:
         lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), Md, s.dec_embed,
                           store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), st)
 
-    def _bwd_enc(self, ws, l, train):
-        s, store = self.spec, self.store
-        M, Mk = ws['M'], ws['Mk']
-        st = self.stream
+    def _bwd_enc_rec(self, ws, l, train):
+        """aux head (if it taps layer l), BPTT of layer l, gradient into the layer below."""
+        s = self.spec
         nl = len(self.enc)
         have_dy = ws['have_dy']
         lay, lw = self.enc[l], ws['enc'][l]
@@ -875,12 +922,22 @@ class Seq2SeqEngine:
         dY = ws['dY'][l].data_ptr() if have_dy[l] else None
         fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
         if l > 0:
-            lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy, **fin)
+            lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy, **fin)
             have_dy[l - 1] = True
             return
         keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
-        lay.bwd(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dEpre'].data_ptr(), self.F8,
-                d_in_bf16_mask=(ws['E'].data_ptr(), self.F8), d_in_alpha=keep, **fin)
+        lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dEpre'].data_ptr(), self.F8,
+                    d_in_bf16_mask=(ws['E'].data_ptr(), self.F8), d_in_alpha=keep, **fin)
+
+    def _bwd_enc_weights(self, ws, l):
+        """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end)."""
+        s, store = self.spec, self.store
+        M, Mk = ws['M'], ws['Mk']
+        st = self.stream
+        x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
+        self.enc[l].bwd_weights(ws['enc'][l], x)
+        if l > 0:
+            return
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
         sid = ws['sid']
         lib.e2t_transpose_bf16(ws['dEpre'].data_ptr(), self.F8, M, s.enc_embed, ws['dEpreT'].data_ptr(), Mk, st)
@@ -975,13 +1032,13 @@ class Seq2SeqEngine:
             if dp:
                 stages = self.backward_stages(ws)
                 graphs = []
-                for i, (fn, ranges) in enumerate(stages):
+                for i, (main, side, ranges) in enumerate(stages):
                     gi = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gi):
                         if i == 0:
                             self.forward(ws, train=True)
                             ws['have_dy'] = [False] * len(self.enc)
-                        fn(True)
+                        self.run_stage(main, side, True)
                     graphs.append((gi, ranges))
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
