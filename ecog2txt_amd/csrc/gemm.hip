@@ -56,6 +56,66 @@ struct GemmArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
 
+// ---- epilogue shared by the GEMM kernel (direct store) and the split-K reduction ----------------------------------
+struct EpiCtx {
+    bool out_bf16, accum, relu, dodrop, vec_ok;
+    int Nst;                          // columns that go to C (N-1 when the last column is diverted to last_col_out)
+    unsigned long long dkey; unsigned dthresh; float dkeep;
+};
+__device__ __forceinline__ EpiCtx epi_ctx(const GemmArgs& p) {
+    EpiCtx c;
+    c.out_bf16 = p.flags & E2T_GEMM_OUT_BF16;
+    c.accum = p.flags & E2T_GEMM_ACCUMULATE;
+    c.relu = p.flags & E2T_GEMM_RELU;
+    c.dodrop = (p.flags & E2T_GEMM_DROPOUT) && p.drop.rate > 0.f;
+    c.Nst = p.last_col_out ? p.N - 1 : p.N;
+    c.vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
+    c.dkey = 0;
+    if (c.dodrop) c.dkey = p.drop.seed + (p.drop.step ? (unsigned long long)(*p.drop.step) : 0ull);
+    c.dthresh = (unsigned)(p.drop.rate * 16777216.0f);
+    c.dkeep = c.dodrop ? 1.0f / (1.0f - p.drop.rate) : 1.0f;
+    return c;
+}
+// v: alpha * product (+ bias) of row gm, columns gn0..gn0+3.  RICH = false drops ReLU / mask / dropout.
+template <bool RICH>
+__device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, int gm, int gn0, float (&v)[4], bool rowvalid) {
+    if (p.last_col_out && gn0 + 3 >= p.N - 1 && gn0 <= p.N - 1) p.last_col_out[gm] = v[p.N - 1 - gn0];
+    if (gn0 >= ec.Nst) return;
+    const int nv = min(4, ec.Nst - gn0);
+    if (RICH && ec.relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+    if (RICH && p.mask_src) {
+        const bf16_t* ms = p.mask_src + (size_t)gm * p.ld_mask + gn0;
+        for (int r = 0; r < nv; ++r) v[r] = (ms[r] & 0x7FFF) != 0 ? v[r] : 0.f;    // kept & active
+    }
+    if (RICH && ec.dodrop) {
+        const unsigned long long e0 = (unsigned long long)gm * p.ld_logical + gn0;
+        if ((e0 & 3ull) == 0) {
+            unsigned rr[4];
+            const unsigned long long ctr = e0 >> 2;
+            philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), p.drop.stream, 0u, (unsigned)ec.dkey, (unsigned)(ec.dkey >> 32), rr);
+            for (int r = 0; r < 4; ++r) v[r] *= ((rr[r] >> 8) >= ec.dthresh) ? ec.dkeep : 0.f;
+        } else {
+            for (int r = 0; r < nv; ++r) v[r] *= drop_scale(p.drop, e0 + r);
+        }
+    }
+    if (!rowvalid) { for (int r = 0; r < 4; ++r) v[r] = 0.f; }
+    if (ec.out_bf16) {
+        bf16_t* c = (bf16_t*)p.C + (size_t)gm * p.ldc + gn0;
+        if (nv == 4 && (p.ldc & 3) == 0) *(ushort4*)c = make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+        else for (int r = 0; r < nv; ++r) c[r] = f2bf(v[r]);
+    } else {
+        float* c = (float*)p.C + (size_t)gm * p.ldc + gn0;
+        if (nv == 4 && ec.vec_ok) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (ec.accum) { const float4 old = *(const float4*)c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            *(float4*)c = o;
+        } else {
+            for (int r = 0; r < nv; ++r) c[r] = ec.accum ? (c[r] + v[r]) : v[r];
+        }
+    }
+}
+
+
 extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
 
 // RICH = false drops the ReLU / mask / dropout epilogue: with 32 accumulator tiles per wave the full epilogue body is too
@@ -175,17 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     // epilogue.  MFMA roles are (B-tile fragment, A-tile fragment), so D[i][j]: column j = lane&15 is the
     // M row, rows (lane>>4)*4 + r are FOUR CONSECUTIVE N columns: every lane stores 16 B (fp32) / 8 B (bf16)
     // per sub-tile instead of four scattered words, and bias / mask / dropout are fetched 4 at a time.
-    const bool out_bf16 = p.flags & E2T_GEMM_OUT_BF16;
-    const bool accum = p.flags & E2T_GEMM_ACCUMULATE;
-    const bool relu = p.flags & E2T_GEMM_RELU;
-    const bool dodrop = (p.flags & E2T_GEMM_DROPOUT) && p.drop.rate > 0.f;
+    const EpiCtx ec = epi_ctx(p);
     const bool atomic = p.splits > 1;
-    const int Nst = p.last_col_out ? p.N - 1 : p.N;                 // columns that go to C
-    const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
-    unsigned long long dkey = 0;
-    if (dodrop) dkey = p.drop.seed + (p.drop.step ? (unsigned long long)(*p.drop.step) : 0ull);
-    const unsigned dthresh = (unsigned)(p.drop.rate * 16777216.0f);
-    const float dkeep = dodrop ? 1.0f / (1.0f - p.drop.rate) : 1.0f;
     // the bias of this lane's 4 columns per column tile: fetched once, not per row tile (a dependent global load per
     // (i, j) in the store loop cost 30 us on the encoder input projection)
     float bias4[TJ][4];
@@ -193,14 +244,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     for (int j = 0; j < TJ; ++j) {
         const int gn0 = n0 + wn + j * 16 + fq * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias4[j][r] = (p.bias && gn0 + r < Nst) ? p.bias[gn0 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bias4[j][r] = (p.bias && !atomic && gn0 + r < ec.Nst) ? p.bias[gn0 + r] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int gm = m0 + wm + i * 16 + frow;
         if (gm >= p.M) continue;
         bool rowvalid = true;
-        if (p.lens) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
+        if (p.lens && !atomic) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int gn0 = n0 + wn + j * 16 + fq * 4;
@@ -209,63 +260,41 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
             if (atomic) {
-                // split-K: dense partial slab (all N columns incl. the bias column); summed in fixed order later
+                // split-K: dense partial slab (all N columns incl. the bias column); summed in fixed order, and run
+                // through the same epilogue, by k_splitk_reduce
                 float* c = p.slab + ((size_t)blockIdx.y * p.M + gm) * p.N + gn0;
                 const int nn = min(4, p.N - gn0);
                 if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
                 else for (int r = 0; r < nn; ++r) c[r] = v[r];
                 continue;
             }
-            if (p.last_col_out && gn0 + 3 >= p.N - 1) p.last_col_out[gm] = v[p.N - 1 - gn0];
-            if (gn0 >= Nst) continue;
-            const int nv = min(4, Nst - gn0);
+#pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += bias4[j][r];
-            if (RICH && relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
-            if (RICH && p.mask_src) {
-                const bf16_t* ms = p.mask_src + (size_t)gm * p.ld_mask + gn0;
-                for (int r = 0; r < nv; ++r) v[r] = (ms[r] & 0x7FFF) != 0 ? v[r] : 0.f;    // kept & active
-            }
-            if (RICH && dodrop) {
-                const unsigned long long e0 = (unsigned long long)gm * p.ld_logical + gn0;
-                if ((e0 & 3ull) == 0) {
-                    unsigned rr[4];
-                    const unsigned long long ctr = e0 >> 2;
-                    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), p.drop.stream, 0u, (unsigned)dkey, (unsigned)(dkey >> 32), rr);
-                    for (int r = 0; r < 4; ++r) v[r] *= ((rr[r] >> 8) >= dthresh) ? dkeep : 0.f;
-                } else {
-                    for (int r = 0; r < nv; ++r) v[r] *= drop_scale(p.drop, e0 + r);
-                }
-            }
-            if (!rowvalid) { for (int r = 0; r < 4; ++r) v[r] = 0.f; }
-            if (out_bf16) {
-                bf16_t* c = (bf16_t*)p.C + (size_t)gm * p.ldc + gn0;
-                if (nv == 4 && (p.ldc & 3) == 0) *(ushort4*)c = make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
-                else for (int r = 0; r < nv; ++r) c[r] = f2bf(v[r]);
-            } else {
-                float* c = (float*)p.C + (size_t)gm * p.ldc + gn0;
-                if (nv == 4 && vec_ok) {
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (accum) { const float4 old = *(const float4*)c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-                    *(float4*)c = o;
-                } else {
-                    for (int r = 0; r < nv; ++r) c[r] = accum ? (c[r] + v[r]) : v[r];
-                }
-            }
+            epi_store4<RICH>(p, ec, gm, gn0, v, rowvalid);
         }
     }
 }
 
-// C[m][n] (+)= sum_s slab[s][m][n] in fixed split order (deterministic); column N-1 -> last_col_out if set
-__global__ __launch_bounds__(256) void k_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
-                                                        float* last_col_out, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    const int m = i / N, n = i - (size_t)m * N;
-    float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += slab[(size_t)s * M * N + i];
-    if (last_col_out && n == N - 1) { last_col_out[m] = acc; return; }
-    float* c = C + (size_t)m * ldc + n;
-    *c = accumulate ? (*c + acc) : acc;
+// C[m][n] (+)= epilogue(sum_s slab[s][m][n]) in fixed split order (deterministic); 4 consecutive columns per thread so
+// the dropout mask is the GEMM kernel's (one Philox counter per aligned group of 4)
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p) {
+    const int N4 = (p.N + 3) >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)p.M * N4) return;
+    const int gm = (int)(idx / N4), gn0 = (int)(idx - (size_t)gm * N4) * 4;
+    const int nn = min(4, p.N - gn0);
+    const EpiCtx ec = epi_ctx(p);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (p.N & 3) == 0;
+    for (int s = 0; s < p.splits; ++s) {
+        const float* c = p.slab + ((size_t)s * p.M + gm) * p.N + gn0;
+        if (vec) { const float4 t = *(const float4*)c; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+        else for (int r = 0; r < nn; ++r) v[r] += c[r];
+    }
+    if (p.bias) for (int r = 0; r < nn; ++r) if (gn0 + r < ec.Nst) v[r] += p.bias[gn0 + r];
+    bool rowvalid = true;
+    if (p.lens) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
+    epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
 }
 
 extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -293,10 +322,16 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
         E2T_CHECK_ARG(!((p.flags & E2T_GEMM_OUT_BF16) && (p.flags & E2T_GEMM_ACCUMULATE)));
     }
     E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
-    // tile choice: 256x256 when it fills the chip (>= 1 tile per CU ... ) and plain (no split-K); E2T_GEMM_TILE=128|256 overrides
+    // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("E2T_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-    const bool want_split = ep && (ep->flags & E2T_GEMM_SPLITK) && ep->splitk_ws;
+    // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
+    // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
+    // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
+    const int nfull = K / BK;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const bool have_ws = ep && ep->splitk_ws && ep->splitk_ws_bytes > 0;
+    const bool want_split = have_ws && ((ep->flags & E2T_GEMM_SPLITK) || (t128 <= 160 && nfull >= 16));
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
     bool big = !want_split && !rich && t256 >= 192 && K >= 256;
@@ -304,12 +339,10 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     if (forced == 256 && !want_split && !rich) big = true;
     const int BM = big ? 256 : 128, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    if (ep && (ep->flags & E2T_GEMM_SPLITK) && ep->splitk_ws) {
-        // plain products only: partial slabs in the caller's workspace, then one fixed-order reduction
-        E2T_CHECK_ARG(!p.bias && !p.mask_src && !p.lens && !(p.flags & (E2T_GEMM_OUT_BF16 | E2T_GEMM_RELU | E2T_GEMM_DROPOUT)));
-        const int nfull = K / BK, tiles = ntm * ntn;
+    if (want_split) {
+        const int tiles = ntm * ntn;
         int s = (512 + tiles - 1) / tiles;             // aim at ~2 workgroups per CU
-        if (s > nfull / 8) s = nfull / 8;              // keep >= 8 K tiles per split
+        if (s > nfull / 6) s = nfull / 6;              // keep >= 6 K tiles per split
         const size_t per = (size_t)M * N * sizeof(float);
         if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
         if (s < 1) s = 1;
@@ -325,9 +358,8 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false>), dim3(ntm * ntn, p.splits), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     if (p.splits > 1) {
-        const size_t n = (size_t)M * N;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.slab, p.splits, M, N,
-                           (float*)C, ldc, p.last_col_out, (p.flags & E2T_GEMM_ACCUMULATE) ? 1 : 0);
+        const size_t n = (size_t)M * ((N + 3) / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;

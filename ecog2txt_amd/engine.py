@@ -612,8 +612,9 @@ class Seq2SeqEngine:
         flags = (H.GEMM_RELU if relu else 0) | (H.GEMM_OUT_BF16 if out_bf16 else 0) | (H.GEMM_ACCUMULATE if accumulate else 0)
         if splitk:
             flags |= H.GEMM_SPLITK
-            wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
-            ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        # the workspace is always offered: the library also splits K on its own when a product has too few tiles
+        wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
+        ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
             ep.drop_rate, ep.drop_stream, ep.drop_ld = drop[0], drop[1], drop[2]
