@@ -72,7 +72,7 @@ int e2t_decoder_tokens(const int32_t* y, int B, int L, int eos, int32_t* U, int3
 #define E2T_GEMM_OUT_BF16 2
 #define E2T_GEMM_ACCUMULATE 4      /* fp32 output only */
 #define E2T_GEMM_DROPOUT 8
-#define E2T_GEMM_SPLITK 16         /* plain fp32 product; K split over workgroups, partials in splitk_ws, fixed-order reduce */
+#define E2T_GEMM_SPLITK 16         /* split K over workgroups: partials in splitk_ws, fixed-order reduce which applies the epilogue */
 typedef struct e2t_gemm_epilogue {
     const float* bias;             /* [N] or NULL */
     const void* relu_bwd_src;      /* bf16 [M][ld]: out = src != 0 ? out : 0 (ReLU/dropout backward) */
@@ -84,7 +84,8 @@ typedef struct e2t_gemm_epilogue {
     float drop_rate; unsigned long long drop_seed; const int32_t* drop_step; unsigned drop_stream; int drop_ld;
     float* last_col_out;           /* fp32 [M] or NULL: column N-1 of the product is written here instead of C
                                       (a ones row appended to B turns it into the bias gradient) */
-    void* splitk_ws;               /* device workspace for E2T_GEMM_SPLITK partial slabs (or NULL: no split) */
+    void* splitk_ws;               /* device workspace for split-K partial slabs (or NULL: never split).  When offered, the
+                                      library also splits on its own if the product has few 128x128 tiles and K >= 1024 */
     size_t splitk_ws_bytes;
 } e2t_gemm_epilogue;
 int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,

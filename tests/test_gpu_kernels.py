@@ -93,6 +93,56 @@ def test_gemm_epilogues(hl):
     np.testing.assert_allclose(host(ct), want, rtol=1e-5, atol=1e-4)
 
 
+def test_gemm_splitk_runs_the_full_epilogue(hl):
+    """Few output tiles + long K: the library splits K on its own when a workspace is offered, and the reduction
+    applies the same bias / ReLU / dropout / row mask / bf16 epilogue (same Philox mask) as the direct store."""
+    rng = np.random.default_rng(5)
+    M, N, K, rowsB = 200, 100, 2048, 8
+    A, Bm = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+    bias = rng.standard_normal(N)
+    lens = rng.integers(0, M // rowsB + 1, size=rowsB)
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    bt = torch.tensor(bias, dtype=torch.float32, device='cuda')
+    lt = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    step = torch.tensor([2], dtype=torch.int32, device='cuda')
+    wsb = torch.zeros(4 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ldc = r8(N)
+    outs = []
+    for use_ws in (False, True):
+        out = torch.zeros(M, ldc, dtype=torch.bfloat16, device='cuda')
+        ep = hl.GemmEpilogue()
+        ep.bias, ep.alpha = bt.data_ptr(), 1.0
+        ep.flags = hl.GEMM_RELU | hl.GEMM_OUT_BF16 | hl.GEMM_DROPOUT
+        ep.drop_rate, ep.drop_seed, ep.drop_step, ep.drop_stream, ep.drop_ld = 0.25, 77, step.data_ptr(), 3, N
+        ep.row_lens, ep.rows_per_step = lt.data_ptr(), rowsB
+        if use_ws:
+            ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, out.data_ptr(), ldc, M, N, K, C.byref(ep), st())
+        torch.cuda.synchronize()
+        outs.append(host(out)[:, :N])
+    assert float(wsb.abs().max()) > 0, 'the split-K path must have been taken'
+    ref = np.maximum(round_bf16(A) @ round_bf16(Bm).T + bias, 0.0)
+    ref = ref * keep_mask((M, N), 0.25, 79, 3) / 0.75
+    valid = (np.arange(M) // rowsB) < lens[np.arange(M) % rowsB]
+    ref = round_bf16(ref * valid[:, None])
+    for got in outs:
+        np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-5)
+    assert ((outs[0] == 0) == (outs[1] == 0)).all()            # identical masks
+    # fp32 accumulate through the split path, with the last column diverted (bias-gradient column of the dW GEMMs)
+    c0 = rng.standard_normal((M, N - 1))
+    ct = torch.tensor(c0, dtype=torch.float32, device='cuda')
+    lastc = torch.zeros(M, dtype=torch.float32, device='cuda')
+    ep2 = hl.GemmEpilogue()
+    ep2.alpha, ep2.flags = 0.5, hl.GEMM_ACCUMULATE | hl.GEMM_SPLITK
+    ep2.last_col_out = lastc.data_ptr()
+    ep2.splitk_ws, ep2.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, ct.data_ptr(), N - 1, M, N, K, C.byref(ep2), st())
+    torch.cuda.synchronize()
+    full = 0.5 * (round_bf16(A) @ round_bf16(Bm).T)
+    np.testing.assert_allclose(host(ct), c0 + full[:, :N - 1], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(host(lastc), full[:, N - 1], rtol=1e-5, atol=2e-3)
+
+
 @pytest.mark.parametrize('R,Cc', [(5, 3), (64, 64), (100, 37), (257, 130)])
 def test_transpose(hl, R, Cc):
     rng = np.random.default_rng(R)
