@@ -461,7 +461,7 @@ class _Lstm:
             launch(0, 0, e.stream)
 
     def bwd_rec(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
-                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0):
+                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False):
         """BPTT + input gradient (the critical path of the backward pass).  d_in_bf16_mask=(src_ptr, ld): emit the input
         gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue)."""
         e = self.eng
@@ -491,7 +491,7 @@ class _Lstm:
                        rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
             else:
                 e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                       rk(self.N4))
+                       rk(self.N4), accumulate=d_in_accumulate)
 
     def bwd_weights(self, ws, x_ptr):
         """dW_x (+ bias) and dW_h from the dG of bwd_rec: operand transposes + split-K GEMMs.  Nothing downstream
@@ -793,7 +793,9 @@ class Seq2SeqEngine:
         st = self.stream
         self.encode(ws, src, train)
         ws['use_aux'] = bool(self.aux and with_aux and s.aux_scale != 0.0)
-        if ws['use_aux']:
+
+        def aux_forward():
+            st = self.stream
             cat = s.aux_dist == 'categorical'
             k = s.aux_layer
             if cat:
@@ -815,6 +817,13 @@ class Seq2SeqEngine:
                             rk(s.aux_dim), st)
                 lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0 / s.aux_dim,
                                 ws['loss'].data_ptr() + 4, st)
+        # the auxiliary head only needs the encoder; it runs on the side stream under the (latency-bound) decoder
+        join = None
+        if ws['use_aux']:
+            if self.overlap:
+                join = self.fork_side(aux_forward)
+            else:
+                aux_forward()
         # decoder (teacher forced)
         lib.e2t_seq_lengths_i32(ws['Y'].data_ptr(), B, L, PAD_ID, 1, ws['dlens'].data_ptr(), None, st)
         lib.e2t_sum_i32(ws['dlens'].data_ptr(), B, ws['ntok'].data_ptr(), st)
@@ -829,6 +838,8 @@ class Seq2SeqEngine:
                            ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), rk(s.vocab), st)
         lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr(), st)
         lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr() + 8, st)
+        if join is not None:
+            self.join_side(join)
 
     # ------------------------------------------------------------------ backward
     def backward_stages(self, ws):
@@ -852,11 +863,13 @@ class Seq2SeqEngine:
                     out.append([a, b])
             return [tuple(r) for r in out]
         head = [n for n in store.order if n.startswith('proj') or n.startswith('dec.')]
-        stages.append((lambda train: self._bwd_head(ws, train), None, rng_of(head)))
         enc_names = lambda l: [n for n in store.order if n.startswith('enc%d.' % l)]
         aux_names = [n for n in store.order if n.startswith('aux')]
+        # the auxiliary head's backward (its own weight gradients + its share of dY[aux_layer]) only needs the forward
+        # pass: side stream, under the decoder's BPTT; the layer above then ACCUMULATES its input gradient onto it
+        stages.append((lambda train: self._bwd_head(ws, train), lambda train: self._bwd_aux(ws, train), rng_of(head + aux_names)))
         for l in range(nl - 1, -1, -1):
-            names = list(aux_names) if self.spec.aux_layer == l else []       # the aux head's own gradients: main stream
+            names = []
             side = None
             if l < nl - 1:
                 names = names + enc_names(l + 1)
@@ -865,29 +878,38 @@ class Seq2SeqEngine:
         stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
         return stages
 
-    def run_stage(self, main, side, train):
-        """main on the current stream, side (if any) on the side stream, joined at the end."""
-        if side is None or not self.overlap:
-            main(train)
-            if side is not None:
-                side(train)
-            return
+    def fork_side(self, fn):
+        """Run fn() on the side stream, ordered after everything enqueued so far on the current stream (a parallel
+        branch of a captured hipGraph).  Returns the event to pass to join_side()."""
         cur = torch.cuda.current_stream(self.device)
         if self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
         fork = torch.cuda.Event()
         fork.record(cur)
         self._wstream.wait_event(fork)
-        main(train)
         with torch.cuda.stream(self._wstream):
             self._on_side = True
             try:
-                side(train)
+                fn()
             finally:
                 self._on_side = False
             join = torch.cuda.Event()
             join.record(self._wstream)
-        cur.wait_event(join)
+        return join
+
+    def join_side(self, join):
+        torch.cuda.current_stream(self.device).wait_event(join)
+
+    def run_stage(self, main, side, train):
+        """main on the current stream, side (if any) on the side stream, joined at the end."""
+        if side is None or not self.overlap:
+            if side is not None:
+                side(train)
+            main(train)
+            return
+        join = self.fork_side(lambda: side(train))
+        main(train)
+        self.join_side(join)
 
     def backward(self, ws, train=True, after_stage=None):
         ws['have_dy'] = [False] * len(self.enc)
@@ -916,19 +938,26 @@ class Seq2SeqEngine:
         nl = len(self.enc)
         have_dy = ws['have_dy']
         lay, lw = self.enc[l], ws['enc'][l]
-        if ws['use_aux'] and s.aux_layer == l:
-            self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, have_dy[l], train)
-            have_dy[l] = True
         x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
         dY = ws['dY'][l].data_ptr() if have_dy[l] else None
         fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
         if l > 0:
-            lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy, **fin)
+            lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy,
+                        d_in_accumulate=have_dy[l - 1], **fin)
             have_dy[l - 1] = True
             return
         keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
         lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dEpre'].data_ptr(), self.F8,
                     d_in_bf16_mask=(ws['E'].data_ptr(), self.F8), d_in_alpha=keep, **fin)
+
+    def _bwd_aux(self, ws, train):
+        s = self.spec
+        if not ws['use_aux']:
+            return
+        l = s.aux_layer
+        lay, lw = self.enc[l], ws['enc'][l]
+        self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train)
+        ws['have_dy'][l] = True
 
     def _bwd_enc_weights(self, ws, l):
         """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end)."""
