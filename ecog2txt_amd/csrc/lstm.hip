@@ -401,13 +401,16 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
 //     parity), so the sums are bit-identical to it; the lane then owns all FOUR gate sums of 4 consecutive units;
 //   * c lives in registers across steps (still saved per step for BPTT);
 //   * h_t is exchanged between the workgroups of a "cluster" (the UT unit tiles that share a row block and a
-//     direction) through global memory: write-through (agent-scope = sc1) stores, the wave drains them and then
-//     raises its own flag word; consumers poll the cluster's flag words (bounded spin) before loading.  The protocol
-//     is placement-independent; clusters are laid on XCDs (workgroup id % 8 = XCC id, read back from
-//     HW_REG_XCC_ID by scripts/probes/xchg_probe.hip) only for speed: a same-XCD hand-off costs ~0.7 us
-//     (store, ack, atomic / poll, load), a cross-XCD one ~1.2 us;
+//     direction) WITHOUT flags: every bf16 in `hx` carries a 1-bit stamp in bit 14 (free, because |h| <= 1 keeps the
+//     exponent below 128) that toggles each time its buffer is rewritten; a consumer loads its fragments and retries
+//     (bounded) until every value it needs shows the expected stamp, then strips the stamps.  This removes the
+//     producer's store-ack wait and the separate flag round trip (~0.9 us of a 3.4 us step).  Each 8-B producer store
+//     is stamped per value, so a torn 16-B read is simply seen as stale.  A buffer is only rewritten by a producer
+//     that has consumed the following step from EVERY cluster member, each of which had read the buffer before
+//     publishing, so nothing is overwritten early.  The protocol is placement-independent; clusters are laid on XCDs
+//     (workgroup id % 8 = XCC id, read back from HW_REG_XCC_ID by scripts/probes/xchg_probe.hip) only for speed;
 //   * everything that is not on the h_t -> h_{t+1} critical path (gate / cell saves, the Philox mask and the
-//     dropped copy for the next layer, the Gx prefetch of the next step) is issued AFTER the publish and runs
+//     dropped copy for the next layer, the Gx prefetch of the next step) is issued AFTER the exchange store and runs
 //     while the other workgroups' stores are in flight.
 // All workgroups must be co-resident (one per CU: checked on the host against the CU count); every spin is
 // bounded and raises err[0] instead of hanging.
@@ -415,11 +418,9 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
 struct LstmPersistArgs {
     LstmFwdArgs a;
     bf16_t* hx;             // [2 step parities][ndir][4*ceil(B/64)][KB][64 lanes][8]  h exchange, MFMA operand order; pad lanes stay zero
-    unsigned* counters;     // [clusters][E2T_PERSIST_FLAG_STRIDE] per-producer-wave step flags, zeroed before the launch
     int* err;               // [1] set to 1 if a bounded spin gave up
 };
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define E2T_PERSIST_FLAG_STRIDE 128      // >= 4 waves x 26 unit tiles (H <= 416)
 
 template <int KB>        // k-blocks of 32 over H8: compile-time, so every fragment sits in a fixed register
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa) {
@@ -468,32 +469,25 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s & 1) * 4 + r) * 64));
     };
     gx_load(0);
-    unsigned* flags = pa.counters + (size_t)cl * E2T_PERSIST_FLAG_STRIDE;
+    // Stamp convention (see the state loads below).  Every slot of an exchange buffer ends a launch on the same stamp
+    // (all producers make the same number of writes), so each wave reads the leftover stamp of its own slot once and
+    // starts the new launch on the opposite one: leftovers -- of the previous launch or of the initial fill -- never
+    // look fresh, and no flag, counter or reset pass is needed.
+    const size_t hx_slot = ((((size_t)p.ndir * 0 + dir) * (RB * 4) + rt) * KB + (ut >> 1)) * 512 + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4;
+    const size_t hx_buf = (size_t)p.ndir * (RB * 4) * KB * 512;          // elements per step-parity buffer
+    unsigned base[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        unsigned long long v = 0ull;
+        if (own) v = __hip_atomic_load((const unsigned long long*)(pa.hx + q * hx_buf + hx_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base[q] = (__builtin_amdgcn_readfirstlane((unsigned)(v >> 14)) & 1u) ^ 1u;     // lane 0 owns a slot whenever the wave owns any
+    }
     long long pts[8];
     const long long t_entry = p.dbg ? wall_clock64() : 0;
 #define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)      // 100 MHz, chip-wide
 
     for (int s = 0; s < S; ++s) {
         PSTAMP(0);
-        // ---- wait until every wave of the cluster has published h of step s-1 ----
-        if (s > 0 && !(p.ablate & 8)) {
-            // every producer wave of the cluster owns one flag word (= number of steps it has published); plain
-            // write-through stores, no read-modify-write: 100 same-address device-scope atomics per step serialise
-            // at ~70 ns each (measured: 7 us per step).  Bounded spin: never hang the GPU; once any wave has given
-            // up (err set) nobody waits any more, so a broken launch drains in milliseconds.
-            const int nfl = 4 * p.UT;
-            int spins = 0;
-            for (;;) {
-                bool ok = true;
-                for (int i = lane; i < nfl; i += 64) ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                if ((spins & 1023) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1 << 18)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        PSTAMP(1);
         // ---- h_{t-1} fragments of this lane's utterance (MFMA B operand: k = kb*32 + fq*8 .. +8) ----
         const bool active = s < len;
         const int t = dir ? (len - 1 - s) : s;
@@ -507,15 +501,52 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
                 asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(st[kb]) : "v"(src), "i"(kb * 64) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));         // uses stay behind the wait
         } else {
+            // No flags: every bf16 in the exchange buffer carries a 1-bit stamp in bit 14 (free: |h| <= 1 keeps the
+            // exponent below 128).  Buffer (s-1)&1 is rewritten every other step, so its stamp toggles with (s-1)>>1;
+            // the consumer simply loads and retries until every value it needs shows the expected stamp.
             const bf16_t* src = pa.hx + ((((size_t)((s - 1) & 1) * p.ndir + dir) * (RB * 4) + rt) * KB * 64 + lane) * 8;
+            const bool tag1 = ((((s - 1) >> 1) & 1) ^ ((s - 1) & 1 ? base[1] : base[0])) != 0;      // wave-uniform
+            const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
+            int spins = 0;
+            for (;;) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)         // the immediate offset field is 13-bit signed: one base per 4 k-blocks
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
+                for (int kb = 0; kb < KB; ++kb)     // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));     // uses stay behind the wait
+                bool fresh;
+                if (tag1) {                                              // all stamps must be set
+                    unsigned m = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int kb = 0; kb < KB - 1; ++kb) m &= st[kb][0] & st[kb][1] & st[kb][2] & st[kb][3];
+                    const unsigned l = st[KB - 1][0] & st[KB - 1][1] & st[KB - 1][2] & st[KB - 1][3];
+                    m &= chk_last ? l : 0xFFFFFFFFu;
+                    fresh = (m & 0x40004000u) == 0x40004000u;
+                } else {                                                 // all stamps must be clear
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int kb = 0; kb < KB - 1; ++kb) m |= st[kb][0] | st[kb][1] | st[kb][2] | st[kb][3];
+                    const unsigned l = st[KB - 1][0] | st[KB - 1][1] | st[KB - 1][2] | st[KB - 1][3];
+                    m |= chk_last ? l : 0u;
+                    fresh = (m & 0x40004000u) == 0u;
+                }
+                // rows that are inactive at this step (or beyond B) may hold anything: their results are discarded
+                if (__all(fresh || !active) || (p.ablate & 8)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
+                if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            if (tag1) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) st[kb] &= 0xBFFFBFFFu;   // strip the stamps before the MFMAs
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));             // uses stay behind the wait
         PSTAMP(2);
 
         f32x4 acc[2][4];
@@ -552,19 +583,15 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         }
         unsigned long long hb = 0ull;
         if (active) hb = (unsigned long long)f2bf(hv[0]) | ((unsigned long long)f2bf(hv[1]) << 16) | ((unsigned long long)f2bf(hv[2]) << 32) | ((unsigned long long)f2bf(hv[3]) << 48);
-        if (own && active && s + 1 < S) {
+        if (own && s + 1 < S) {
             // write-through store into the exchange buffer: unit u0 sits in k-block ut/2, k-group (ut&1)*2 + fq/2,
-            // half (fq&1) of the 16-B lane slot; the consumers of the next step load it with sc1
-            unsigned long long* hp = (unsigned long long*)(pa.hx + ((((size_t)(s & 1) * p.ndir + dir) * (RB * 4) + rt) * KB + (ut >> 1)) * 512
-                                                           + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4);
-            if (p.ablate & 4) *hp = hb; else __hip_atomic_store(hp, hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // half (fq&1) of the 16-B lane slot.  EVERY owned slot is rewritten EVERY step (padded positions: zeros),
+            // so all stamps of a buffer move together.
+            unsigned long long* hp = (unsigned long long*)(pa.hx + (s & 1) * hx_buf + hx_slot);
+            const unsigned long long stamp = ((((s >> 1) & 1) ^ (s & 1 ? base[1] : base[0])) != 0) ? 0x4000400040004000ull : 0ull;
+            __hip_atomic_store(hp, hb | stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PSTAMP(4);
-        // ---- publish: drain this wave's stores, then raise this wave's flag ----
-        if (s + 1 < S) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0 && !(p.ablate & 64)) __hip_atomic_store(flags + ut * 4 + wave, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         PSTAMP(5);
         // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
         if (own) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
@@ -1024,8 +1051,8 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
 
 extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop,
                                            float* Cs, float* Gs, const int32_t* lens, const float* c0, void* hx,
-                                           uint32_t* counters, int32_t* err, int num_cus, void* stream) {
-    E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens && hx && counters && err);
+                                           int32_t* err, int num_cus, void* stream) {
+    E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens && hx && err);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && d->ldy % 8 == 0 && d->ldy >= d->ndir * ((d->H + 7) / 8) * 8);
     LstmPersistArgs pa{};
@@ -1036,18 +1063,17 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    pa.hx = (bf16_t*)hx; pa.counters = counters; pa.err = err;
+    pa.hx = (bf16_t*)hx; pa.err = err;
     { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     { const char* e = getenv("E2T_LSTM_ABLATE"); p.ablate = e ? atoi(e) : 0; }      // diagnostics only
     const int ncl = ((d->B + 63) / 64) * d->ndir;
     const int nwg = ncl * p.UT;
     // every workgroup must be resident at once (1 per CU), and the W_h fragments of a unit tile must fit the
     // wave's registers (13 k-blocks x 4 gates x 4 registers)
-    if (p.KB > 13 || d->H % 4 != 0 || nwg > num_cus) {
+    if (p.KB > 13 || d->H % 8 != 0 || nwg > num_cus) {
         e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
         return E2T_ERR_ARG;
     }
-    hipLaunchKernelGGL(k_zero_u32, dim3((ncl * E2T_PERSIST_FLAG_STRIDE + 255) / 256), dim3(256), 0, (hipStream_t)stream, counters, ncl * E2T_PERSIST_FLAG_STRIDE);
 #define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist<K>, dim3(nwg), dim3(256), 4 * 2 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
     switch (p.KB) {
         E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)

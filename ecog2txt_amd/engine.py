@@ -395,7 +395,7 @@ class _Lstm:
         """One workgroup per CU for the whole layer, and the W_h fragments of a unit tile fit a wave's registers
         (mirrors the check in e2t_lstm_seq_fwd_persistent)."""
         nwg = ceil_div(B, 64) * self.ndir * self.UT
-        return nwg <= num_cus and self.KB <= 13 and self.H % 4 == 0
+        return nwg <= num_cus and self.KB <= 13 and self.H % 8 == 0
 
     def persistent_bwd_ok(self, B, num_cus):
         """Mirrors the check in e2t_lstm_seq_bwd_persistent (16-utterance x 64-unit workgroups, one per CU)."""
@@ -445,7 +445,7 @@ class _Lstm:
             d = self.desc(ws, train)
             lib.e2t_lstm_seq_fwd_persistent(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
                                             ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
-                                            c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(), ws['counters'].data_ptr(),
+                                            c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(),
                                             e.sync_err.data_ptr(), e.num_cus, e.stream)
             return
 

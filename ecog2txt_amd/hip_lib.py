@@ -60,7 +60,7 @@ SIGNATURES = {
     'e2t_pack_frag': [_p, _l, _l, _i, _i, _p, _p],
     'e2t_pack_batch': [_p, _i, _i, _p, _p],
     'e2t_lstm_seq_fwd': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    'e2t_lstm_seq_fwd_persistent': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    'e2t_lstm_seq_fwd_persistent': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_lstm_seq_bwd': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'e2t_lstm_seq_bwd_persistent': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_final_state': [_p, _i, _p, _p, _i, _i, _p, _i, _p, _p],

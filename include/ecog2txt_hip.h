@@ -124,14 +124,14 @@ typedef struct e2t_lstm_desc {
 int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
                      float* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
 /* Same result (bit for bit) as e2t_lstm_seq_fwd over steps [0,S) in ONE persistent launch: W_h stays in registers,
- * h is exchanged between CUs inside the launch (bounded spins).  Applicable when the layer's workgroups
- * (ceil(H/16) * ceil(B/64) * ndir) fit the CUs one-to-one, H % 4 == 0 and H <= 416; returns non-zero otherwise (use
- * e2t_lstm_seq_fwd).  hx: bf16 exchange scratch [2][ndir][4*ceil(B/64)][ceil(roundup(H,8)/32)][64][8], zero-filled once
- * by the caller (pad lanes must stay finite); counters: uint32 [ceil(B/64)*ndir*128] scratch (per-wave step flags); err: int32 [1], set to 1 if
- * a wait timed out (results then invalid). */
+ * h is exchanged between CUs inside the launch (stamped values, bounded retries).  Applicable when the layer's workgroups
+ * (ceil(H/16) * ceil(B/64) * ndir) fit the CUs one-to-one, H % 8 == 0 and H <= 416; returns non-zero otherwise (use
+ * e2t_lstm_seq_fwd).  hx: bf16 exchange scratch [2][ndir][4*ceil(B/64)][ceil(H/32)][64][8], zero-filled once by the
+ * caller and afterwards only touched by this entry point with the same S, B, H (zero it again after an error);
+ * err: int32 [1], set to 1 if a wait timed out (results then invalid). */
 int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
-                                float* Gs, const int32_t* lens, const float* c0, void* hx, uint32_t* counters,
-                                int32_t* err, int num_cus, void* stream);
+                                float* Gs, const int32_t* lens, const float* c0, void* hx, int32_t* err, int num_cus,
+                                void* stream);
 /* BPTT over all S steps (+ pseudo-step -1 when dh0/dc0 are given).  dG bf16 [(S+1)*B][lddg] out
  * (block S is all-zero slack that no kernel writes). */
 int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,

@@ -40,7 +40,7 @@ def bwd():
 cnt = torch.zeros(4096, dtype=torch.int32, device='cuda'); err = torch.zeros(1, dtype=torch.int32, device='cuda')
 def fwd_p():
     lib.e2t_lstm_seq_fwd_persistent(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(), lw['Ydrop'].data_ptr(),
-                                    lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, lw['hx'].data_ptr(), cnt.data_ptr(),
+                                    lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, lw['hx'].data_ptr(),
                                     err.data_ptr(), eng.num_cus, eng.stream)
 if lay.persistent_ok(B, eng.num_cus):
     for ab in [int(x) for x in os.environ.get('PABLATIONS', '0').split(',')]:
