@@ -513,6 +513,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
             int spins = 0;
             for (;;) {
+                // NOTHING may sit between the issue and the wait, and the loads stay inline (not in a lambda): a copy of a
+                // load destination taken while the load is in flight is garbage -- hipcc makes such copies when it parks
+                // registers in AGPRs or gives a by-reference capture a home (seen: stale stamps, timeout).  Moving the
+                // Philox mask in front of the MFMAs was measured too: +0.2 us on the MFMA phase, more retries, slower.
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)     // the immediate offset field is 13-bit signed: one base per 4 k-blocks
                     asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
@@ -625,8 +629,6 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
     if (p.dbg && lane == 0) p.dbg[(size_t)(gridDim.x * 4) * 8 + (size_t)blockIdx.x * 4 + wave] = wall_clock64() - t_entry;
 #undef PSTAMP
 }
-
-__global__ void k_zero_u32(unsigned* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0; }
 
 struct LstmBwdArgs {
     const bf16_t* WhB;      // [ndir][UT][KB4][64][8]  fragment-packed W_h^T operand (K = 4H gate columns)
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
 struct LstmBwdPersistArgs {
     LstmBwdArgs a;
     bf16_t* dgx;            // [2 step parities][ndir][RT][4*KQ][64 lanes][8]  dG exchange, MFMA operand order; zero-filled once
-    unsigned* flags;        // [clusters = RT*ndir][E2T_PERSIST_BWD_FLAG_STRIDE] per-producer-wave step counts, zeroed per launch
+    unsigned* flags;        // [clusters = RT*ndir][E2T_PERSIST_BWD_FLAG_STRIDE] per-producer-wave published-step counts (never reset), then [1] launch count
     int* err;
 };
 #define E2T_PERSIST_BWD_FLAG_STRIDE 32      // >= 4 waves x 7 unit groups (H <= 416)
@@ -837,6 +839,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     uint4* pre = lstm_smem + (size_t)wave * (2 * E2T_BWD_PRE16);              // wave-private prefetch double buffer
     float4* part = (float4*)(lstm_smem + 4 * 2 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
     unsigned* flags = pa.flags + (size_t)cl * E2T_PERSIST_BWD_FLAG_STRIDE;
+    // flag words only ever grow: they count published steps over ALL launches (launch number x S + steps), so there is no
+    // reset pass; the launch number lives behind the flag words and is bumped by one wave when it is done
+    unsigned* epoch = pa.flags + (size_t)ncl * E2T_PERSIST_BWD_FLAG_STRIDE;
+    const unsigned fbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (unsigned)S;
 
     // operands of step s that do not depend on the recurrence, by LDS-DMA into buffer s&1 (full exec, clamped addresses)
     const unsigned pre_lds = lds_addr_of(lstm_smem) + (unsigned)wave * (2 * E2T_BWD_PRE16 * 16);    // LDS byte address (integer math:
@@ -925,10 +931,11 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             int spins = 0;
             for (;;) {
                 bool ok = true;
-                for (int i = lane; i < nfl; i += 64) ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)k);
+                for (int i = lane; i < nfl; i += 64)
+                    ok = ok && ((int)(__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fbase + (unsigned)k)) >= 0);
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
-                ++spins;
+                ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
                 if ((spins & 1023) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                 if (spins > (1 << 18)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
@@ -990,7 +997,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             PSTAMP(4);
             // ---- publish: drain this wave's stores (and the prefetch DMA), then raise this wave's flag ----
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(flags + ug * 4 + wave, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(flags + ug * 4 + wave, fbase + (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PSTAMP(5);
         // ---- off the critical path: row-major dG for the weight-gradient GEMMs, factors of the next step ----
@@ -999,11 +1006,13 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             uint4* gp = (uint4*)(p.dG + ((size_t)(active ? t : s) * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4);
             gp[0] = og0; gp[1] = og1;
         }
-        if (s > 0) precompute(s - 1);
+        if (s > 0) precompute(s - 1);        // (a first look at the next step's flags from here was measured: slower,
+                                             //  hipcc waits for the loads at once when registers are this tight)
         PSTAMP(6);
         if (p.dbg && s == S / 2 && lane == 0)
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef PSTAMP
 }
 
@@ -1143,7 +1152,6 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
         return E2T_ERR_ARG;
     }
     const size_t lds = (size_t)(4 * 2 * E2T_BWD_PRE16 + 16 * 64) * 16;
-    hipLaunchKernelGGL(k_zero_u32, dim3((ncl * E2T_PERSIST_BWD_FLAG_STRIDE + 255) / 256), dim3(256), 0, (hipStream_t)stream, flags, ncl * E2T_PERSIST_BWD_FLAG_STRIDE);
 #define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_bwd_persist<K>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
     switch (KQ) {
         E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)

@@ -419,7 +419,7 @@ class _Lstm:
         ws['xT'] = _bf(self.D + 1, Mk, device=dev)
         ws['xT'][self.D, :M] = 1.0
         ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
-        ws['counters'] = torch.zeros(max(ceil_div(B, 64) * 128, ceil_div(B, 16) * 32) * nd, dtype=torch.int32, device=dev)
+        ws['counters'] = torch.zeros(ceil_div(B, 16) * 32 * nd + 1, dtype=torch.int32, device=dev)   # persistent BPTT: step flags + launch count
         ws['dgx'] = _bf(2, nd, ceil_div(B, 16), 4 * ceil_div(self.KB4, 4), 64, 8, device=dev)   # in-launch dG exchange (persistent BPTT)
         ws['hx'] = _bf(2, nd, 4 * ceil_div(B, 64), self.KB, 64, 8, device=dev)     # in-launch h exchange (persistent recurrence)
         return ws

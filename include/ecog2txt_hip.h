@@ -141,7 +141,8 @@ int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg
  * ONE persistent launch; no pseudo-step -1 (dh0/dc0), so for layers whose initial state is not trained.  Applicable when
  * ceil(B/16) * ndir * ceil(ceil(H/16)/4) workgroups fit the CUs one-to-one, H % 4 == 0 and H <= 416; returns non-zero
  * otherwise.  dgx: bf16 exchange scratch [2][ndir][ceil(B/16)][4*ceil(ceil(4H/32)/4)][64][8], zero-filled once by the
- * caller; flags: uint32 [ceil(B/16)*ndir*32] scratch; err as for the forward. */
+ * caller; flags: uint32 [ceil(B/16)*ndir*32 + 1], zero-filled once by the caller and afterwards only touched by this entry
+ * point with the same S (zero it again after an error); err as for the forward. */
 int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
                                 const float* Gs, const float* Cs, const int32_t* lens, const float* c0,
                                 const float* dh_final, const float* dc_final, void* dgx, uint32_t* flags, int32_t* err,
