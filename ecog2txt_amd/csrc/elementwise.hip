@@ -232,7 +232,9 @@ __global__ __launch_bounds__(64) void k_pack_frag(const float* src, long sn, lon
 
 // All operand images in ONE launch: a device table of descriptors, each owning a contiguous range of
 // 256-thread workgroups (prefix in `first_block`).  kind 0 = strided cast (one row x 256 columns per
-// workgroup), kind 1 = MFMA fragment image (4 fragments per workgroup).
+// workgroup; for sources that are contiguous along the destination's columns), kind 1 = MFMA fragment image
+// (4 fragments per workgroup), kind 2 = transposing cast (source contiguous along the destination's ROWS, s0 == 1):
+// 64x64 tiles through LDS so that both the fp32 reads and the bf16 writes are coalesced.
 __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, int ndesc, const float* base) {
     // binary search for the descriptor that owns this workgroup (uniform)
     int lo = 0, hi = ndesc - 1;
@@ -242,7 +244,23 @@ __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, 
     const int lb = bid - d.first_block;
     const float* src = base + d.src_off;
     bf16_t* dst = (bf16_t*)d.dst;
-    if (d.kind == 0) {
+    if (d.kind == 2) {
+        __shared__ float tile[64][65];
+        const int tcn = (d.d1 + 63) / 64;
+        const int tr = lb / tcn, tc = lb - tr * tcn;
+        const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = tc * 64 + q * 16 + i, r = tr * 64 + l;
+            tile[q * 16 + i][l] = (r < d.d0 && c < d.d1) ? src[(size_t)r * d.s0 + (size_t)c * d.s1] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = tr * 64 + q * 16 + i, c = tc * 64 + l;
+            if (r < d.d0 && c < d.d1) dst[(size_t)r * d.ld + c] = f2bf(tile[l][q * 16 + i]);
+        }
+    } else if (d.kind == 0) {
         const int cb = (d.d1 + 255) / 256;                 // column blocks per row
         const int r = lb / cb, c = (lb - r * cb) * 256 + threadIdx.x;
         if (r < d.d0 && c < d.d1) dst[(size_t)r * d.ld + c] = f2bf(src[(size_t)r * d.s0 + (size_t)c * d.s1]);

@@ -688,9 +688,10 @@ class Seq2SeqEngine:
                 if op[0] == 'cast':
                     _, sp, rs, cs, R, Cn, dst, k0, r0 = op
                     ld = dst.shape[-1]
-                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = 0, (sp - p0) // 4, rs, cs, R, Cn, ld
+                    tr = rs == 1 and cs != 1                 # source contiguous along the image's rows: tiled transpose
+                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = (2 if tr else 0), (sp - p0) // 4, rs, cs, R, Cn, ld
                     d.dst = dst.data_ptr() + 2 * (r0 * ld + k0)
-                    nblk += R * ceil_div(Cn, 256)
+                    nblk += ceil_div(R, 64) * ceil_div(Cn, 64) if tr else R * ceil_div(Cn, 256)
                 else:
                     _, sp, ns, ks, Nn, Kk, dst = op
                     KB = ceil_div(Kk, 32)

@@ -98,7 +98,9 @@ int e2t_pack_frag(const float* src, long n_stride, long k_stride, int Nn, int Kk
 /* every image in one launch: device table of descriptors (src = base + src_off) */
 typedef struct e2t_pack_desc {
     int kind;            /* 0: dst[r][c] = bf16(src[r*s0 + c*s1]), r < d0, c < d1, leading dim ld
-                            1: MFMA fragment image of Bn[n][k] = src[n*s0 + k*s1], n < d0, k < d1, ld = ceil(d1/32) */
+                            1: MFMA fragment image of Bn[n][k] = src[n*s0 + k*s1], n < d0, k < d1, ld = ceil(d1/32)
+                            2: as 0 for sources with s0 == 1 (contiguous along r): 64x64 tiles through LDS,
+                               ceil(d0/64)*ceil(d1/64) workgroups instead of d0*ceil(d1/256) */
     int first_block;     /* first 256-thread workgroup of this descriptor (exclusive prefix, ascending) */
     long long src_off;   /* element offset into the fp32 base */
     long long s0, s1;
