@@ -233,7 +233,7 @@ struct LstmFwdArgs {
     float* Gs;              // lane-native, see above
     const int* lens;        // [B]
     const float* c0;        // [B][ndir*H] or null
-    int S, B, H, H8, ndir, ldy, UT, KB, step, ablate, rb_begin, rb_count;
+    int S, B, H, H8, ndir, ldy, UT, KB, step, rb_begin, rb_count;
     float forget_bias;
     DropCfg drop;
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
@@ -292,10 +292,8 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     // ---- round trip 1 (bulk, everything in flight together, issued by all 8 waves) -------------
     const uint4* wsrc = (const uint4*)p.WhF + ((size_t)(dir * 4) * p.UT + ut) * KB * 64;
     const size_t wgs = (size_t)p.UT * KB * 64;
-    if (!(p.ablate & 1)) {
-        issue_chunk<4>(wsrc, wgs, KB, srow, 0, lstm_smem, G, wave, lane);
-        if (G.nch > 1) issue_chunk<4>(wsrc, wgs, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
-    }
+    issue_chunk<4>(wsrc, wgs, KB, srow, 0, lstm_smem, G, wave, lane);
+    if (G.nch > 1) issue_chunk<4>(wsrc, wgs, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
     // Gx of the fetched rows: 8 rows x 256 B = two 8-row x 128-B instructions (unit halves)
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
@@ -323,10 +321,8 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
         STAMP(3);
         __syncthreads();
         STAMP(4);
-        if (!(p.ablate & 4)) {
-            for (int cc = c; cc < min(c + 2, G.nch); ++cc)
-                mma_chunk<4, 4>(acc, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
-        }
+        for (int cc = c; cc < min(c + 2, G.nch); ++cc)
+            mma_chunk<4, 4>(acc, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
         if (c + 2 < G.nch) {
             __syncthreads();                         // everyone is done reading both buffers
             issue_chunk<4>(wsrc, wgs, KB, srow, c + 2, lstm_smem, G, wave, lane);
@@ -462,8 +458,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
     uint4* gxl = lstm_smem + (size_t)wave * (2 * 4 * 64);
     auto gx_load = [&](int s) {
         const bool act = own && s < len;
-        int tt = act ? (dir ? (len - 1 - s) : s) : 0;
-        if (p.ablate & 32) tt &= 1;
+        const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
         const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s & 1) * 4 + r) * 64));
@@ -540,7 +535,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                     fresh = (m & 0x40004000u) == 0u;
                 }
                 // rows that are inactive at this step (or beyond B) may hold anything: their results are discarded
-                if (__all(fresh || !active) || (p.ablate & 8)) break;
+                if (__all(fresh || !active)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
                 if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -599,14 +594,13 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         PSTAMP(5);
         // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
         if (own) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
-            size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
-            if (p.ablate & 32) blk = 1 + (blk & 1);
+            const size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
             *(unsigned long long*)(p.Yext + (blk * B + b) * p.ldy + dir * p.H8 + u0) = hb;
         }
-        if (own && !(p.ablate & 1)) {
+        if (own) {
             if (active) {
-                const size_t m = (size_t)((p.ablate & 32) ? (t & 1) : t) * B + b;
-                const size_t tile = native_tile((p.ablate & 32) ? (s & 1) : s, dir, rt, ut, p.ndir, RT, p.UT);
+                const size_t m = (size_t)t * B + b;
+                const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi[r], gj[r], gf[r], go[r]);
                 ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
@@ -620,7 +614,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                 *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
             }
         }
-        if (s + 1 < S && !(p.ablate & 2)) gx_load(s + 1);
+        if (s + 1 < S) gx_load(s + 1);
         PSTAMP(6);
         if (p.dbg && s == S / 2 && lane == 0)
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
@@ -1039,7 +1033,6 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
-    { const char* e = getenv("E2T_LSTM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
     { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
@@ -1074,7 +1067,6 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     pa.hx = (bf16_t*)hx; pa.err = err;
     { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
-    { const char* e = getenv("E2T_LSTM_ABLATE"); p.ablate = e ? atoi(e) : 0; }      // diagnostics only
     const int ncl = ((d->B + 63) / 64) * d->ndir;
     const int nwg = ncl * p.UT;
     // every workgroup must be resident at once (1 per CU), and the W_h fragments of a unit tile must fit the

@@ -43,18 +43,13 @@ def fwd_p():
                                     lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, lw['hx'].data_ptr(),
                                     err.data_ptr(), eng.num_cus, eng.stream)
 if lay.persistent_ok(B, eng.num_cus):
-    for ab in [int(x) for x in os.environ.get('PABLATIONS', '0').split(',')]:
-        os.environ['E2T_LSTM_ABLATE'] = str(ab)
-        print('persistent fwd (ablate %d): %.2f us/step (S=%d), err=%d' % (ab, timeit(fwd_p, S), S, int(err.item())), flush=True)
-    os.environ['E2T_LSTM_ABLATE'] = '0'
+    print('persistent fwd: %.2f us/step (S=%d), err=%d' % (timeit(fwd_p, S), S, int(err.item())), flush=True)
     if os.environ.get('TIMELINE'):
         import numpy as np
         dbg = torch.zeros(256 * 8 * 8 + 2048, dtype=torch.int64, device='cuda')
         os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
-        os.environ['E2T_LSTM_ABLATE'] = os.environ.get('TL_ABLATE', '0')
         fwd_p(); torch.cuda.synchronize()
-        os.environ['E2T_LSTM_ABLATE'] = '0'
-        del os.environ['E2T_LSTM_DBG']
+            del os.environ['E2T_LSTM_DBG']
         raw = dbg.cpu().numpy()
         nw = 4 * ceil_div(B, 64) * lay.ndir * lay.UT
         tot = raw[nw * 8: nw * 8 + nw] / 100.0
@@ -63,7 +58,7 @@ if lay.persistent_ok(B, eng.num_cus):
         t = raw[:nw * 8].reshape(-1, 8)[:, :7]
         t = t[t[:, 0] > 0]
         rel = (t - t[:, :1]) / 100.0
-        names = ['step top', 'poll done', 'state landed', 'mma done', 'h stored', 'published', 'side work issued']
+        names = ['step top', '(unused)', 'state landed (incl. retries)', 'mma done', 'h stored', '(unused)', 'side work issued']
         print('  persistent step %d, %d waves; time since step top (us):' % (S // 2, len(t)))
         for i, nme in enumerate(names):
             print('    %-20s min %.2f  median %.2f  max %.2f' % (nme, rel[:, i].min(), np.median(rel[:, i]), rel[:, i].max()))
@@ -89,14 +84,11 @@ if lay.persistent_bwd_ok(B, eng.num_cus):
         names = ['step top', 'poll done', 'state landed', 'mma+reduce done', 'dG exchange stored', 'published', 'side work done']
         dd = np.diff(rel, axis=1)
         print('  persistent bwd step %d, %d waves; phase durations (us): ' % (S // 2, len(t)) + ' | '.join('%s: min %.1f med %.1f p90 %.1f max %.1f' % (names[i + 1], dd[:, i].min(), np.median(dd[:, i]), np.percentile(dd[:, i], 90), dd[:, i].max()) for i in range(6)))
-for ab in [int(x) for x in os.environ.get('ABLATIONS', '0').split(',')]:
-    os.environ['E2T_LSTM_ABLATE'] = str(ab)
-    print('ablate %3d: fwd %.2f us/step   bwd %.2f us/step' % (ab, timeit(fwd, S), timeit(bwd, S)), flush=True)
+print('launch per step: fwd %.2f us/step   bwd %.2f us/step' % (timeit(fwd, S), timeit(bwd, S)), flush=True)
 # ---- per-phase timeline of ONE step (s_memtime stamps written by the kernel) ----
 if os.environ.get('TIMELINE'):
     import numpy as np
     dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device='cuda')
-    os.environ['E2T_LSTM_ABLATE'] = '0'
     os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
     lib.e2t_lstm_seq_fwd(C.byref(d), lw['Gx'].data_ptr(), lay.WhF.data_ptr(), lw['Yext'].data_ptr(), lw['Ydrop'].data_ptr(),
                          lw['Cs'].data_ptr(), lw['Gs'].data_ptr(), ws['lens_d'].data_ptr(), None, 5, 6, eng.stream)

@@ -11,8 +11,8 @@ for r in rows[:14]:
 tr = list(csv.DictReader(open('%s/%s_kernel_trace.csv' % (d, pref))))
 g = collections.defaultdict(list)
 for r in tr:
-    if r['Kernel_Name'].startswith('k_gemm_nt'):
-        g[(int(r['Grid_Size_X']) // 256, int(r['Grid_Size_Y']))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    if 'k_gemm_nt' in r['Kernel_Name']:
+        g[(int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), int(r['Grid_Size_Y']))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 print('GEMM by (tiles, splits):')
 for k in sorted(g):
     v = g[k]
