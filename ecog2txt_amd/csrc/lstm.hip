@@ -29,6 +29,7 @@
 #include "common.h"
 #include "ecog2txt_hip.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -624,6 +625,222 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
 #undef PSTAMP
 }
 
+// ---------------------------------------------------------------------------
+// Persistent forward recurrence, WIDE layers (14 <= KB <= 26 k-blocks, i.e. 417 <= H <= 832: the decoder).
+// The W_h slice of a 64-utterance x 16-unit workgroup no longer fits a wave's registers, so the tiling is
+//   workgroup = 32 utterances (2 row tiles) x 32 units (2 unit tiles) x direction, 4 waves at one wave per SIMD;
+//   wave w = (unit tile w&1, K half w>>1): it keeps the W_h fragments of its unit tile, all four gates, for its
+//   half of the k-blocks (4 x KH x 4 registers), multiplies BOTH row tiles with them, hands the partial sums of the
+//   row tile it does not finish to the wave with the other K half (through LDS, one barrier) and finishes the
+//   cells of (row tile rb*2 + (w>>1), its unit tile): same lane <-> cell map and saves as the other kernels.
+// The k-blocks of a K half are the ones k_lstm_step_fwd gives that half, in its order (the host passes the two
+// lists: they follow from its chunked LDS geometry), so the result is bit-identical to the launch-per-step kernel.
+// Exchange, stamps, prefetch and bounded retries exactly as in k_lstm_seq_fwd_persist.
+// ---------------------------------------------------------------------------
+struct LstmPersistWideArgs {
+    LstmFwdArgs a;
+    bf16_t* hx;                     // [2][ndir][>= 2*ceil(B/32)][KB][64][8]
+    int* err;
+    unsigned char kbl[2][16];       // k-blocks of K half h in accumulation order
+    unsigned char nkb[2];
+};
+
+template <int KH>
+__global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWideArgs pa) {
+    const LstmFwdArgs& p = pa.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int B = p.B, H = p.H, S = p.S, KB = p.KB;
+    const int RB = (B + 31) >> 5, RT = (B + 15) >> 4, UG = (p.UT + 1) >> 1, RTP = 2 * RB;
+    const int ncl = RB * p.ndir;
+    const int cl = blockIdx.x % ncl, ug = blockIdx.x / ncl;      // cluster-major ids: cluster c sits on XCD c % 8
+    if (ug >= UG) return;
+    const int rb = cl % RB, dir = cl / RB;
+    const int khalf = wave >> 1;
+    const int ut = ug * 2 + (wave & 1);
+    const bool tile_ok = ut < p.UT;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int NH = p.ndir * H;
+    const int rt = rb * 2 + khalf;                                // row tile whose cells this wave finishes
+    const int b = rt * 16 + frow;
+    const int bc = min(b, B - 1);
+    const int len = (b < B) ? p.lens[b] : 0;
+    int len2[2];                                                  // lengths of the rows whose state this lane loads
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) { const int rr = (rb * 2 + r2) * 16 + frow; len2[r2] = (rr < B) ? p.lens[rr] : 0; }
+    const int u0 = ut * 16 + fq * 4;
+    const bool own = (b < B) && tile_ok && (u0 < H);
+    const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
+    const int nk = pa.nkb[khalf];
+
+    // ---- once: W_h fragments of (dir, ut), this wave's K half ----
+    bf16x8 W[KH][4];
+    int kbj[KH];
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+        kbj[j] = (j < nk) ? pa.kbl[khalf][j] : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (j < nk && tile_ok) v = ((const uint4*)p.WhF)[(((size_t)(dir * 4 + g) * p.UT + ut) * KB + kbj[j]) * 64 + lane];
+            W[j][g] = *(bf16x8*)&v;
+        }
+    }
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    if (own && len > 0 && p.c0) { const float4 c = *(const float4*)(p.c0 + (size_t)b * NH + dir * H + u0); cst[0] = c.x; cst[1] = c.y; cst[2] = c.z; cst[3] = c.w; }
+    uint4* gxl = lstm_smem + (size_t)wave * (2 * 4 * 64);
+    float4* xbuf = (float4*)(lstm_smem + 4 * 2 * 4 * 64);         // [wave][gate][lane]
+    auto gx_load = [&](int s) {
+        const bool act = own && s < len;
+        const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
+        const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (own ? u0 : 0)) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s & 1) * 4 + r) * 64));
+    };
+    gx_load(0);
+    const size_t hx_slot = ((((size_t)dir) * RTP + rt) * KB + (ut >> 1)) * 512 + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4;
+    const size_t hx_buf = (size_t)p.ndir * RTP * KB * 512;       // elements per step-parity buffer
+    unsigned base[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        unsigned long long v = 0ull;
+        if (own) v = __hip_atomic_load((const unsigned long long*)(pa.hx + q * hx_buf + hx_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base[q] = (__builtin_amdgcn_readfirstlane((unsigned)(v >> 14)) & 1u) ^ 1u;
+    }
+
+    for (int s = 0; s < S; ++s) {
+        const bool active = s < len;
+        const int t = dir ? (len - 1 - s) : s;
+        u32x4 st[2][KH];
+        if (s == 0) {
+            // initial state from the row-major array (block 0; the backward direction of a bidirectional layer: slack)
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const int rr = min((rb * 2 + r2) * 16 + frow, B - 1);
+                size_t tau = 0, srb = rr;
+                if (0 < len2[r2] && dir == 1) { tau = (size_t)S + 1; srb = 0; }
+                const bf16_t* src = p.Yext + (tau * B + srb) * p.ldy + dir * p.H8 + fq * 8;
+#pragma unroll
+                for (int j = 0; j < KH; ++j)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st[r2][j]) : "v"(src + kbj[j] * 32) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                for (int j = 0; j < KH; ++j) asm volatile("" : "+v"(st[r2][j]));
+        } else {
+            const bf16_t* src = pa.hx + ((s - 1) & 1) * hx_buf + ((((size_t)dir) * RTP + rb * 2) * KB * 64 + lane) * 8;
+            const bool tag1 = ((((s - 1) >> 1) & 1) ^ ((s - 1) & 1 ? base[1] : base[0])) != 0;      // wave-uniform
+            int spins = 0;
+            for (;;) {
+                // (nothing between the issue and the wait: see k_lstm_seq_fwd_persist)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int j = 0; j < KH; ++j)
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(st[r2][j]) : "v"(src + ((size_t)r2 * KB + kbj[j]) * 512) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int j = 0; j < KH; ++j) asm volatile("" : "+v"(st[r2][j]));
+                bool fresh = true;
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    unsigned ma = 0xFFFFFFFFu, mo = 0u;
+#pragma unroll
+                    for (int j = 0; j < KH; ++j) {
+                        // k-blocks beyond this half's list and the padding k-groups of the last block are never written
+                        const bool chk = (j < nk) && (kbj[j] * 32 + fq * 8 < H);
+                        const unsigned a = st[r2][j][0] & st[r2][j][1] & st[r2][j][2] & st[r2][j][3];
+                        const unsigned o = st[r2][j][0] | st[r2][j][1] | st[r2][j][2] | st[r2][j][3];
+                        ma &= chk ? a : 0xFFFFFFFFu; mo |= chk ? o : 0u;
+                    }
+                    const bool f = tag1 ? ((ma & 0x40004000u) == 0x40004000u) : ((mo & 0x40004000u) == 0u);
+                    fresh = fresh && (f || !(s < len2[r2]));          // rows inactive at this step may hold anything
+                }
+                if (__all(fresh)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
+                if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            if (tag1) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int j = 0; j < KH; ++j) st[r2][j] &= 0xBFFFBFFFu;   // strip the stamps before the MFMAs
+            }
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[r2][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KH; ++j)
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[r2][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[j][g], *(bf16x8*)&st[r2][j], acc[r2][g], 0, 0, 0);
+        // ---- the other K half of "my" row tile comes from wave ^ 2; mine of the other row tile goes there ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = khalf ? acc[0][g] : acc[1][g];
+            xbuf[(wave * 4 + g) * 64 + lane] = make_float4(a[0], a[1], a[2], a[3]);
+        }
+        __syncthreads();
+        float z[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 o = xbuf[((wave ^ 2) * 4 + g) * 64 + lane];
+            const f32x4 a = khalf ? acc[1][g] : acc[0][g];
+            z[g][0] = a[0] + o.x; z[g][1] = a[1] + o.y; z[g][2] = a[2] + o.z; z[g][3] = a[3] + o.w;
+        }
+        // ---- lane-local cell update for (utterance b, units u0..u0+3) ----
+        float gi[4], gj[4], gf[4], go[4], hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint4 graw = gxl[((s & 1) * 4 + r) * 64 + lane];
+            gi[r] = fsigmoid(z[0][r] + __uint_as_float(graw.x));
+            gj[r] = ftanh(z[1][r] + __uint_as_float(graw.y));
+            gf[r] = fsigmoid(z[2][r] + __uint_as_float(graw.z) + p.forget_bias);
+            go[r] = fsigmoid(z[3][r] + __uint_as_float(graw.w));
+            const float cv = fmaf(gf[r], cst[r], gi[r] * gj[r]);
+            hv[r] = go[r] * ftanh(cv);
+            if (active) cst[r] = cv;
+        }
+        unsigned long long hb = 0ull;
+        if (active) hb = (unsigned long long)f2bf(hv[0]) | ((unsigned long long)f2bf(hv[1]) << 16) | ((unsigned long long)f2bf(hv[2]) << 32) | ((unsigned long long)f2bf(hv[3]) << 48);
+        if (own && s + 1 < S) {
+            const unsigned long long stamp = ((((s >> 1) & 1) ^ (s & 1 ? base[1] : base[0])) != 0) ? 0x4000400040004000ull : 0ull;
+            __hip_atomic_store((unsigned long long*)(pa.hx + (s & 1) * hx_buf + hx_slot), hb | stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
+        if (own) {
+            const size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
+            *(unsigned long long*)(p.Yext + (blk * B + b) * p.ldy + dir * p.H8 + u0) = hb;
+            if (active) {
+                const size_t m = (size_t)t * B + b;
+                const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi[r], gj[r], gf[r], go[r]);
+                ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
+                ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
+                if (p.Ydrop) {
+                    float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
+                    nt_store_bf4(p.Ydrop + m * p.ldy + dir * p.H8 + u0, f2bf(hv[0] * dsc4[0]), f2bf(hv[1] * dsc4[1]), f2bf(hv[2] * dsc4[2]), f2bf(hv[3] * dsc4[3]));
+                }
+            } else if (p.Ydrop) {
+                *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
+            }
+        }
+        if (s + 1 < S) gx_load(s + 1);
+    }
+}
+
 struct LstmBwdArgs {
     const bf16_t* WhB;      // [ndir][UT][KB4][64][8]  fragment-packed W_h^T operand (K = 4H gate columns)
     bf16_t* dG;             // [(S+1)*B][lddg]  (dir, unit, gate) interleaved, bf16, time-major rows; block S = zero slack
@@ -1067,6 +1284,31 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     pa.hx = (bf16_t*)hx; pa.err = err;
     { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    if (p.KB > 13 && p.KB <= 26 && d->H % 8 == 0) {
+        // wide layer: 32 x 32 workgroups, K halves in the accumulation order of k_lstm_step_fwd (its LDS chunk geometry)
+        LstmPersistWideArgs pw{};
+        pw.a = p; pw.hx = (bf16_t*)hx; pw.err = err;
+        const StepGeom G = step_geom(p.KB, 4, 4 * 256 + 1024);
+        int n[2] = {0, 0};
+        for (int c = 0; c < G.nch; ++c) {
+            const int kb0 = c * G.kch, kc = std::min(G.kch, p.KB - kb0), npr = kc >> 1;
+            for (int pp = 0; pp < npr; ++pp) { pw.kbl[pp & 1][n[pp & 1]++] = (unsigned char)(kb0 + 2 * pp); pw.kbl[pp & 1][n[pp & 1]++] = (unsigned char)(kb0 + 2 * pp + 1); }
+            if (kc & 1) pw.kbl[npr & 1][n[npr & 1]++] = (unsigned char)(kb0 + kc - 1);
+        }
+        pw.nkb[0] = (unsigned char)n[0]; pw.nkb[1] = (unsigned char)n[1];
+        const int KH = std::max(n[0], n[1]);
+        const int nwgw = ((d->B + 31) / 32) * d->ndir * ((p.UT + 1) / 2);
+        if (KH > 13 || nwgw > num_cus) {
+            e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwgw, num_cus);
+            return E2T_ERR_ARG;
+        }
+        const size_t ldsw = (size_t)(4 * 2 * 4 * 64 + 4 * 4 * 64) * 16;
+#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist_wide<K>, dim3(nwgw), dim3(256), ldsw, (hipStream_t)stream, pw); break;
+        switch (KH) { E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10) E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13) }
+#undef E2T_PERSIST_CASE
+        E2T_LAUNCH_CHECK();
+        return E2T_OK;
+    }
     const int ncl = ((d->B + 63) / 64) * d->ndir;
     const int nwg = ncl * p.UT;
     // every workgroup must be resident at once (1 per CU), and the W_h fragments of a unit tile must fit the

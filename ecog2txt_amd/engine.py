@@ -392,10 +392,13 @@ class _Lstm:
         return self.eng.store.ptr(self.name + '.Wx', src, self.D * self.N4)
 
     def persistent_ok(self, B, num_cus):
-        """One workgroup per CU for the whole layer, and the W_h fragments of a unit tile fit a wave's registers
-        (mirrors the check in e2t_lstm_seq_fwd_persistent)."""
-        nwg = ceil_div(B, 64) * self.ndir * self.UT
-        return nwg <= num_cus and self.KB <= 13 and self.H % 8 == 0
+        """One workgroup per CU for the whole layer and the W_h fragments fit the waves' registers (mirrors the checks
+        in e2t_lstm_seq_fwd_persistent): 64-utterance x 16-unit workgroups up to H = 416, 32 x 32 up to H = 832."""
+        if self.H % 8 != 0:
+            return False
+        if self.KB <= 13:
+            return ceil_div(B, 64) * self.ndir * self.UT <= num_cus
+        return self.KB <= 26 and ceil_div(B, 32) * self.ndir * ceil_div(self.UT, 2) <= num_cus
 
     def persistent_bwd_ok(self, B, num_cus):
         """Mirrors the check in e2t_lstm_seq_bwd_persistent (16-utterance x 64-unit workgroups, one per CU)."""

@@ -126,9 +126,9 @@ typedef struct e2t_lstm_desc {
 int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
                      float* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
 /* Same result (bit for bit) as e2t_lstm_seq_fwd over steps [0,S) in ONE persistent launch: W_h stays in registers,
- * h is exchanged between CUs inside the launch (stamped values, bounded retries).  Applicable when the layer's workgroups
- * (ceil(H/16) * ceil(B/64) * ndir) fit the CUs one-to-one, H % 8 == 0 and H <= 416; returns non-zero otherwise (use
- * e2t_lstm_seq_fwd).  hx: bf16 exchange scratch [2][ndir][4*ceil(B/64)][ceil(H/32)][64][8], zero-filled once by the
+ * h is exchanged between CUs inside the launch (stamped values, bounded retries).  Applicable when H % 8 == 0 and the
+ * layer's workgroups fit the CUs one-to-one: ceil(H/16) * ceil(B/64) * ndir of them for H <= 416, ceil(H/32) * ceil(B/32)
+ * * ndir for H <= 832; returns non-zero otherwise (use e2t_lstm_seq_fwd).  hx: bf16 exchange scratch [2][ndir][4*ceil(B/64)][ceil(H/32)][64][8], zero-filled once by the
  * caller and afterwards only touched by this entry point with the same S, B, H (zero it again after an error);
  * err: int32 [1], set to 1 if a wait timed out (results then invalid). */
 int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,

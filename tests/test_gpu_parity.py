@@ -164,6 +164,8 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
         eng, ws, ospec, P, batch = build(SPECS[name], B, T, L, seed=4, ragged=True)
         if flag != '0':
             assert all(lay.persistent_ok(B, eng.num_cus) for lay in eng.enc), 'case must exercise the persistent path'
+            if name == 'cfg2_widths':
+                assert eng.dec.persistent_ok(B, eng.num_cus), 'the decoder (H=800) must take the wide persistent kernel'
         if flag == '1':
             assert all(lay.persistent_bwd_ok(B, eng.num_cus) for lay in eng.enc)
         for _ in range(3):                       # repeated launches: flags / exchange buffers are reused
@@ -174,11 +176,13 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
         lw = ws['enc'][-1]
         outs[flag] = dict(Y=lw['Yext'].view(torch.int16).cpu().numpy(), Yd=lw['Ydrop'].view(torch.int16).cpu().numpy(),
                           Cs=lw['Cs'].cpu().numpy(), loss=eng.losses(ws), g=eng.store.g.cpu().numpy(),
+                          Ydec=ws['dec']['Yext'].view(torch.int16).cpu().numpy(),
                           emb=eng.store.seg_range('dec.emb'), dG=[w['dG'].float().cpu().numpy() for w in ws['enc']],
                           lens=ws['lens_d'].cpu().numpy())
     a, b, c = outs['0'], outs['fwd'], outs['1']
     np.testing.assert_array_equal(a['Y'], b['Y'])
     np.testing.assert_array_equal(a['Yd'], b['Yd'])
+    np.testing.assert_array_equal(a['Ydec'], b['Ydec'])
     assert a['loss'] == b['loss'] == c['loss']
     # saved cell states: compare where written (rows active at that processing step)
     S = a['Cs'].shape[0]
