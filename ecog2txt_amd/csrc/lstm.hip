@@ -1005,29 +1005,31 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
 struct LstmBwdPersistArgs {
     LstmBwdArgs a;
     bf16_t* dgx;            // [2 step parities][ndir][RT][4*KQ][64 lanes][8]  dG exchange, MFMA operand order; zero-filled once
-    unsigned* flags;        // [clusters = RT*ndir][E2T_PERSIST_BWD_FLAG_STRIDE] per-producer-wave published-step counts (never reset), then [1] launch count
+    unsigned* flags;        // [clusters][fstride] per-producer-wave published-step counts (never reset), then [1] launch count
     int* err;
+    int fstride;            // flag words per cluster (>= 4 waves x workgroups of a cluster)
 };
-#define E2T_PERSIST_BWD_FLAG_STRIDE 32      // >= 4 waves x 7 unit groups (H <= 416)
 #define E2T_BWD_PRE16 (6 * 64)              // 16-B units of one prefetch buffer: Gs 4 KiB, Cs 1 KiB, dY 1 KiB
 
-template <int KQ>
+template <int KQ, bool WIDE>
 __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs pa) {
     const LstmBwdArgs& p = pa.a;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int B = p.B, H = p.H, S = p.S, KB4 = p.KB4;
-    const int RT = (B + 15) >> 4, UG = (p.UT + 3) >> 2;
-    const int ncl = RT * p.ndir;
+    constexpr int RW = WIDE ? 2 : 1, UW = WIDE ? 2 : 4;         // row tiles x unit tiles of a workgroup (RW * UW = 4 waves)
+    const int RT = (B + 15) >> 4, RTG = (RT + RW - 1) / RW, RTD = RTG * RW, UG = (p.UT + UW - 1) / UW;
+    const int ncl = RTG * p.ndir;
     const int cl = blockIdx.x % ncl, ug = blockIdx.x / ncl;      // cluster-major ids: cluster c sits on XCD c % 8
     if (ug >= UG) return;
-    const int rt = cl % RT, dir = cl / RT;
+    const int rg = cl % RTG, dir = cl / RTG;
+    const int rt = WIDE ? rg * 2 + (wave >> 1) : rg;             // row tile whose cells this wave finishes
     const int frow = lane & 15, fq = lane >> 4;
     const int NH = p.ndir * H, K4 = 4 * H;
     const int b = rt * 16 + frow;
     const int bc = min(b, B - 1);
     const int len = (b < B) ? p.lens[b] : 0;
-    const int ut = ug * 4 + wave;                                 // unit tile this wave finishes
+    const int ut = WIDE ? ug * 2 + (wave & 1) : ug * 4 + wave;    // unit tile this wave finishes
     const bool tile_ok = ut < p.UT;
     const int u0 = ut * 16 + fq * 4;
     const bool own = (b < B) && tile_ok && (u0 < H);
@@ -1036,23 +1038,23 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
     constexpr int KBP = 4 * KQ;
 
-    // ---- once: W_h^T fragments: K quarter `wave` for the 4 unit tiles of this group ----
-    bf16x8 W[4][KQ];
+    // ---- once: W_h^T fragments: K quarter `wave` for the UW unit tiles of this group ----
+    bf16x8 W[UW][KQ];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < UW; ++u)
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            const int utu = ug * 4 + u, kb = wave * KQ + i;
+            const int utu = ug * UW + u, kb = wave * KQ + i;
             if (utu < p.UT && kb < KB4) v = ((const uint4*)p.WhB)[(((size_t)dir * p.UT + utu) * KB4 + kb) * 64 + lane];
             W[u][i] = *(bf16x8*)&v;
         }
     uint4* pre = lstm_smem + (size_t)wave * (2 * E2T_BWD_PRE16);              // wave-private prefetch double buffer
     float4* part = (float4*)(lstm_smem + 4 * 2 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
-    unsigned* flags = pa.flags + (size_t)cl * E2T_PERSIST_BWD_FLAG_STRIDE;
+    unsigned* flags = pa.flags + (size_t)cl * pa.fstride;
     // flag words only ever grow: they count published steps over ALL launches (launch number x S + steps), so there is no
     // reset pass; the launch number lives behind the flag words and is bumped by one wave when it is done
-    unsigned* epoch = pa.flags + (size_t)ncl * E2T_PERSIST_BWD_FLAG_STRIDE;
+    unsigned* epoch = pa.flags + (size_t)ncl * pa.fstride;
     const unsigned fbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (unsigned)S;
 
     // operands of step s that do not depend on the recurrence, by LDS-DMA into buffer s&1 (full exec, clamped addresses)
@@ -1131,10 +1133,11 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     long long pts[8];
 #define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)
 
-    for (int k = 0; k < S; ++k) {
+    const bool want0 = p.dh0 != nullptr;          // pseudo-step -1: gradient into the initial state (decoder <- encoder seam)
+    for (int k = 0; k < S + (want0 ? 1 : 0); ++k) {
         const int s = S - 1 - k;
         PSTAMP(0);
-        const bool active = s < len;
+        const bool active = s >= 0 && s < len;
         f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (k > 0) {
             // ---- wait until every producer wave of the cluster has published step s+1 ----
@@ -1151,25 +1154,28 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
                 if (spins > (1 << 18)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             PSTAMP(1);
-            // ---- this wave's K quarter of the 16 dG rows of step s+1 (rows without a successor step hold zeros) ----
-            u32x4 st[KQ];
-            const bf16_t* src = pa.dgx + (((((size_t)((s + 1) & 1) * p.ndir + dir) * RT + rt) * KBP + wave * KQ) * 64 + lane) * 8;
-#pragma unroll
-            for (int i = 0; i < KQ; ++i)            // the immediate offset field is 13-bit signed: one base per 4 k-blocks
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[i]) : "v"(src + (i >> 2) * 2048), "i"((i & 3) * 1024) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < KQ; ++i) asm volatile("" : "+v"(st[i]));
-            PSTAMP(2);
-            if (s > 0) prefetch(s - 1);             // lands while this step computes; drained by the publish wait
+            // ---- this wave's K quarter of the dG rows of step s+1 (rows without a successor step hold zeros), one row
+            //      tile at a time (a wide layer's quarter is 25 KiB per tile: both would not fit the registers) ----
             f32x4 acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < KQ; ++i)
+            for (int r2 = 0; r2 < RW; ++r2) {
+                u32x4 st[KQ];
+                const bf16_t* src = pa.dgx + (((((size_t)((s + 1) & 1) * p.ndir + dir) * RTD + rg * RW + r2) * KBP + wave * KQ) * 64 + lane) * 8;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[u][i], *(bf16x8*)&st[i], acc[u], 0, 0, 0);
-            // ---- reduce the 4 K-quarter partials of every unit tile through LDS ----
+                for (int i = 0; i < KQ; ++i)        // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[i]) : "v"(src + (i >> 2) * 2048), "i"((i & 3) * 1024) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < KQ; ++i) asm volatile("" : "+v"(st[i]));
+                if (r2 == 0) { PSTAMP(2); if (s > 0) prefetch(s - 1); }    // lands while this step computes; drained by the publish wait
+#pragma unroll
+                for (int i = 0; i < KQ; ++i)
+#pragma unroll
+                    for (int u = 0; u < UW; ++u) acc[r2 * UW + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[u][i], *(bf16x8*)&st[i], acc[r2 * UW + u], 0, 0, 0);
+            }
+            // ---- reduce the 4 K-quarter partials of every (row tile, unit tile) through LDS; tile index == finishing wave ----
 #pragma unroll
             for (int u = 0; u < 4; ++u) part[(u * 4 + wave) * 64 + lane] = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
             __syncthreads();
@@ -1180,6 +1186,17 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             prefetch(s - 1);
         }
         PSTAMP(3);
+        if (s < 0) {
+            if (own) {
+                float4 oh = make_float4(rec[0], rec[1], rec[2], rec[3]), oc = make_float4(dcc[0], dcc[1], dcc[2], dcc[3]);
+                if (len == 0) {
+                    oh = p.dh_final ? *(const float4*)(p.dh_final + su) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    oc = p.dc_final ? *(const float4*)(p.dc_final + su) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *(float4*)(p.dh0 + su) = oh; *(float4*)(p.dc0 + su) = oc;
+            }
+            break;
+        }
         // ---- cell backward for (utterance b, units u0..u0+3): the part that needs dh_rec ----
         uint4 og0 = make_uint4(0u, 0u, 0u, 0u), og1 = make_uint4(0u, 0u, 0u, 0u);      // (i,j,f,o) x units 0,1 / units 2,3
         if (own && active) {
@@ -1197,11 +1214,11 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             og0 = make_uint4(og[0] | ((unsigned)og[1] << 16), og[2] | ((unsigned)og[3] << 16), og[4] | ((unsigned)og[5] << 16), og[6] | ((unsigned)og[7] << 16));
             og1 = make_uint4(og[8] | ((unsigned)og[9] << 16), og[10] | ((unsigned)og[11] << 16), og[12] | ((unsigned)og[13] << 16), og[14] | ((unsigned)og[15] << 16));
         }
-        if (s > 0) {
+        if (s > 0 || want0) {
             if (own) {
                 // exchange copy for the next step's consumers: gate columns u0*4 .. u0*4+15 = k-block ut*2 + fq/2,
                 // k-groups (fq&1)*2 and +1; padded positions publish zeros.  Write-through (sc1) stores.
-                u32x4* hp = (u32x4*)(pa.dgx + (((((size_t)(s & 1) * p.ndir + dir) * RT + rt) * KBP + ut * 2 + (fq >> 1)) * 64 + (fq & 1) * 32 + frow) * 8);
+                u32x4* hp = (u32x4*)(pa.dgx + (((((size_t)(s & 1) * p.ndir + dir) * RTD + rt) * KBP + ut * 2 + (fq >> 1)) * 64 + (fq & 1) * 32 + frow) * 8);
                 const u32x4 v0 = (u32x4){og0.x, og0.y, og0.z, og0.w}, v1 = (u32x4){og1.x, og1.y, og1.z, og1.w};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:256 sc1" :: "v"(hp), "v"(v0), "v"(v1) : "memory");
             }
@@ -1362,37 +1379,56 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
 
 extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY,
                                            int lddy, const float* Gs, const float* Cs, const int32_t* lens,
-                                           const float* c0, const float* dh_final, const float* dc_final, void* dgx,
-                                           uint32_t* flags, int32_t* err, int num_cus, void* stream) {
+                                           const float* c0, const float* dh_final, const float* dc_final, float* dh0,
+                                           float* dc0, void* dgx, uint32_t* flags, int32_t* err, int num_cus, void* stream) {
     E2T_CHECK_ARG(d && WhB && dG && Gs && Cs && lens && dgx && flags && err);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
+    E2T_CHECK_ARG((dh0 == nullptr) == (dc0 == nullptr));
     LstmBwdPersistArgs pa{};
     LstmBwdArgs& p = pa.a;
     p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
-    p.dh_final = dh_final; p.dc_final = dc_final;
+    p.dh_final = dh_final; p.dc_final = dc_final; p.dh0 = dh0; p.dc0 = dc0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir;
     p.lddg = lddg; p.lddy = lddy;
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     pa.dgx = (bf16_t*)dgx; pa.flags = flags; pa.err = err;
-    const int ncl = ((d->B + 15) / 16) * d->ndir;
-    const int nwg = ncl * ((p.UT + 3) / 4);
-    const int KQ = (p.KB4 + 3) / 4;
-    // every workgroup must be resident at once (1 per CU); a K quarter of W_h^T for 4 unit tiles must fit a wave's registers
-    if (KQ > 13 || d->H % 4 != 0 || nwg > num_cus) {
+    const int RT = (d->B + 15) / 16;
+    const int kq = (p.KB4 + 3) / 4;
+    const bool wide = kq > 13;
+    const int KQ = e2t_bwd_persist_kq(d->H);
+    // every workgroup must be resident at once (1 per CU); a K quarter of W_h^T for the workgroup's unit tiles must fit a
+    // wave's registers (4 tiles x 13 k-blocks, or 2 tiles x 25)
+    const int nwg = wide ? ((RT + 1) / 2) * d->ndir * ((p.UT + 1) / 2) : RT * d->ndir * ((p.UT + 3) / 4);
+    if (KQ == 0 || d->H % 4 != 0 || nwg > num_cus) {
         e2t_set_error("persistent BPTT not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
         return E2T_ERR_ARG;
     }
+    pa.fstride = wide ? 128 : 32;
     const size_t lds = (size_t)(4 * 2 * E2T_BWD_PRE16 + 16 * 64) * 16;
-#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_bwd_persist<K>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
-    switch (KQ) {
-        E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)
-        E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10)
-        E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13)
+#define E2T_PERSIST_CASE(K, W) case K: hipLaunchKernelGGL((k_lstm_seq_bwd_persist<K, W>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
+    if (!wide) {
+        switch (KQ) {
+            E2T_PERSIST_CASE(1, false) E2T_PERSIST_CASE(2, false) E2T_PERSIST_CASE(3, false) E2T_PERSIST_CASE(4, false) E2T_PERSIST_CASE(5, false)
+            E2T_PERSIST_CASE(6, false) E2T_PERSIST_CASE(7, false) E2T_PERSIST_CASE(8, false) E2T_PERSIST_CASE(9, false) E2T_PERSIST_CASE(10, false)
+            E2T_PERSIST_CASE(11, false) E2T_PERSIST_CASE(12, false) E2T_PERSIST_CASE(13, false)
+        }
+    } else {
+        switch (KQ) { E2T_PERSIST_CASE(16, true) E2T_PERSIST_CASE(20, true) E2T_PERSIST_CASE(25, true) }
     }
 #undef E2T_PERSIST_CASE
     E2T_LAUNCH_CHECK();
     return E2T_OK;
+}
+
+// k-blocks per K quarter the persistent BPTT kernel is instantiated for (dgx holds 4x this many per row tile); 0 = none
+extern "C" int e2t_bwd_persist_kq(int H) {
+    const int kq = ((4 * H + 31) / 32 + 3) / 4;
+    if (kq <= 13) return kq;
+    if (kq <= 16) return 16;
+    if (kq <= 20) return 20;
+    if (kq <= 25) return 25;
+    return 0;
 }

@@ -401,9 +401,14 @@ class _Lstm:
         return self.KB <= 26 and ceil_div(B, 32) * self.ndir * ceil_div(self.UT, 2) <= num_cus
 
     def persistent_bwd_ok(self, B, num_cus):
-        """Mirrors the check in e2t_lstm_seq_bwd_persistent (16-utterance x 64-unit workgroups, one per CU)."""
-        nwg = ceil_div(B, 16) * self.ndir * ceil_div(self.UT, 4)
-        return nwg <= num_cus and ceil_div(self.KB4, 4) <= 13 and self.H % 4 == 0
+        """Mirrors the checks in e2t_lstm_seq_bwd_persistent: 16-utterance x 64-unit workgroups up to H = 416,
+        32 x 32 up to H = 800, one per CU."""
+        kq = H.load().e2t_bwd_persist_kq(self.H)
+        if kq == 0 or self.H % 4 != 0:
+            return False
+        RT = ceil_div(B, 16)
+        nwg = RT * self.ndir * ceil_div(self.UT, 4) if kq <= 13 else ceil_div(RT, 2) * self.ndir * ceil_div(self.UT, 2)
+        return nwg <= num_cus
 
     def alloc(self, S, B):
         dev = self.eng.device
@@ -422,8 +427,12 @@ class _Lstm:
         ws['xT'] = _bf(self.D + 1, Mk, device=dev)
         ws['xT'][self.D, :M] = 1.0
         ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
-        ws['counters'] = torch.zeros(ceil_div(B, 16) * 32 * nd + 1, dtype=torch.int32, device=dev)   # persistent BPTT: step flags + launch count
-        ws['dgx'] = _bf(2, nd, ceil_div(B, 16), 4 * ceil_div(self.KB4, 4), 64, 8, device=dev)   # in-launch dG exchange (persistent BPTT)
+        kq = H.load().e2t_bwd_persist_kq(Hh)
+        if kq:      # persistent BPTT: per-wave step flags + launch count, and the in-launch dG exchange (include/ecog2txt_hip.h)
+            RT = ceil_div(B, 16)
+            nflag = RT * nd * 32 if kq <= 13 else ceil_div(RT, 2) * nd * 128
+            ws['counters'] = torch.zeros(nflag + 1, dtype=torch.int32, device=dev)
+            ws['dgx'] = _bf(2, nd, RT if kq <= 13 else 2 * ceil_div(RT, 2), 4 * kq, 64, 8, device=dev)
         ws['hx'] = _bf(2, nd, 4 * ceil_div(B, 64), self.KB, 64, 8, device=dev)     # in-launch h exchange (persistent recurrence)
         return ws
 
@@ -479,12 +488,12 @@ class _Lstm:
             lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                  ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
                                  ws['dc_carry'].data_ptr(), p(dh0), p(dc0), stream)
-        if e.persistent_bwd and dh0 is None and self.persistent_bwd_ok(B, e.num_cus):
+        if e.persistent_bwd and self.persistent_bwd_ok(B, e.num_cus):
             # whole BPTT sweep in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_bwd_persist)
             d = self.desc(ws, train)
             lib.e2t_lstm_seq_bwd_persistent(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                             ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final),
-                                            p(dc_final), ws['dgx'].data_ptr(), ws['counters'].data_ptr(),
+                                            p(dc_final), p(dh0), p(dc0), ws['dgx'].data_ptr(), ws['counters'].data_ptr(),
                                             e.sync_err.data_ptr(), e.num_cus, e.stream)
         else:
             e.run_chains(B, launch)

@@ -62,7 +62,7 @@ SIGNATURES = {
     'e2t_lstm_seq_fwd': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     'e2t_lstm_seq_fwd_persistent': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_lstm_seq_bwd': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    'e2t_lstm_seq_bwd_persistent': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    'e2t_lstm_seq_bwd_persistent': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_final_state': [_p, _i, _p, _p, _i, _i, _p, _i, _p, _p],
     'e2t_embed_fwd': [_p, _i, _p, _i, _i, _i, _p, _i, C.POINTER(Dropout), _p],
     'e2t_embed_bwd': [_p, _i, _p, _i, _i, _p, _i, C.POINTER(Dropout), _p],
@@ -72,7 +72,8 @@ SIGNATURES = {
     'e2t_inc_step': [_p, _p],
     'e2t_adam_ema_step': [_p, _p, _p, _p, _p, _z, _p, C.POINTER(AdamHyper), _p],
 }
-PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int)}
+PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int),
+         'e2t_bwd_persist_kq': ([_i], C.c_int)}
 
 _lib = None
 

@@ -140,15 +140,18 @@ int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg
                      const float* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
                      const float* dc_final, float* dc_carry, float* dh0, float* dc0, void* stream);
 /* Same gradients as e2t_lstm_seq_bwd (to fp32 round-off: the K = 4H sum is split in 4 quarters instead of 2 halves) in
- * ONE persistent launch; no pseudo-step -1 (dh0/dc0), so for layers whose initial state is not trained.  Applicable when
- * ceil(B/16) * ndir * ceil(ceil(H/16)/4) workgroups fit the CUs one-to-one, H % 4 == 0 and H <= 416; returns non-zero
- * otherwise.  dgx: bf16 exchange scratch [2][ndir][ceil(B/16)][4*ceil(ceil(4H/32)/4)][64][8], zero-filled once by the
- * caller; flags: uint32 [ceil(B/16)*ndir*32 + 1], zero-filled once by the caller and afterwards only touched by this entry
- * point with the same S (zero it again after an error); err as for the forward. */
+ * ONE persistent launch, incl. the pseudo-step -1 when dh0/dc0 are given.  Applicable when H % 4 == 0 and the workgroups
+ * fit the CUs one-to-one: ceil(B/16) * ndir * ceil(ceil(H/16)/4) of them for H <= 416, ceil(B/32) * ndir * ceil(H/32) for
+ * H <= 800; returns non-zero otherwise.  KQ = e2t_bwd_persist_kq(H) (0: not applicable).
+ * dgx: bf16 exchange scratch [2][ndir][RTD][4*KQ][64][8] with RTD = ceil(B/16) (H <= 416) or 2*ceil(B/32), zero-filled
+ * once by the caller; flags: uint32 [clusters*stride + 1] with clusters*stride = ceil(B/16)*ndir*32 (H <= 416) or
+ * ceil(B/32)*ndir*128, zero-filled once by the caller and afterwards only touched by this entry point with the same S
+ * (zero it again after an error); err as for the forward. */
+int e2t_bwd_persist_kq(int H);
 int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
                                 const float* Gs, const float* Cs, const int32_t* lens, const float* c0,
-                                const float* dh_final, const float* dc_final, void* dgx, uint32_t* flags, int32_t* err,
-                                int num_cus, void* stream);
+                                const float* dh_final, const float* dc_final, float* dh0, float* dc0, void* dgx,
+                                uint32_t* flags, int32_t* err, int num_cus, void* stream);
 /* encoder final state -> decoder initial state (App. D2) */
 int e2t_final_state(const void* Yext, int ldy, const float* Cs, const int32_t* lens, int B, int H, void* h0, int ldh0,
                     float* c0, void* stream);

@@ -67,7 +67,7 @@ if lay.persistent_ok(B, eng.num_cus):
         print('    spread of step-top across waves: %.2f us (100 MHz wall clock: values are us)' % ((t[:, 0].max() - t[:, 0].min()) / 100.0))
 def bwd_p():
     lib.e2t_lstm_seq_bwd_persistent(C.byref(d), lay.WhB.data_ptr(), lw['dG'].data_ptr(), lw['dG'].shape[1], ws['dY'][1].data_ptr(), lay.ldy,
-                                    lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None,
+                                    lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None, None, None,
                                     lw['dgx'].data_ptr(), cnt.data_ptr(), err.data_ptr(), eng.num_cus, eng.stream)
 if lay.persistent_bwd_ok(B, eng.num_cus):
     print('persistent bwd: %.2f us/step (S=%d), err=%d' % (timeit(bwd_p, S), S, int(err.item())), flush=True)

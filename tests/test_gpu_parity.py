@@ -168,6 +168,8 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
                 assert eng.dec.persistent_ok(B, eng.num_cus), 'the decoder (H=800) must take the wide persistent kernel'
         if flag == '1':
             assert all(lay.persistent_bwd_ok(B, eng.num_cus) for lay in eng.enc)
+            if name == 'cfg2_widths':
+                assert eng.dec.persistent_bwd_ok(B, eng.num_cus), 'decoder BPTT (H=800, with the pseudo-step) must be persistent'
         for _ in range(3):                       # repeated launches: flags / exchange buffers are reused
             eng.forward(ws, train=True)
             eng.backward(ws, train=True)
