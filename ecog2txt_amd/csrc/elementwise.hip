@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_conv_pack(const float* x, const int* le
     if ((C & 3) == 0) {
         for (int k4 = threadIdx.x * 4; k4 < lda; k4 += 1024) {
             ushort4 o = make_ushort4(0, 0, 0, 0);
+            if (k4 == K) o.x = 0x3F80;          // column K (when lda > K) = 1.0: the ones column of the TN weight-gradient GEMM
             if (k4 < K) {
                 const int w = k4 / C, c = k4 - w * C;
                 const int tt = tp * N + w;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_conv_pack(const float* x, const int* le
         }
     } else {
         for (int k = threadIdx.x; k < lda; k += 256) {
-            bf16_t o = 0;
+            bf16_t o = (k == K) ? (bf16_t)0x3F80 : (bf16_t)0;
             if (k < K) {
                 const int w = k / C, c = k - w * C;
                 const int tt = tp * N + w;

@@ -52,6 +52,7 @@ struct GemmArgs {
     float* last_col_out;       // if set: column N-1 of the product goes to last_col_out[row] instead of C
     int splits;
     float* slab;               // split-K partials [splits][M][N] fp32 (dense), reduced by k_splitk_reduce
+    const bf16_t* zero_page;   // TN: 512 zero bytes for k-rows beyond K
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
@@ -120,7 +121,7 @@ extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
 
 // RICH = false drops the ReLU / mask / dropout epilogue: with 32 accumulator tiles per wave the full epilogue body is too
 // large for hipcc to unroll, and a rolled loop indexes the accumulators dynamically (= scratch memory, 4x slower kernel).
-template <int BM, int BN, int WM, int WN, bool RICH>
+template <int BM, int BN, int WM, int WN, bool RICH, bool TN>
 __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void k_gemm_nt(GemmArgs p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE = (BM + BN) * 8;         // 16-B units per stage: [A: BM rows | B: BN rows][8 chunks]
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
 
     // K range of this split (in full 64-wide tiles; the zero-filled tail belongs to the last split)
-    const int nfull = p.K / BK;
-    const bool has_tail = (p.K % BK) != 0;
+    const int nfull = TN ? (p.K + BK - 1) / BK : p.K / BK;
+    const bool has_tail = !TN && (p.K % BK) != 0;
     const int per = (nfull + p.splits - 1) / p.splits;
     const int t0 = blockIdx.y * per;
     const int t1 = min(nfull, t0 + per);
@@ -161,10 +162,37 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     // DMA map: wave w, instruction i fills rows (w*I+i)*8 .. +8 of an operand tile;
     // lane -> (row = base + lane/8, physical chunk = lane%8), source chunk = physical ^ (row&7).
     const int drow = lane >> 3, dpc = lane & 7;
+    // TN: operands are K-major ([k][m] / [k][n] row-major, e.g. activations and their gradients as the layers wrote
+    // them).  A tile is [64 k-rows][BM columns]; one DMA instruction moves 1 KiB = (2048 / BM) k-rows of BM*2 bytes, the
+    // 16-B chunk position inside a row is XOR-swizzled with tn_swz(k-row) on the SOURCE side, rows k >= K come from a zero
+    // page, columns beyond M/N are clamped (their products are never stored).  Fragments are then gathered with the
+    // transposing LDS read (ds_read_b64_tr_b16, lane mapping verified by scripts/probes/trread_probe.hip).
+    auto tn_swz = [](int row) { return (row & 3) | (((row >> 3) & 3) << 2); };
     auto issue = [&](int t, int buf) {
         const int k0 = t * BK;
         uint4* sa = smem + buf * STAGE;
         uint4* sb = sa + BM * 8;
+        if (TN) {
+            constexpr int CA = BM / 8, CB = BN / 8;                // 16-B chunks per k-row
+            constexpr int RA = 64 / CA, RB_ = 64 / CB;             // k-rows per DMA instruction
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const int rb = (wave * IA + i) * RA, r = rb + lane / CA, pc = lane % CA;
+                const int c = pc ^ (tn_swz(r) & (CA - 1));
+                const int gm = min(m0 + c * 8, (p.M - 1) & ~7);    // 8-column chunks; lda % 8 == 0 keeps them in the row
+                const bf16_t* src = (k0 + r < p.K) ? p.A + (size_t)(k0 + r) * p.lda + gm : p.zero_page;
+                dma16_to_lds(src, lds_addr_of(sa + rb * CA));
+            }
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const int rb = (wave * IB + i) * RB_, r = rb + lane / CB, pc = lane % CB;
+                const int c = pc ^ (tn_swz(r) & (CB - 1));
+                const int gn = min(n0 + c * 8, (p.N - 1) & ~7);
+                const bf16_t* src = (k0 + r < p.K) ? p.B + (size_t)(k0 + r) * p.ldb + gn : p.zero_page;
+                dma16_to_lds(src, lds_addr_of(sb + rb * CB));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int rb = (wave * IA + i) * 8;
@@ -181,17 +209,44 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
         }
     };
     const int frow = lane & 15, fq = lane >> 4;
+    typedef short v4s16 __attribute__((ext_vector_type(4)));
     auto compute = [&](int buf) {
         const uint4* sa = smem + buf * STAGE;
         const uint4* sb = sa + BM * 8;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             bf16x8 fa[TI], fb[TJ];
-            const int ch = kb * 4 + fq;
+            if (TN) {
+                // lane (frow = l&15, fq = l>>4) needs k = kb*32 + fq*8 .. +7 of column (tile offset + frow): two transposing
+                // reads of a [4 k][16 columns] block; within the 16-lane group lane j points at k-row j>>2, columns (j&3)*4..
+                constexpr int CA = BM / 8, CB = BN / 8;
+                const int jr = frow >> 2, jc = frow & 3;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) { uint4 va = sa[swz(wm + i * 16 + frow, ch)]; fa[i] = *(bf16x8*)&va; }
+                for (int h = 0; h < 2; ++h) {
+                    const int row = kb * 32 + fq * 8 + h * 4 + jr;
+                    const int sw = tn_swz(row);
+                    const char* ra = (const char*)sa + (size_t)row * (BM * 2);
+                    const char* rb = (const char*)sb + (size_t)row * (BN * 2);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) { uint4 vb = sb[swz(wn + j * 16 + frow, ch)]; fb[j] = *(bf16x8*)&vb; }
+                    for (int i = 0; i < TI; ++i) {
+                        const int chunk = ((wm + i * 16) >> 3) + (jc >> 1);
+                        const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ra + ((chunk ^ (sw & (CA - 1))) << 4) + (jc & 1) * 8));
+                        fa[i][h * 4 + 0] = v[0]; fa[i][h * 4 + 1] = v[1]; fa[i][h * 4 + 2] = v[2]; fa[i][h * 4 + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        const int chunk = ((wn + j * 16) >> 3) + (jc >> 1);
+                        const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(rb + ((chunk ^ (sw & (CB - 1))) << 4) + (jc & 1) * 8));
+                        fb[j][h * 4 + 0] = v[0]; fb[j][h * 4 + 1] = v[1]; fb[j][h * 4 + 2] = v[2]; fb[j][h * 4 + 3] = v[3];
+                    }
+                }
+            } else {
+                const int ch = kb * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) { uint4 va = sa[swz(wm + i * 16 + frow, ch)]; fa[i] = *(bf16x8*)&va; }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) { uint4 vb = sb[swz(wn + j * 16 + frow, ch)]; fb[j] = *(bf16x8*)&vb; }
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -297,12 +352,19 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p) {
     epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
 }
 
-extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                                int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
+static const bf16_t* gemm_zero_page() {
+    static bf16_t* zp = nullptr;
+    if (!zp) { if (hipMalloc(&zp, 512) != hipSuccess || hipMemset(zp, 0, 512) != hipSuccess) zp = nullptr; }
+    return zp;
+}
+
+static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                       int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
     E2T_CHECK_ARG(A && B && C);
     E2T_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
-    E2T_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
-    E2T_CHECK_ARG(lda >= K && ldb >= K);
+    E2T_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0);
+    if (tn) E2T_CHECK_ARG(lda >= (M + 7) / 8 * 8 && ldb >= (N + 7) / 8 * 8);      // K-major operands [K][M], [K][N]
+    else E2T_CHECK_ARG(K % 8 == 0 && lda >= K && ldb >= K);
     E2T_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0);
     if (M == 0 || N == 0) return E2T_OK;
     GemmArgs p{};
@@ -310,6 +372,7 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = 1.0f;
     p.splits = 1;
+    if (tn) { p.zero_page = gemm_zero_page(); if (!p.zero_page) { e2t_set_error("hipMalloc of the zero page failed"); return E2T_ERR_HIP; } }
     if (ep) {
         p.bias = ep->bias;
         p.mask_src = (const bf16_t*)ep->relu_bwd_src; p.ld_mask = ep->ld_relu_bwd_src;
@@ -328,15 +391,15 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
     // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
     // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
-    const int nfull = K / BK;
+    const int nfull = tn ? (K + BK - 1) / BK : K / BK;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool have_ws = ep && ep->splitk_ws && ep->splitk_ws_bytes > 0;
     const bool want_split = have_ws && ((ep->flags & E2T_GEMM_SPLITK) || (t128 <= 160 && nfull >= 16));
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
-    bool big = !want_split && !rich && t256 >= 192 && K >= 256;
+    bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 256;
     if (forced == 128) big = false;
-    if (forced == 256 && !want_split && !rich) big = true;
+    if (forced == 256 && !tn && !want_split && !rich) big = true;
     const int BM = big ? 256 : 128, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     if (want_split) {
@@ -351,16 +414,27 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
         if (e1 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e1)); return E2T_ERR_HIP; }
         attr_done = true;
     }
-    if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false>), dim3(ntm * ntn, p.splits), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
+    if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
+    else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     if (p.splits > 1) {
         const size_t n = (size_t)M * ((N + 3) / 4);
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
+}
+
+extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
+    return gemm_launch(false, A, lda, B, ldb, C, ldc, M, N, K, ep, stream);
+}
+
+extern "C" int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
+    return gemm_launch(true, A, lda, B, ldb, C, ldc, M, N, K, ep, stream);
 }

@@ -418,6 +418,8 @@ class _Lstm:
         ws['Gx'] = _f32(M, self.N4, device=dev)
         ws['Yext'] = _bf((S + 3) * B, self.ldy, device=dev)       # block 0 = initial state, S+1.. = zero slack
         ws['Ydrop'] = _bf(M, self.ldy, device=dev)
+        if self.ldy > nd * self.H8:
+            ws['Ydrop'][:, nd * self.H8] = 1.0        # ones column for the dW_x of the layer above (no kernel writes it)
         RT, UT = ceil_div(B, 16), ceil_div(Hh, 16)
         ws['Cs'] = _f32(S, nd, RT, UT, 2, 64, 2, device=dev)       # lane-native per-step saves (lstm.hip)
         ws['Gs'] = _f32(S, nd, RT, UT, 4, 64, 4, device=dev)
@@ -506,12 +508,26 @@ class _Lstm:
                        rk(self.N4), accumulate=d_in_accumulate)
 
     def bwd_weights(self, ws, x_ptr):
-        """dW_x (+ bias) and dW_h from the dG of bwd_rec: operand transposes + split-K GEMMs.  Nothing downstream
-        of the recurrence depends on it, so the engine runs it on a side stream under the next layer's BPTT."""
+        """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the
+        engine runs it on a side stream under the next layer's BPTT.  Both products have K = S*B rows of activations
+        (x, h_{t-1}) and of their gradients (dG) exactly as the layers wrote them -- K-major -- so they go to the TN
+        GEMM directly; the bias gradient comes from a ones column kept at x[:, D] (the forward GEMM's weight image is
+        zero there).  Layouts the TN form cannot take (input features not dense, no room for the ones column) fall
+        back to operand transposes + NT GEMM."""
         e = self.eng
         st = e.store
         M, Mk, B = ws['M'], ws['Mk'], ws['B']
         nd, Hh = self.ndir, self.H
+        dense = all(k0 == r0 for (r0, n, k0) in self.in_blocks) and self.in_ld > self.D
+        if e.tn and dense and self.ones_col_set:
+            e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
+                   self.D + 1, self.N4, M, splitk=True, tn=True)
+            for dd in range(nd):
+                # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction)
+                row_off = (2 * B if dd == 1 else 0) * self.ldy
+                e.gemm(ws['Yext'].data_ptr() + 2 * (row_off + dd * self.H8), self.ldy, ws['dG'].data_ptr() + 2 * dd * 4 * Hh,
+                       rk(self.N4), st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, M, splitk=True, tn=True)
+            return
         lib.e2t_transpose_bf16(ws['dG'].data_ptr(), rk(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
@@ -549,7 +565,7 @@ class Seq2SeqEngine:
         dev = self.device
         self.F8 = rk(s.enc_embed)
         # conv operand per subject: B operand [F][Kc8]; input-gradient operand [Kc8][F8] made on demand
-        self.convT = {sid: _bf(s.enc_embed, rk(s.decimation * Cc), device=dev) for sid, Cc in s.channels.items()}
+        self.convT = {sid: _bf(s.enc_embed, rk(s.decimation * Cc + 1), device=dev) for sid, Cc in s.channels.items()}
         self.convB = {}
         self.enc = []
         for l, Hh in enumerate(s.enc_rnn):
@@ -569,6 +585,11 @@ class Seq2SeqEngine:
         self.dec = _Lstm(self, 'dec', 1, s.dec_embed, [(0, s.dec_embed, 0)], self.E8, s.dec_rnn, STREAM_DEC_OUT)
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
                              [(0, s.dec_rnn, 0)], rk(s.dec_rnn), STREAM_DEC_OUT + 1)
+        # does the buffer a layer reads as x carry the ones column at x[:, D]?  (set where the buffers are allocated)
+        self.enc[0].ones_col_set = self.F8 > s.enc_embed
+        for l in range(1, len(self.enc)):
+            self.enc[l].ones_col_set = self.enc[l - 1].ldy > 2 * self.enc[l - 1].H8
+        self.dec.ones_col_set = self.E8 > s.dec_embed
         self._pack_table = None
         mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
         self.persistent = mode != '0'
@@ -584,6 +605,7 @@ class Seq2SeqEngine:
         self._on_side = False
         self._wstream = None
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
+        self.tn = os.environ.get('E2T_TN', '1') != '0'       # weight gradients straight from the K-major activations (no transposes)
         self.trainable = None         # None = everything; else set of segment names
 
     def init_params(self, seed=0):
@@ -616,7 +638,7 @@ class Seq2SeqEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
-             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None):
+             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False):
         ep = H.GemmEpilogue()
         ep.bias = bias
         ep.alpha = alpha
@@ -636,7 +658,7 @@ class Seq2SeqEngine:
         if row_lens is not None:
             ep.row_lens, ep.rows_per_step = row_lens
         ep.flags = flags
-        lib.e2t_gemm_nt_bf16(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
+        (lib.e2t_gemm_tn_bf16 if tn else lib.e2t_gemm_nt_bf16)(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
 
     def _dropout(self, rate, stream):
         d = H.Dropout()
@@ -731,15 +753,18 @@ class Seq2SeqEngine:
         Cc, N = s.channels[sid], s.decimation
         S = ceil_div(T, N)
         M, Mk = S * B, rk(S * B)
-        Kc, Kc8 = N * Cc, rk(N * Cc)
+        Kc, Kc8 = N * Cc, rk(N * Cc + 1)         # + the ones column that turns dW = A^T . dE into [weights; bias]
         ws = dict(sid=sid, B=B, T=T, L=L, S=S, M=M, Mk=Mk, C=Cc, Kc=Kc, Kc8=Kc8)
         ws['X'] = _f32(B, T, Cc, device=dev)
         ws['Y'] = _i32(B, L, device=dev)
         ws['lens'], ws['lens_d'] = _i32(B, device=dev), _i32(B, device=dev)
         ws['A'] = _bf(M, Kc8, device=dev)
+        ws['A'][:, Kc] = 1.0                      # never written by e2t_conv_pack; the weight image has a zero there
         ws['AT'] = _bf(Kc + 1, Mk, device=dev)
         ws['AT'][Kc, :M] = 1.0
         ws['E'] = _bf(M, self.F8, device=dev)
+        if self.F8 > s.enc_embed:
+            ws['E'][:, s.enc_embed] = 1.0         # ones column for layer 0's dW_x (see _Lstm.bwd_weights)
         ws['dEpre'] = _bf(M, self.F8, device=dev)
         ws['dEpreT'] = _bf(s.enc_embed, Mk, device=dev)
         ws['enc'] = [lay.alloc(S, B) for lay in self.enc]
@@ -757,6 +782,8 @@ class Seq2SeqEngine:
         ws['dlens'], ws['ntok'] = _i32(B, device=dev), _i32(1, device=dev)
         ws['U'], ws['Tg'] = _i32(Md, device=dev), _i32(Md, device=dev)
         ws['e'] = _bf(Md, self.E8, device=dev)
+        if self.E8 > s.dec_embed:
+            ws['e'][:, s.dec_embed] = 1.0             # ones column for the decoder's dW_x
         ws['dec'] = self.dec.alloc(L, B)
         ws['c0'] = _f32(B, s.dec_rnn, device=dev)
         ws['proj'] = self.proj.alloc(Md)
@@ -992,6 +1019,10 @@ class Seq2SeqEngine:
             return
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
         sid = ws['sid']
+        if self.tn:
+            self.gemm(ws['A'].data_ptr(), ws['Kc8'], ws['dEpre'].data_ptr(), self.F8, store.ptr('conv%s.W' % sid, store.g),
+                      s.enc_embed, ws['Kc'] + 1, s.enc_embed, M, splitk=True, tn=True)
+            return
         lib.e2t_transpose_bf16(ws['dEpre'].data_ptr(), self.F8, M, s.enc_embed, ws['dEpreT'].data_ptr(), Mk, st)
         lib.e2t_transpose_bf16(ws['A'].data_ptr(), ws['Kc8'], M, ws['Kc'], ws['AT'].data_ptr(), Mk, st)
         self.gemm(ws['AT'].data_ptr(), Mk, ws['dEpreT'].data_ptr(), Mk, store.ptr('conv%s.W' % sid, store.g), s.enc_embed,

@@ -55,6 +55,7 @@ SIGNATURES = {
     'e2t_gather_rev_decim_i32': [_p, _p, _i, _i, _i, _p, _p],
     'e2t_decoder_tokens': [_p, _i, _i, _i, _p, _p, _p],
     'e2t_gemm_nt_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    'e2t_gemm_tn_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     'e2t_transpose_bf16': [_p, _i, _i, _i, _p, _i, _p],
     'e2t_cast_pack': [_p, _l, _l, _i, _i, _p, _i, _p],
     'e2t_pack_frag': [_p, _l, _l, _i, _i, _p, _p],

@@ -56,7 +56,8 @@ int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float*
 
 /* ---- a5+a6: tf.reverse_sequence (trainers.py:808-810) fused with the im2row staging of
  *      SequenceNetwork._convolve_sequences (trainers.py:813-818): x [B][T][C] fp32 ->
- *      A [(T/N)*B][lda] bf16, row (t',b), column (w,c)  ---- */
+ *      A [(T/N)*B][lda] bf16, row (t',b), column (w,c); columns N*C.. are zero except column N*C = 1.0 when lda > N*C
+ *      (the ones column that makes A^T . dE = [dW; db] in e2t_gemm_tn_bf16)  ---- */
 int e2t_conv_pack(const float* x, const int32_t* lens, int B, int T, int C, int N, void* A, int lda, void* stream);
 /* a12: scatter d/dA [S*B][ldda] fp32 back to d/dx [B][T][C] (restore_and_get_saliencies, trainers.py:722-725) */
 int e2t_conv_unpack_grad(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, float* dx, void* stream);
@@ -90,6 +91,12 @@ typedef struct e2t_gemm_epilogue {
 } e2t_gemm_epilogue;
 int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep /* host pointer or NULL */, void* stream);
+/* Same product and epilogue with K-MAJOR operands: C[M][N] (+)= alpha * sum_k A[k][m] * B[k][n] (A bf16 [K][lda >= M],
+ * B bf16 [K][ldb >= N]; lda, ldb multiples of 8; any K).  This is the shape of every weight gradient (K = S*B rows of
+ * activations and of their gradients as the layers wrote them), so no operand is ever transposed in memory: fragments are
+ * gathered from the K-major LDS tile with the transposing read ds_read_b64_tr_b16. */
+int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const e2t_gemm_epilogue* ep, void* stream);
 int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
 
 /* ---- weight packing: fp32 masters -> bf16 operand images (after every optimiser step) ---- */

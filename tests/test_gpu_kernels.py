@@ -93,6 +93,29 @@ def test_gemm_epilogues(hl):
     np.testing.assert_allclose(host(ct), want, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('M,N,K', [(16, 16, 64), (128, 128, 256), (130, 70, 200), (801, 400, 1000), (100, 3073, 333), (37, 9, 5)])
+def test_gemm_tn_k_major_operands(hl, M, N, K):
+    """C = A^T . B with both operands K-major (the weight-gradient shape): ragged K, M, N; with and without split-K."""
+    rng = np.random.default_rng(M + 3 * N + K)
+    lda, ldb = r8(M) + 8, r8(N)
+    A = np.zeros((K, lda)); A[:, :M] = rng.standard_normal((K, M))
+    Bm = np.zeros((K, ldb)); Bm[:, :N] = rng.standard_normal((K, N))
+    A[:, M:] = 7.0                                           # columns beyond M must never reach the output
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    want = round_bf16(A[:, :M]).T @ round_bf16(Bm[:, :N])
+    wsb = torch.zeros(4 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    for split in (False, True):
+        c = torch.full((M, r8(N)), 7.0, dtype=torch.float32, device='cuda')
+        ep = hl.GemmEpilogue(); ep.alpha = 1.0
+        if split:
+            ep.flags = hl.GEMM_SPLITK
+            ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), r8(N), M, N, K, C.byref(ep), st())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(host(c)[:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+        assert np.all(host(c)[:, N:] == 7.0)
+
+
 def test_gemm_splitk_runs_the_full_epilogue(hl):
     """Few output tiles + long K: the library splits K on its own when a workspace is offered, and the reduction
     applies the same bias / ReLU / dropout / row mask / bf16 epilogue (same Philox mask) as the direct store."""
