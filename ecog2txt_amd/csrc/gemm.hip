@@ -404,7 +404,8 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     if (want_split) {
         const int tiles = ntm * ntn;
-        int s = (512 + tiles - 1) / tiles;             // aim at ~2 workgroups per CU
+        int s = 512 / tiles;                           // fill, but never exceed, the 2 x 256 resident workgroups: one block
+                                                       // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
         if (s > nfull / 6) s = nfull / 6;              // keep >= 6 K tiles per split
         const size_t per = (size_t)M * N * sizeof(float);
         if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
