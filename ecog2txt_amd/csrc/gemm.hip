@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
                 // reads of a [4 k][16 columns] block; within the 16-lane group lane j points at k-row j>>2, columns (j&3)*4..
                 constexpr int CA = BM / 8, CB = BN / 8;
                 const int jr = frow >> 2, jc = frow & 3;
+                v4s16 va[2][TI], vb[2][TJ];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = kb * 32 + fq * 8 + h * 4 + jr;
@@ -230,16 +231,19 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
 #pragma unroll
                     for (int i = 0; i < TI; ++i) {
                         const int chunk = ((wm + i * 16) >> 3) + (jc >> 1);
-                        const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ra + ((chunk ^ (sw & (CA - 1))) << 4) + (jc & 1) * 8));
-                        fa[i][h * 4 + 0] = v[0]; fa[i][h * 4 + 1] = v[1]; fa[i][h * 4 + 2] = v[2]; fa[i][h * 4 + 3] = v[3];
+                        va[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ra + ((chunk ^ (sw & (CA - 1))) << 4) + (jc & 1) * 8));
                     }
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
                         const int chunk = ((wn + j * 16) >> 3) + (jc >> 1);
-                        const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(rb + ((chunk ^ (sw & (CB - 1))) << 4) + (jc & 1) * 8));
-                        fb[j][h * 4 + 0] = v[0]; fb[j][h * 4 + 1] = v[1]; fb[j][h * 4 + 2] = v[2]; fb[j][h * 4 + 3] = v[3];
+                        vb[h][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(rb + ((chunk ^ (sw & (CB - 1))) << 4) + (jc & 1) * 8));
                     }
                 }
+                // the two halves are the low / high register pair of the fragment: a concatenation, no element moves
+#pragma unroll
+                for (int i = 0; i < TI; ++i) fa[i] = __builtin_shufflevector(va[0][i], va[1][i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) fb[j] = __builtin_shufflevector(vb[0][j], vb[1][j], 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
                 const int ch = kb * 4 + fq;
 #pragma unroll
