@@ -297,6 +297,8 @@ class _FFStack:
             fin = self.sizes[i]
             if i > 0:
                 ws['act'].append(_bf(M, rk(fin), device=dev))            # hidden activation i-1
+                if rk(fin) > fin:
+                    ws['act'][-1][:, fin] = 1.0                          # ones column for the TN weight gradient (no kernel writes it)
                 ws['dpre'].append(_bf(M, rk(fin), device=dev))
             t = _bf(fin + 1, Mk, device=dev)
             t[fin, :M] = 1.0                                             # ones row => bias gradient for free
@@ -324,21 +326,48 @@ class _FFStack:
                 cur, ld = o.data_ptr(), rk(fout)
         return ws['out']
 
-    def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train):
-        """d_out: bf16 [M][rk(out)] gradient of the final linear output.  Writes weight grads
-        into the store and the input gradient (fp32) into d_in_ptr."""
+    def bwd_dx(self, ws, d_out, d_in_ptr, d_in_ld, accumulate, train):
+        """Input-gradient chain (the critical path): d_out bf16 [M][rk(out)] -> hidden pre-activation gradients
+        (ws['dpre'], masked by ReLU/dropout in the GEMM epilogue) -> fp32 gradient of the stack's input."""
         e = self.eng
-        st = e.store
-        M, Mk = ws['M'], ws['Mk']
+        M = ws['M']
         d, ldd = d_out.data_ptr(), rk(self.sizes[-1])
         keep = 1.0 / (1.0 - e.spec.ff_dropout) if (train and e.spec.ff_dropout > 0) else 1.0
         for i in range(self.nl - 1, -1, -1):
+            fin, fout = self.sizes[i], self.sizes[i + 1]
+            kin = self.in_ld if i == 0 else rk(fin)
+            if i > 0:
+                dp = ws['dpre'][i - 1]
+                e.gemm(d, ldd, self.WB[i].data_ptr(), rk(fout), dp.data_ptr(), rk(fin), M, fin, rk(fout),
+                       out_bf16=True, alpha=keep, mask_src=(ws['act'][i - 1].data_ptr(), rk(fin)))
+                d, ldd = dp.data_ptr(), rk(fin)
+            else:
+                e.gemm(d, ldd, self.WB[0].data_ptr(), rk(fout), d_in_ptr, d_in_ld, M, kin, rk(fout),
+                       accumulate=accumulate)
+
+    def bwd_dw(self, ws, x_ptr, d_out):
+        """Weight (+ bias) gradients from the layer inputs and the gradients bwd_dx left in ws['dpre']: K = M rows of
+        K-major operands -> TN GEMM where the input carries its ones column (x[:, fin] == 1), else operand transposes
+        + NT GEMM.  Nothing downstream depends on it: the engine queues it on the side stream."""
+        e = self.eng
+        st = e.store
+        M, Mk = ws['M'], ws['Mk']
+        for i in range(self.nl - 1, -1, -1):
             last = i == self.nl - 1
             fin, fout = self.sizes[i], self.sizes[i + 1]
-            # transposes (K-contiguous operands for the weight-gradient GEMM)
-            lib.e2t_transpose_bf16(d, ldd, M, fout, ws['dT'][i].data_ptr(), Mk, e.stream)
+            d, ldd = (d_out.data_ptr(), rk(fout)) if last else (ws['dpre'][i].data_ptr(), rk(fout))
             xp, xld = (x_ptr, self.in_ld) if i == 0 else (ws['act'][i - 1].data_ptr(), rk(fin))
             blocks = self.in_blocks if i == 0 else [(0, fin, 0)]
+            dense = all(k0 == r0 for (r0, n, k0) in blocks) and xld > fin
+            if e.tn and dense and (self.ones_col_set if i == 0 else True):
+                if last:      # dW^T = d^T . [x | 1]  [out][in + 1]; the last column is the bias gradient
+                    e.gemm(d, ldd, xp, xld, st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin + 1, M, splitk=True,
+                           last_col_out=st.ptr('%s%d.b' % (self.prefix, i), st.g), tn=True)
+                else:         # [dW; db] = [x | 1]^T . d  [in + 1][out]
+                    e.gemm(xp, xld, d, ldd, st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, M, splitk=True, tn=True)
+                continue
+            # transposes (K-contiguous operands for the NT weight-gradient GEMM)
+            lib.e2t_transpose_bf16(d, ldd, M, fout, ws['dT'][i].data_ptr(), Mk, e.stream)
             for (r0, n, k0) in blocks:
                 lib.e2t_transpose_bf16(xp + 2 * k0, xld, M, n, ws['actT'][i].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
             if last:
@@ -349,15 +378,12 @@ class _FFStack:
             else:
                 e.gemm(ws['actT'][i].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
                        st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk, splitk=True)
-            kin = self.in_ld if i == 0 else rk(fin)
-            if i > 0:
-                dp = ws['dpre'][i - 1]
-                e.gemm(d, ldd, self.WB[i].data_ptr(), rk(fout), dp.data_ptr(), rk(fin), M, fin, rk(fout),
-                       out_bf16=True, alpha=keep, mask_src=(ws['act'][i - 1].data_ptr(), rk(fin)))
-                d, ldd = dp.data_ptr(), rk(fin)
-            else:
-                e.gemm(d, ldd, self.WB[0].data_ptr(), rk(fout), d_in_ptr, d_in_ld, M, kin, rk(fout),
-                       accumulate=accumulate)
+
+    def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train):
+        """d_out: bf16 [M][rk(out)] gradient of the final linear output.  Writes weight grads
+        into the store and the input gradient (fp32) into d_in_ptr."""
+        self.bwd_dx(ws, d_out, d_in_ptr, d_in_ld, accumulate, train)
+        self.bwd_dw(ws, x_ptr, d_out)
 
 
 class _Lstm:
@@ -590,6 +616,10 @@ class Seq2SeqEngine:
         for l in range(1, len(self.enc)):
             self.enc[l].ones_col_set = self.enc[l - 1].ldy > 2 * self.enc[l - 1].H8
         self.dec.ones_col_set = self.E8 > s.dec_embed
+        self.proj.ones_col_set = self.dec.ldy > self.dec.H8 and self.dec.H8 == s.dec_rnn      # the column must be x[:, fin]
+        if self.aux:
+            k = s.aux_layer
+            self.aux.ones_col_set = self.enc[k].ldy > 2 * self.enc[k].H8
         self._pack_table = None
         mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
         self.persistent = mode != '0'
@@ -907,13 +937,14 @@ class Seq2SeqEngine:
         aux_names = [n for n in store.order if n.startswith('aux')]
         # the auxiliary head's backward (its own weight gradients + its share of dY[aux_layer]) only needs the forward
         # pass: side stream, under the decoder's BPTT; the layer above then ACCUMULATES its input gradient onto it
-        stages.append((lambda train: self._bwd_head(ws, train), lambda train: self._bwd_aux(ws, train), rng_of(head + aux_names)))
+        stages.append((lambda train: self._bwd_head(ws, train), lambda train: self._bwd_aux(ws, train), rng_of(aux_names)))
         for l in range(nl - 1, -1, -1):
-            names = []
-            side = None
             if l < nl - 1:
-                names = names + enc_names(l + 1)
+                names = enc_names(l + 1)
                 side = (lambda train, l=l: self._bwd_enc_weights(ws, l + 1))
+            else:       # the head's own weight gradients queue up first, under the top layer's BPTT
+                names = head
+                side = (lambda train: self._bwd_head_weights(ws, train))
             stages.append((lambda train, l=l: self._bwd_enc_rec(ws, l, train), side, rng_of(names)))
         stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
         return stages
@@ -968,18 +999,22 @@ class Seq2SeqEngine:
             self.join_side(j)
 
     def _bwd_head(self, ws, train):
+        """Critical path of the head: gradient through the vocabulary projection, decoder BPTT (-> gradient into the
+        encoder's final state and into the embedded tokens)."""
         s, store = self.spec, self.store
-        Md = ws['Md']
-        st = self.stream
         store.view('dec.emb', store.g).zero_()          # the embedding scatter-add accumulates by atomics
-        # vocabulary projection
-        self.proj.bwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train)
-        # decoder BPTT (+ gradient into the encoder's final state)
-        self.dec.bwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
-                     ws['de'].data_ptr(), self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
+        self.proj.bwd_dx(ws['proj'], ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train)
+        self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
+                         ws['de'].data_ptr(), self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
+
+    def _bwd_head_weights(self, ws, train):
+        """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them."""
+        s, store = self.spec, self.store
+        self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
+        self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
         dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
-        lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), Md, s.dec_embed,
-                          store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), st)
+        lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
+                          store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)
 
     def _bwd_enc_rec(self, ws, l, train):
         """aux head (if it taps layer l), BPTT of layer l, gradient into the layer below."""
