@@ -1182,7 +1182,14 @@ class Seq2SeqEngine:
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()
         if int(self.sync_err.item()) != 0:
-            raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results invalid)')
+            # the exchange buffers / flag words of the persistent recurrences are now inconsistent: reset them so that
+            # the next step starts clean, then fail loudly (E2T_PERSISTENT=0 selects the launch-per-step kernels)
+            self.sync_err.zero_()
+            for lw in list(ws['enc']) + [ws['dec']]:
+                for k in ('hx', 'dgx', 'counters'):
+                    if k in lw:
+                        lw[k].zero_()
+            raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid)')
         out = dict(decoder=float(v[0]), accuracy=float(v[2]))
         if ws.get('use_aux'):
             out['aux'] = float(v[1])
