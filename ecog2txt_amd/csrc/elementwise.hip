@@ -16,18 +16,35 @@ __global__ __launch_bounds__(1024) void k_seq_lengths_f32(const float* x, int T,
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* xb = x + (size_t)b * T * C;
     int cnt = 0;
-    for (int t = wave; t < T; t += 16) {
-        const float* row = xb + (size_t)t * C;
-        bool nz = false;
-        if ((C & 3) == 0) {
-            for (int c = lane * 4; c < C; c += 256) {
-                float4 v = *(const float4*)(row + c);
-                nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    if ((C & 3) == 0 && C <= 256) {
+        // the common shape (one 16-B load per lane covers a row): 8 rows in flight per wave -- a load / vote / next-row
+        // chain is a memory round trip per row (33 us for 105 MB), the loads of 8 rows are independent
+        const int c = lane * 4;
+        for (int t0 = wave; t0 < T; t0 += 16 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = t0 + 16 * i;
+                v[i] = (t < T && c < C) ? *(const float4*)(xb + (size_t)t * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        } else {
-            for (int c = lane; c < C; c += 64) nz |= row[c] != 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (__any((v[i].x != 0.f) | (v[i].y != 0.f) | (v[i].z != 0.f) | (v[i].w != 0.f))) cnt++;      // wave-uniform
         }
-        if (__any(nz)) cnt++;            // wave-uniform
+    } else {
+        for (int t = wave; t < T; t += 16) {
+            const float* row = xb + (size_t)t * C;
+            bool nz = false;
+            if ((C & 3) == 0) {
+                for (int c = lane * 4; c < C; c += 256) {
+                    float4 v = *(const float4*)(row + c);
+                    nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+                }
+            } else {
+                for (int c = lane; c < C; c += 64) nz |= row[c] != 0.f;
+            }
+            if (__any(nz)) cnt++;            // wave-uniform
+        }
     }
     __shared__ int sc[16];
     if (lane == 0) sc[wave] = cnt;
@@ -318,8 +335,22 @@ __global__ __launch_bounds__(256) void k_softmax_ce(const float* logits, int ldl
     if (m >= M) return;
     const float* row = logits + (size_t)m * ldl;
     const bool valid = lens ? ((m / rowsB) < lens[m % rowsB]) : true;
+    // the row stays in registers when it fits (V <= 2048: 32 values per lane): ONE pass over memory with all loads in
+    // flight instead of three dependent passes; same reduction order either way
+    constexpr int NR = 32;
+    const bool inreg = V <= NR * 64;
+    float xr[NR];
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { const int v = lane + 64 * i; xr[i] = (v < V) ? row[v] : -INFINITY; }
+    }
     float mx = -INFINITY; int arg = 0;
-    for (int v = lane; v < V; v += 64) { float x = row[v]; if (x > mx) { mx = x; arg = v; } }
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { if (xr[i] > mx) { mx = xr[i]; arg = lane + 64 * i; } }
+    } else {
+        for (int v = lane; v < V; v += 64) { float x = row[v]; if (x > mx) { mx = x; arg = v; } }
+    }
     // wave arg-max with lowest-index tie-break (matches numpy argmax)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -327,7 +358,12 @@ __global__ __launch_bounds__(256) void k_softmax_ce(const float* logits, int ldl
         if (omx > mx || (omx == mx && oarg < arg)) { mx = omx; arg = oarg; }
     }
     float se = 0.f;
-    for (int v = lane; v < V; v += 64) se += __expf(row[v] - mx);
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { if (lane + 64 * i < V) se += __expf(xr[i] - mx); }
+    } else {
+        for (int v = lane; v < V; v += 64) se += __expf(row[v] - mx);
+    }
     se = wave_sum(se);
     const float lse = mx + __logf(se);
     const int t = tgt ? tgt[m] : 0;
@@ -339,9 +375,17 @@ __global__ __launch_bounds__(256) void k_softmax_ce(const float* logits, int ldl
     if (dl) {
         const float sc = valid ? w / (float)max(ntok ? *ntok : 1, 1) : 0.f;
         bf16_t* drow = dl + (size_t)m * lddl;
-        for (int v = lane; v < V; v += 64) {
-            float pr = __expf(row[v] - lse);
-            drow[v] = f2bf((pr - (v == t ? 1.f : 0.f)) * sc);
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int v = lane + 64 * i;
+                if (v < V) drow[v] = f2bf((__expf(xr[i] - lse) - (v == t ? 1.f : 0.f)) * sc);
+            }
+        } else {
+            for (int v = lane; v < V; v += 64) {
+                float pr = __expf(row[v] - lse);
+                drow[v] = f2bf((pr - (v == t ? 1.f : 0.f)) * sc);
+            }
         }
     }
 }
