@@ -292,6 +292,72 @@ class SequenceNetwork:
             return G
         return np.sqrt((G ** 2).mean(axis=(0, 1)))
 
+    def restore_and_get_internal_activations(self, subjects, restore_epoch, data_partition='validation'):
+        """The tensors the reference's activation probe fetches (trainers.py:757-765) for the last subject:
+        'reversed_inputs' [n,T,C] (time-reversed over each utterance's valid length, trainers.py:808-810),
+        'convolved_inputs' [n,S,F] (front-end output, S = T/decimation), 'decimated_reversed_targets' [n,S,K]
+        (auxiliary encoder targets, reversed then every decimation-th sample, trainers.py:791-795; None without
+        an auxiliary target) and 'final_RNN_state' [2,n,2H] = (c, h) of the top encoder layer at each utterance's own
+        last step (what initialises the decoder).  Computed with the EMA weights, dropout off."""
+        import torch
+        eng = self._get_engine(subjects)
+        self._restore(eng, restore_epoch, None)
+        subject = subjects[-1]
+        data = self._stage(subject, data_partition)
+        ws = eng.workspace(subject.subnet_id, self.N_cases, data['T'], data['L'])
+        s = eng.spec
+        S, B, F = ws['S'], ws['B'], s.enc_embed
+        out = dict(reversed_inputs=[], convolved_inputs=[], decimated_reversed_targets=[], final_RNN_state=[])
+        for idx in self._batches(data):
+            self._load_batch(eng, ws, data, idx)
+            if eng._packed != 'ema':
+                eng.pack('ema')
+            eng.forward(ws, train=False, which='ema')
+            torch.cuda.synchronize(eng.device)
+            n = len(idx)
+            lens = ws['lens'].cpu().numpy()[:n]
+            X = data['X'][idx]
+            R = np.zeros_like(X)
+            for i, ln in enumerate(lens):
+                R[i, :ln] = X[i, :ln][::-1]
+            out['reversed_inputs'].append(R)
+            E = ws['E'].float().cpu().numpy().reshape(S, B, -1)[:, :n, :F]
+            out['convolved_inputs'].append(E.transpose(1, 0, 2))
+            if ws.get('use_aux'):
+                At = ws['At'].cpu().numpy().reshape(S, B, -1)[:, :n]
+                out['decimated_reversed_targets'].append(At.transpose(1, 0, 2))
+            H2 = 2 * s.enc_rnn[-1]
+            h = ws['dec']['Yext'][:B].float().cpu().numpy()[:n, :H2]
+            c = ws['c0'].cpu().numpy()[:n, :H2]
+            out['final_RNN_state'].append(np.stack([c, h]))
+        eng.pack('p')
+        res = {k: (np.concatenate(v, axis=1 if k == 'final_RNN_state' else 0) if v else None) for k, v in out.items()}
+        return res
+
+    def online_predictor(self, subjects, restore_epoch, targets_list=None, subject=None, max_length=None):
+        """predict(inputs) for one utterance [T,C] or a batch [B,T,C] of (zero-padded) ECoG: greedy word sequences
+        from the restored EMA weights -- the device-resident counterpart of the reference's SavedModel predictor
+        (trainers.py:925-949).  With targets_list the hypotheses come back as strings, else as token-id arrays."""
+        import torch
+        eng = self._get_engine(subjects)
+        self._restore(eng, restore_epoch, None)
+        subject = subject or subjects[-1]
+        N = eng.spec.decimation
+        L = int(max_length or self.max_hyp_length)
+        eng.pack('ema')
+
+        def predict(inputs):
+            x = np.asarray(inputs, np.float32)
+            x = x[None] if x.ndim == 2 else x
+            B, T = x.shape[0], -(-x.shape[1] // N) * N
+            ws = eng.workspace(subject.subnet_id, B, T, L)
+            ws['X'].zero_()
+            ws['X'][:, :x.shape[1]].copy_(torch.from_numpy(np.ascontiguousarray(x)))
+            ws['Y'].zero_()
+            hyp = eng.greedy_decode(ws, which='ema').cpu().numpy()
+            return target_inds_to_sequences(hyp, list(targets_list)) if targets_list is not None else hyp
+        return predict
+
     # ------------------------------------------------------------------ checkpoints (rows a13, SURVEY.md section 5)
     def _tf_names(self, eng):
         """segment name -> representative TF-style variable name (for the scope regexes of trainers.py:337-366)."""

@@ -1,8 +1,8 @@
 """`MultiSubjectTrainer`: orchestration of (transfer) learning across participants, restated over
 the MI355X backend.  Same constructor, kwargs routing and public methods as the reference
-orchestrator (ecog2txt/trainers.py:41-442, 556-602, 703-732), minus the TensorFlow-only
-introspection helpers (graph probes, TF checkpoint reader, SavedModel predictor), which are
-outside the hot path.
+orchestrator (ecog2txt/trainers.py:41-442, 556-602, 703-732, 757-859, 925-949); the TensorFlow-only
+pieces (graph rebuilding, TF checkpoint reader, SavedModel loading) are replaced by reads of this backend's
+device buffers and checkpoints.
 
 Usage is the README's (reference README.md:72-102):
 
@@ -284,6 +284,25 @@ class MultiSubjectTrainer:
         finally:
             for key, v in old.items():
                 subject.data_manifests[key].penalty_scale = v
+
+    def get_internal_activations(self):
+        """'convolved_inputs', 'reversed_inputs', 'decimated_reversed_targets', 'final_RNN_state' on the last
+        subject's validation blocks with the saved model (trainers.py:757-859; the reference rebuilds these graph
+        snippets in TF, here they are read back from the device buffers of a forward pass)."""
+        self.update_net_from_saved_model()
+        return self.net.restore_and_get_internal_activations(self.ecog_subjects, self.restore_epoch,
+                                                              data_partition='validation')
+
+    def construct_online_predictor(self, targets_list=None, subject=None, max_length=None):
+        """predict(inputs) -> hypotheses for raw ECoG [T,C] / [B,T,C] with the saved model (the reference builds this
+        from a SavedModel export, trainers.py:925-949; here from this trainer's checkpoint).  targets_list defaults
+        to the decoder vocabulary, so the hypotheses are word strings."""
+        self.update_net_from_saved_model()
+        subject = subject or self.ecog_subjects[-1]
+        if targets_list is None:
+            targets_list = list(subject.data_manifests['decoder_targets'].get_feature_list())
+        return self.net.online_predictor(self.ecog_subjects, self.restore_epoch, targets_list=targets_list,
+                                         subject=subject, max_length=max_length)
 
     def subject_to_table(self):
         import pandas as pd

@@ -55,6 +55,29 @@ def test_readme_flow_learns(small):
     assert seqs.ndim == 3 and seqs.shape[2] == 16
     w = tr.net.get_weights_as_numpy_array('seq2seq/subnet_401/encoder_embedding_16_24_0/weights/ExponentialMovingAverage', 60)
     assert w.shape == (1, 12, 16, 24)
+    # activation probe (trainers.py:757-765): shapes, reversal, and the front-end against the oracle's conv on the EMA weights
+    act = tr.get_internal_activations()
+    n = len(res['validation'].references)
+    X = act['reversed_inputs']
+    assert X.shape[0] == n and X.shape[2] == 16
+    S = X.shape[1] // 12
+    assert act['convolved_inputs'].shape == (n, S, 24) and act['final_RNN_state'].shape == (2, n, 64)
+    assert act['decimated_reversed_targets'] is None or act['decimated_reversed_targets'].shape[:2] == (n, S)
+    from oracle.bf16 import round_bf16
+    wc = round_bf16(w.reshape(12 * 16, 24))
+    bc = tr.net.get_weights_as_numpy_array('seq2seq/subnet_401/encoder_embedding_16_24_0/biases/ExponentialMovingAverage', 60)
+    lens = (np.abs(X).sum(-1) > 0).sum(-1)
+    for i in range(min(n, 4)):
+        z = round_bf16(X[i]).reshape(S, 12 * 16) @ wc + bc
+        z = np.maximum(z, 0.0) * (np.arange(S)[:, None] < -(-lens[i] // 12))
+        np.testing.assert_allclose(act['convolved_inputs'][i], round_bf16(z), rtol=2e-2, atol=2e-2)
+    assert np.isfinite(act['final_RNN_state']).all() and np.abs(act['final_RNN_state'][1]).max() <= 1.0
+    # online predictor (trainers.py:925-949): one utterance at a time reproduces the batch assessment's hypotheses
+    predict = tr.construct_online_predictor()
+    data = tr.net._stage(tr.ecog_subjects[-1], 'validation')
+    for i in (0, 1, n - 1):
+        assert predict(data['X'][i]) == [res['validation'].hypotheses[i]]
+    assert predict(data['X'][:3]) == res['validation'].hypotheses[:3]
 
 
 def test_sequential_transfer_and_resume(small):
