@@ -53,6 +53,22 @@ def load_examples(subject, blocks):
     return out
 
 
+class _Arrays(dict):
+    """dict of arrays with the `.files` attribute of an NpzFile"""
+    @property
+    def files(self):
+        return list(self)
+
+
+def load_checkpoint_arrays(prefix, names=None):
+    """Variables of checkpoint `prefix`: this backend's `.npz` (weights, EMA shadows, Adam state) when present, else
+    a TensorFlow V2 checkpoint `prefix.index` + `prefix.data-*` as written by the reference's TF1 Saver."""
+    if os.path.exists(prefix + '.npz'):
+        return np.load(prefix + '.npz')
+    from . import tf_checkpoint
+    return _Arrays(tf_checkpoint.read_checkpoint(prefix, names=names))
+
+
 class SequenceNetwork:
     @auto_attribute(CHECK_MANIFEST=True)
     def __init__(self, manifest, EOS_token='<EOS>', pad_token='<pad>', OOV_token='<OOV>', training_GPUs=(0,),
@@ -391,11 +407,15 @@ class SequenceNetwork:
         arrays['__step'] = eng.step_t.cpu().numpy()
         os.makedirs(os.path.dirname(self.checkpoint_path) or '.', exist_ok=True)
         np.savez(self._ckpt(epoch) + '.npz', **arrays)
-        open(self._ckpt(epoch) + '.index', 'w').close()          # marker the trainer's restore_epoch scan looks for
+        # the same variables (weights + EMA shadows, reference naming grammar) as a TensorFlow V2 checkpoint:
+        # `model.ckpt-<epoch>.index` is what the trainer's restore_epoch scan looks for (trainers.py:235-252), and the
+        # pair is readable by TF's own checkpoint reader (recover_model_sizes, trainers.py:444-554)
+        from . import tf_checkpoint
+        tf_checkpoint.write_checkpoint(self._ckpt(epoch), {k: v for k, v in arrays.items() if not k.startswith('__')})
 
     def _restore(self, eng, epoch, reuse_vars_scope):
         import torch
-        z = np.load(self._ckpt(epoch) + '.npz')
+        z = load_checkpoint_arrays(self._ckpt(epoch))
         P = {k: z[k] for k in z.files if not k.startswith('__') and not k.endswith(EMA_SUFFIX)}
         E = {k[:-len(EMA_SUFFIX)]: z[k] for k in z.files if k.endswith(EMA_SUFFIX)}
         if reuse_vars_scope is not None:
@@ -416,5 +436,5 @@ class SequenceNetwork:
         eng.pack('p')
 
     def get_weights_as_numpy_array(self, full_var_name, epoch):
-        z = np.load(self._ckpt(epoch) + '.npz')
+        z = load_checkpoint_arrays(self._ckpt(epoch), names=[full_var_name])
         return z[full_var_name]

@@ -193,13 +193,18 @@ class MultiSubjectTrainer:
         """Walk the checkpoint's variable->shape map with the reference's naming grammar: outer scope seq2seq,
         optional subnet_<id>, '<subnet>_<in>_<out>_<layer>/weights', RNN variables under cell_<k> with 4 packed
         gates, transposed last projection layer, rank-4 conv weights whose width is the stride."""
-        z = np.load('%s-%d.npz' % (os.path.join(self.checkpoint_dir, 'model.ckpt'), self.restore_epoch))
+        prefix = '%s-%d' % (os.path.join(self.checkpoint_dir, 'model.ckpt'), self.restore_epoch)
+        if os.path.exists(prefix + '.npz'):
+            z = np.load(prefix + '.npz')
+            shapes = {name: z[name].shape for name in z.files}
+        else:       # a TensorFlow checkpoint (e.g. written by the reference): the index alone has names and shapes
+            from . import tf_checkpoint
+            shapes = dict(tf_checkpoint.list_variables(prefix))
         info = defaultdict(lambda: defaultdict(dict))
         EMA = False
-        for name in z.files:
+        for name, shape in shapes.items():
             if name.startswith('__'):
                 continue
-            shape = z[name].shape
             scopes = name.split('/')
             if scopes[-1] == 'ExponentialMovingAverage':
                 EMA = True

@@ -78,6 +78,13 @@ def test_readme_flow_learns(small):
     for i in (0, 1, n - 1):
         assert predict(data['X'][i]) == [res['validation'].hypotheses[i]]
     assert predict(data['X'][:3]) == res['validation'].hypotheses[:3]
+    # the checkpoint is also a TensorFlow V2 checkpoint (index + data shard): with the .npz gone, sizes, weights and EMA
+    # shadows come from it and the assessment is reproduced
+    assert os.path.getsize(os.path.join(ck, 'model.ckpt-60.index')) > 48
+    os.remove(os.path.join(ck, 'model.ckpt-60.npz'))
+    res_tf = tr.assess_saved_model()
+    assert res_tf['validation'].hypotheses == res['validation'].hypotheses
+    assert res_tf['validation'].accuracy == res['validation'].accuracy
 
 
 def test_sequential_transfer_and_resume(small):

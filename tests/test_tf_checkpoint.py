@@ -1,0 +1,110 @@
+"""TensorFlow V2 checkpoint codec: known answers of the primitives, structure of the
+written files, round trips; no TensorFlow needed (and none is available to cross-read)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from ecog2txt_amd import tf_checkpoint as T
+from ecog2txt_amd.tfrecord import crc32c as crc_serial
+
+
+def test_crc32c_known_answers_and_lane_combination():
+    assert T.crc32c(b'123456789') == 0xE3069283                 # Castagnoli check value
+    assert T.crc32c(bytes(32)) == 0x8A9136AA                     # RFC 3720 B.4: 32 bytes of zeros
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43            # RFC 3720 B.4: 32 bytes of ones
+    rng = np.random.default_rng(0)
+    for n in (4096 * 64, 4096 * 64 + 13, 700001):                # the multi-lane path and its tail
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert T.crc32c(b) == crc_serial(b)
+    # TensorFlow / LevelDB masking: rotate right by 15, add the delta
+    assert T.mask_crc(0) == 0xA282EAD8 and T.mask_crc(0xE3069283) == ((0xE3069283 >> 15 | 0xE3069283 << 17) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_snappy_literal_and_copies():
+    # "abcdabcdabcdXY": literal 'abcd', copy(offset 4, len 8) with a 1-byte offset tag, literal 'XY'
+    stream = bytes([14]) + bytes([(4 - 1) << 2]) + b'abcd' + bytes([((8 - 4) << 2) | 1, 4]) + bytes([(2 - 1) << 2]) + b'XY'
+    assert T._snappy_decompress(stream) == b'abcdabcdabcdXY'
+    # 2-byte-offset copy
+    stream = bytes([12]) + bytes([(6 - 1) << 2]) + b'abcdef' + bytes([((6 - 1) << 2) | 2, 6, 0])
+    assert T._snappy_decompress(stream) == b'abcdefabcdef'
+
+
+def test_table_round_trip_prefix_compression_and_blocks(tmp_path):
+    keys = sorted({('seq2seq/encoder_rnn_%d/%s/cell_0/%s' % (i % 7, d, k)).encode() for i in range(40) for d in ('fw', 'bw')
+                   for k in ('kernel', 'bias', 'kernel/Adam', 'kernel/Adam_1')} | {b''})
+    items = [(k, bytes([i % 251]) * (i % 37 + 1)) for i, k in enumerate(keys)]
+    path = str(tmp_path / 't.index')
+    T.write_table(path, items, block_size=256)                   # many small blocks -> a multi-entry index block
+    assert T.read_table(path) == items
+    buf = open(path, 'rb').read()
+    assert struct.unpack('<Q', buf[-8:])[0] == 0xdb4775248b80fb57 and len(buf) > 48
+    # a flipped byte in a data block is caught by the block checksum
+    bad = bytearray(buf); bad[10] ^= 1
+    open(path, 'wb').write(bytes(bad))
+    with pytest.raises(ValueError, match='checksum'):
+        T.read_table(path)
+    with pytest.raises(ValueError, match='increasing'):
+        T.write_table(path, [(b'b', b''), (b'a', b'')])
+
+
+def test_checkpoint_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(1)
+    arrays = {
+        'seq2seq/subnet_401/encoder_embedding_256_100_0/weights': rng.standard_normal((1, 12, 256, 100)).astype(np.float32),
+        'seq2seq/subnet_401/encoder_embedding_256_100_0/biases': rng.standard_normal(100).astype(np.float32),
+        'seq2seq/encoder_rnn_0/fw/cell_0/kernel': rng.standard_normal((500, 1600)).astype(np.float32),
+        'seq2seq/encoder_rnn_0/fw/cell_0/kernel/ExponentialMovingAverage': rng.standard_normal((500, 1600)).astype(np.float32),
+        'global_step': np.array(1234, np.int64),
+        'beta1_power': np.array(0.5, np.float32),
+        'empty': np.zeros((0, 3), np.float32),
+    }
+    prefix = str(tmp_path / 'model.ckpt-7')
+    T.write_checkpoint(prefix, arrays)
+    assert os.path.exists(prefix + '.index') and os.path.exists(prefix + '.data-00000-of-00001')
+    assert os.path.getsize(prefix + '.data-00000-of-00001') == sum(a.nbytes for a in arrays.values())
+    got = T.read_checkpoint(prefix, check_crc=True)
+    assert set(got) == set(arrays)
+    for k, a in arrays.items():
+        assert got[k].dtype == a.dtype and got[k].shape == a.shape and np.array_equal(got[k], a), k
+    assert dict(T.list_variables(prefix))['seq2seq/encoder_rnn_0/fw/cell_0/kernel'] == (500, 1600)
+    assert set(T.read_checkpoint(prefix, names=['global_step'])) == {'global_step'}
+    # header entry: key "" with num_shards = 1; entries carry dtype DT_FLOAT = 1 and the tensor's byte size
+    table = dict(T.read_table(prefix + '.index'))
+    assert table[b''][:2] == bytes([0x08, 0x01])
+    e = T._parse_entry(table[b'seq2seq/encoder_rnn_0/fw/cell_0/kernel'])
+    assert e['dtype'] == 1 and e['shape'] == [500, 1600] and e['size'] == 500 * 1600 * 4 and e['shard_id'] == 0
+    # corrupting the data file is caught by the per-tensor checksum
+    with open(prefix + '.data-00000-of-00001', 'r+b') as f:
+        f.seek(e['offset'] + 5); f.write(b'\x00\x01\x02')
+    with pytest.raises(ValueError, match='checksum'):
+        T.read_checkpoint(prefix, check_crc=True)
+
+
+def test_model_sizes_are_recovered_from_a_tf_checkpoint(tmp_path):
+    """recover_model_sizes (trainers.py:444-554) walks names and shapes only: it must work on a TensorFlow checkpoint
+    (no .npz next to it), e.g. one written by the reference."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    f32 = lambda *s: np.zeros(s, np.float32)
+    arrays = {
+        'seq2seq/subnet_401/encoder_embedding_256_100_0/weights': f32(1, 12, 256, 100),
+        'seq2seq/subnet_401/encoder_embedding_256_100_0/biases': f32(100),
+        'seq2seq/decoder_embedding_1806_150_0/weights': f32(1806, 150),
+        'seq2seq/decoder_projection_800_1806_0/weights': f32(1806, 800),
+        'seq2seq/encoder_1_projection_800_225_0/weights': f32(800, 225),
+        'seq2seq/encoder_1_projection_225_13_1/weights': f32(13, 225),
+        'seq2seq/decoder_rnn/cell_0/kernel': f32(950, 3200),
+        'seq2seq/decoder_rnn/cell_0/kernel/ExponentialMovingAverage': f32(950, 3200),
+    }
+    for l, d in enumerate((100, 800, 800)):
+        for direction in ('fw', 'bw'):
+            arrays['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, direction)] = f32(d + 400, 1600)
+    T.write_checkpoint(str(tmp_path / 'model.ckpt-3'), arrays)
+    tr = MultiSubjectTrainer.__new__(MultiSubjectTrainer)
+    tr._checkpoint_dir, tr._restore_epoch = str(tmp_path), 3
+    ls, ds, strides, ema = MultiSubjectTrainer.recover_model_sizes(tr)
+    assert ls['encoder_rnn'] == [400, 400, 400] and ls['decoder_rnn'] == [800] and ls['encoder_embedding'] == [100]
+    assert ls['decoder_embedding'] == [150] and ls['encoder_1_projection'] == [225] and ls['decoder_projection'] == []
+    assert ds['401']['encoder_inputs'] == 256 and ds[None]['decoder_targets'] == 1806 and ds[None]['encoder_1_targets'] == 13
+    assert strides['401'] == [12] and ema
