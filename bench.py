@@ -221,7 +221,7 @@ def main():
                 lw['counters'].data_ptr(), eng.sync_err.data_ptr(), eng.num_cus, eng.stream), 3) / S
             extra['lstm_bwd_us_per_step'] = round(us_b, 3)
         extra['lstm_step_flops'] = 2 * B * lay.H * 4 * lay.H * 2      # both directions, one time step of one layer
-        assert int(eng.sync_err.item()) == 0
+        assert int(eng.sync_err[0].item()) == 0
 
     if rank == 0:
         utt = B * world * args.steps / el

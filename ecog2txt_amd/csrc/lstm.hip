@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
     if (own && len > 0 && p.c0) { const float4 c = *(const float4*)(p.c0 + (size_t)b * NH + dir * H + u0); cst[0] = c.x; cst[1] = c.y; cst[2] = c.z; cst[3] = c.w; }
     uint4* gxl = lstm_smem + (size_t)wave * (2 * 4 * 64);
-    float4* xbuf = (float4*)(lstm_smem + 4 * 2 * 4 * 64);         // [wave][gate][lane]
+    float4* xbuf0 = (float4*)(lstm_smem + 4 * 2 * 4 * 64);        // [step parity][wave][gate][lane]
     auto gx_load = [&](int s) {
         const bool act = own && s < len;
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
@@ -758,13 +758,15 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
                         ma &= chk ? a : 0xFFFFFFFFu; mo |= chk ? o : 0u;
                     }
                     const bool f = tag1 ? ((ma & 0x40004000u) == 0x40004000u) : ((mo & 0x40004000u) == 0u);
-                    fresh = fresh && (f || !(s < len2[r2]));          // rows inactive at this step may hold anything
+                    // rows inactive at this step may hold anything; a wave whose unit tile does not exist (odd number of
+                    // unit tiles) owns no slot to take its stamp base from and multiplies zero weights: it never waits
+                    fresh = fresh && (f || !(s < len2[r2]) || !tile_ok);
                 }
                 if (__all(fresh)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
                 if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             if (tag1) {
 #pragma unroll
@@ -773,6 +775,14 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
                     for (int j = 0; j < KH; ++j) st[r2][j] &= 0xBFFFBFFFu;   // strip the stamps before the MFMAs
             }
         }
+        // fragments beyond this half's list are padding (their weights are zero) -- and must BE zero: they were loaded
+        // from k-block 0 without a freshness check, and a stale value still carries the opposite stamp in bit 14, which
+        // turns a saturated h = +-1.0 into +-Inf; Inf x 0 = NaN (seen after ~50 train steps, once the LSTM saturates)
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int j = 0; j < KH; ++j)
+                if (j >= nk) st[r2][j] = (u32x4){0u, 0u, 0u, 0u};
         f32x4 acc[2][4];
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2)
@@ -785,6 +795,11 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[r2][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[j][g], *(bf16x8*)&st[r2][j], acc[r2][g], 0, 0, 0);
         // ---- the other K half of "my" row tile comes from wave ^ 2; mine of the other row tile goes there ----
+        // Double-buffered by step parity: a wave only waits for the k-blocks of ITS K half, so it may enter step s+1 (and
+        // write its partials) while its partner still reads those of step s; the barrier of step s+1 then keeps it from
+        // reaching step s+2's write before the partner has left step s.  (With one buffer this write-after-read race
+        // corrupted the sums as soon as other kernels' traffic skewed the waves: NaN after ~50 train steps.)
+        float4* xbuf = xbuf0 + (s & 1) * (4 * 4 * 64);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 a = khalf ? acc[0][g] : acc[1][g];
@@ -1005,7 +1020,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
 struct LstmBwdPersistArgs {
     LstmBwdArgs a;
     bf16_t* dgx;            // [2 step parities][ndir][RT][4*KQ][64 lanes][8]  dG exchange, MFMA operand order; zero-filled once
-    unsigned* flags;        // [clusters][fstride] per-producer-wave published-step counts (never reset), then [1] launch count
+    unsigned* flags;        // [clusters][fstride]: per-producer-wave published-step counts (never reset); last word of a row = launch count
     int* err;
     int fstride;            // flag words per cluster (>= 4 waves x workgroups of a cluster)
 };
@@ -1053,8 +1068,12 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     float4* part = (float4*)(lstm_smem + 4 * 2 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
     unsigned* flags = pa.flags + (size_t)cl * pa.fstride;
     // flag words only ever grow: they count published steps over ALL launches (launch number x S + steps), so there is no
-    // reset pass; the launch number lives behind the flag words and is bumped by one wave when it is done
-    unsigned* epoch = pa.flags + (size_t)ncl * pa.fstride;
+    // reset pass.  The launch number is kept PER CLUSTER (last word of the cluster's flag row) and bumped by the cluster's
+    // first workgroup when it is done: a cluster cannot finish before every member has started (and read the number),
+    // whereas clusters are independent of each other -- with one global word, a cluster that finished early bumped it
+    // under workgroups of other clusters that the dispatcher had not started yet (CUs busy with side-stream GEMMs), and
+    // those then waited for flag values nobody would ever publish (seen: one 80-ms timeout every ~20 train steps)
+    unsigned* epoch = flags + (pa.fstride - 1);
     const unsigned fbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (unsigned)S;
 
     // operands of step s that do not depend on the recurrence, by LDS-DMA into buffer s&1 (full exec, clamped addresses)
@@ -1151,7 +1170,19 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
                 if ((spins & 1023) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1 << 18)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (spins > (1 << 18)) {
+                    // err[0] = code; err[1..7] = who waited for what (first reporter wins): diagnostics for the host
+                    if (lane == 0 && atomicCAS((int*)pa.err, 0, 3) == 0) {
+                        int badi = -1; unsigned badv = 0;
+                        for (int i = 0; i < nfl; ++i) {
+                            const unsigned v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((int)(v - (fbase + (unsigned)k)) < 0) { badi = i; badv = v; break; }
+                        }
+                        pa.err[1] = blockIdx.x; pa.err[2] = wave; pa.err[3] = k; pa.err[4] = badi; pa.err[5] = (int)badv;
+                        pa.err[6] = (int)fbase; pa.err[7] = (int)__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
             }
             PSTAMP(1);
             // ---- this wave's K quarter of the dG rows of step s+1 (rows without a successor step hold zeros), one row
@@ -1240,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         if (p.dbg && s == S / 2 && lane == 0)
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ug == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef PSTAMP
 }
 
@@ -1319,7 +1350,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
             e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwgw, num_cus);
             return E2T_ERR_ARG;
         }
-        const size_t ldsw = (size_t)(4 * 2 * 4 * 64 + 4 * 4 * 64) * 16;
+        const size_t ldsw = (size_t)(4 * 2 * 4 * 64 + 2 * 4 * 4 * 64) * 16;
 #define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist_wide<K>, dim3(nwgw), dim3(256), ldsw, (hipStream_t)stream, pw); break;
         switch (KH) { E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10) E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13) }
 #undef E2T_PERSIST_CASE

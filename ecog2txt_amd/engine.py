@@ -625,7 +625,7 @@ class Seq2SeqEngine:
         self.persistent = mode != '0'
         self.persistent_fwd, self.persistent_bwd = mode in ('1', 'fwd'), mode in ('1', 'bwd')
         self.num_cus = H.load().e2t_device_cus(self.device.index or 0)
-        self.sync_err = _i32(1, device=dev)      # raised by a bounded in-kernel wait that gave up (persistent recurrence)
+        self.sync_err = _i32(16, device=dev)      # raised by a bounded in-kernel wait that gave up (persistent recurrence)
         self.chains = 1          # >1 measured slower: a step launch is bound by chip-level L2-miss traffic, not latency
         self._side = []
         self._ws = {}
@@ -635,6 +635,7 @@ class Seq2SeqEngine:
         self._on_side = False
         self._wstream = None
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
+        self._ovl = os.environ.get('E2T_OVERLAP', '1')          # diagnostics: 'auxf' / 'stage' / 'defer' subsets
         self.tn = os.environ.get('E2T_TN', '1') != '0'       # weight gradients straight from the K-major activations (no transposes)
         self.trainable = None         # None = everything; else set of segment names
 
@@ -890,7 +891,7 @@ class Seq2SeqEngine:
         # the auxiliary head only needs the encoder; it runs on the side stream under the (latency-bound) decoder
         join = None
         if ws['use_aux']:
-            if self.overlap:
+            if self.overlap and self._ovl in ('1', 'auxf'):
                 join = self.fork_side(aux_forward)
             else:
                 aux_forward()
@@ -973,7 +974,7 @@ class Seq2SeqEngine:
 
     def run_stage(self, main, side, train):
         """main on the current stream, side (if any) on the side stream, joined at the end."""
-        if side is None or not self.overlap:
+        if side is None or not self.overlap or self._ovl == 'auxf':
             if side is not None:
                 side(train)
             main(train)
@@ -986,7 +987,7 @@ class Seq2SeqEngine:
         ws['have_dy'] = [False] * len(self.enc)
         deferred = []
         for i, (main, side, ranges) in enumerate(self.backward_stages(ws)):
-            if after_stage is None and self.overlap and side is not None and i > 0:
+            if after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i > 0:
                 # nobody needs a layer's weight gradients before the optimiser: the side stream just queues them (it is
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
                 deferred.append(self.fork_side(lambda side=side: side(train)))
@@ -1148,16 +1149,32 @@ class Seq2SeqEngine:
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
             if dp:
+                # one graph per stage for the BPTT chain (main stream) and one per stage for its weight-gradient work
+                # (side stream): the all-reduce of a stage's ranges is issued behind the graph that completes them, the
+                # main chain never waits for the side work (same schedule as the single-GPU graph)
                 stages = self.backward_stages(ws)
+                if self._wstream is None:
+                    self._wstream = torch.cuda.Stream(device=self.device)
                 graphs = []
                 for i, (main, side, ranges) in enumerate(stages):
-                    gi = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gi):
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm):
                         if i == 0:
                             self.forward(ws, train=True)
                             ws['have_dy'] = [False] * len(self.enc)
-                        self.run_stage(main, side, True)
-                    graphs.append((gi, ranges))
+                            self.run_stage(main, side, True)         # the aux head's backward feeds the chain: joined here
+                        else:
+                            main(True)
+                    gs = None
+                    if i > 0 and side is not None:
+                        gs = torch.cuda.CUDAGraph()
+                        self._on_side = True
+                        try:
+                            with torch.cuda.graph(gs):
+                                side(True)
+                        finally:
+                            self._on_side = False
+                    graphs.append((gm, gs, ranges))
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
                     self.adam_step(ws['sid'])
@@ -1173,15 +1190,28 @@ class Seq2SeqEngine:
         if not dp:
             g[0].replay()
             return
-        for gi, ranges in g[0]:
-            gi.replay()
-            after(0, ranges)
+        cur = torch.cuda.current_stream(self.device)
+        side_stream = self._wstream
+        for gm, gs, ranges in g[0]:
+            if gs is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)                       # everything the side work reads was enqueued on the main stream before
+                side_stream.wait_event(ev)
+                with torch.cuda.stream(side_stream):
+                    gs.replay()
+                    after(0, ranges)                 # the collective orders itself behind the side stream
+            gm.replay()
+            if gs is None:
+                after(0, ranges)
+        ev = torch.cuda.Event()
+        ev.record(side_stream)
+        cur.wait_event(ev)
         sync.wait()
         g[1].replay()
 
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()
-        if int(self.sync_err.item()) != 0:
+        if int(self.sync_err[0].item()) != 0:
             # the exchange buffers / flag words of the persistent recurrences are now inconsistent: reset them so that
             # the next step starts clean, then fail loudly (E2T_PERSISTENT=0 selects the launch-per-step kernels)
             self.sync_err.zero_()

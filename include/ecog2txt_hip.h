@@ -151,8 +151,8 @@ int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg
  * fit the CUs one-to-one: ceil(B/16) * ndir * ceil(ceil(H/16)/4) of them for H <= 416, ceil(B/32) * ndir * ceil(H/32) for
  * H <= 800; returns non-zero otherwise.  KQ = e2t_bwd_persist_kq(H) (0: not applicable).
  * dgx: bf16 exchange scratch [2][ndir][RTD][4*KQ][64][8] with RTD = ceil(B/16) (H <= 416) or 2*ceil(B/32), zero-filled
- * once by the caller; flags: uint32 [clusters*stride + 1] with clusters*stride = ceil(B/16)*ndir*32 (H <= 416) or
- * ceil(B/32)*ndir*128, zero-filled once by the caller and afterwards only touched by this entry point with the same S
+ * once by the caller; flags: uint32 [clusters*stride] with clusters*stride = ceil(B/16)*ndir*32 (H <= 416) or
+ * ceil(B/32)*ndir*128 (the last word of each cluster's row counts launches), zero-filled once by the caller and afterwards only touched by this entry point with the same S
  * (zero it again after an error); err as for the forward. */
 int e2t_bwd_persist_kq(int H);
 int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,

@@ -33,4 +33,4 @@ for mode in ('1', '0'):
     f = timeit(lambda: lay.fwd(lw, x, ws['dlens'], eng.store.p, True, c0=ws['c0'], steps=(0, S)))
     b = timeit(lambda: lay.bwd_rec(lw, x, ws['dlens'], ws['dHd'].data_ptr(), lay.ldy, True, None, 0, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0']))
     print('decoder S=%d persistent=%s: fwd %.1f us (%.2f us/step)   bwd %.1f us (%.2f us/step incl. pseudo-step)' % (S, mode, f, f / S, b, b / (S + 1)))
-assert int(eng.sync_err.item()) == 0
+assert int(eng.sync_err[0].item()) == 0

@@ -10,7 +10,7 @@ for flag in ('0', '1'):
     os.environ['E2T_PERSISTENT'] = flag
     eng, ws, ospec, P, batch = build(SPECS[name], B, T, L, seed=4, ragged=True)
     eng.forward(ws, train=True); torch.cuda.synchronize()
-    outs.append([lw['Yext'].float().cpu().numpy() for lw in ws['enc']] + [ws['lens_d'].cpu().numpy(), int(eng.sync_err.item())])
+    outs.append([lw['Yext'].float().cpu().numpy() for lw in ws['enc']] + [ws['lens_d'].cpu().numpy(), int(eng.sync_err[0].item())])
 lens = outs[0][-2]
 print('err', outs[1][-1], 'lens', lens[:16], 'S', ws['S'])
 for l in range(len(eng.enc)):

@@ -131,3 +131,34 @@ def test_other_baseline_configs_step(name):
             first = eng.losses(ws)
     last = eng.losses(ws)
     assert np.isfinite(last['total']) and last['decoder'] < first['decoder']
+
+
+def test_long_run_at_full_size_has_no_in_kernel_timeouts():
+    """150 optimisation steps at cfg2 sizes with everything on (persistent recurrences, side-stream overlap): every step
+    must be fast and clean.  Two bugs only showed here: (1) under partial residency -- side-stream GEMMs delay the dispatch
+    of late workgroups -- an early cluster of the persistent BPTT kernel finished and bumped a GLOBAL launch counter under
+    workgroups that had not started yet (80-ms timeout every ~20 steps); (2) once the decoder LSTM saturates (h = +-1.0
+    exactly, after ~50 steps) a stale unchecked padding fragment of the wide forward kernel turned into Inf and Inf x 0
+    into NaN."""
+    import time
+    import bench
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    kw, B, T, L = bench.CONFIGS['cfg2']
+    eng = Seq2SeqEngine(NetSpec(**kw), seed=1)
+    eng.init_params(0)
+    ws = eng.workspace(401, B, T, L)
+    eng.set_batch(ws, bench.synth_batch(kw, B, T, L, 1))
+    for _ in range(3):
+        eng.train_step(ws)
+    first = eng.losses(ws)['decoder']
+    slow = []
+    for step in range(150):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.train_step(ws)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if dt > 20e-3:
+            slow.append((step, dt))
+        assert int(eng.sync_err[0].item()) == 0, ('in-kernel wait timed out', step, eng.sync_err.cpu().numpy().tolist())
+    last = eng.losses(ws)
+    assert not slow, slow
+    assert np.isfinite(last['total']) and last['decoder'] < 0.5 * first, (first, last)

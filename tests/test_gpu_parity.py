@@ -174,7 +174,7 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
             eng.forward(ws, train=True)
             eng.backward(ws, train=True)
         torch.cuda.synchronize()
-        assert int(eng.sync_err.item()) == 0
+        assert int(eng.sync_err[0].item()) == 0
         lw = ws['enc'][-1]
         outs[flag] = dict(Y=lw['Yext'].view(torch.int16).cpu().numpy(), Yd=lw['Ydrop'].view(torch.int16).cpu().numpy(),
                           Cs=lw['Cs'].cpu().numpy(), loss=eng.losses(ws), g=eng.store.g.cpu().numpy(),
