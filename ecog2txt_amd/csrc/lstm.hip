@@ -466,18 +466,16 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
     };
     gx_load(0);
     // Stamp convention (see the state loads below).  Every slot of an exchange buffer ends a launch on the same stamp
-    // (all producers make the same number of writes), so each wave reads the leftover stamp of its own slot once and
-    // starts the new launch on the opposite one: leftovers -- of the previous launch or of the initial fill -- never
-    // look fresh, and no flag, counter or reset pass is needed.
+    // (all producers make the same number of writes); the new launch starts on the opposite one, so leftovers -- of the
+    // previous launch or of the initial fill -- never look fresh, and no flag, counter or reset pass is needed.  The
+    // leftover stamps (bit q = buffer q) live in one word per cluster behind the buffers; the cluster's first workgroup
+    // updates it when it is done -- a cluster cannot finish before all its members have started and read the word.
+    // (Reading the leftover from the wave's own slot instead fails for waves that own none but still check others' rows.)
     const size_t hx_slot = ((((size_t)p.ndir * 0 + dir) * (RB * 4) + rt) * KB + (ut >> 1)) * 512 + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4;
     const size_t hx_buf = (size_t)p.ndir * (RB * 4) * KB * 512;          // elements per step-parity buffer
-    unsigned base[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        unsigned long long v = 0ull;
-        if (own) v = __hip_atomic_load((const unsigned long long*)(pa.hx + q * hx_buf + hx_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base[q] = (__builtin_amdgcn_readfirstlane((unsigned)(v >> 14)) & 1u) ^ 1u;     // lane 0 owns a slot whenever the wave owns any
-    }
+    unsigned* hxw = (unsigned*)(pa.hx + 2 * hx_buf) + cl;
+    const unsigned left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hxw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned base[2] = {(left & 1u) ^ 1u, ((left >> 1) & 1u) ^ 1u};
     long long pts[8];
     const long long t_entry = p.dbg ? wall_clock64() : 0;
 #define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)      // 100 MHz, chip-wide
@@ -621,6 +619,16 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
         if (p.dbg && s == 0 && lane == 0) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = wall_clock64() - t_entry;   // prologue + step 0
     }
+    if (ut == 0 && threadIdx.x == 0) {
+        // stamps the buffers are left with: buffer q was written at steps q, q+2, ... <= S-2 with stamps base, !base, ...
+        unsigned nl = left;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nwr = (S - 1 > q) ? (S - q) / 2 : 0;
+            if (nwr > 0) nl = (nl & ~(1u << q)) | ((((unsigned)(nwr - 1) & 1u) ^ base[q]) << q);
+        }
+        __hip_atomic_store(hxw, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (p.dbg && lane == 0) p.dbg[(size_t)(gridDim.x * 4) * 8 + (size_t)blockIdx.x * 4 + wave] = wall_clock64() - t_entry;
 #undef PSTAMP
 }
@@ -700,13 +708,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
     gx_load(0);
     const size_t hx_slot = ((((size_t)dir) * RTP + rt) * KB + (ut >> 1)) * 512 + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4;
     const size_t hx_buf = (size_t)p.ndir * RTP * KB * 512;       // elements per step-parity buffer
-    unsigned base[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        unsigned long long v = 0ull;
-        if (own) v = __hip_atomic_load((const unsigned long long*)(pa.hx + q * hx_buf + hx_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base[q] = (__builtin_amdgcn_readfirstlane((unsigned)(v >> 14)) & 1u) ^ 1u;
-    }
+    unsigned* hxw = (unsigned*)(pa.hx + 2 * hx_buf) + cl;       // leftover stamps of this cluster's buffers (see the narrow kernel)
+    const unsigned left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hxw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned base[2] = {(left & 1u) ^ 1u, ((left >> 1) & 1u) ^ 1u};
 
     for (int s = 0; s < S; ++s) {
         const bool active = s < len;
@@ -853,6 +857,15 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
             }
         }
         if (s + 1 < S) gx_load(s + 1);
+    }
+    if (ug == 0 && threadIdx.x == 0) {
+        unsigned nl = left;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nwr = (S - 1 > q) ? (S - q) / 2 : 0;
+            if (nwr > 0) nl = (nl & ~(1u << q)) | ((((unsigned)(nwr - 1) & 1u) ^ base[q]) << q);
+        }
+        __hip_atomic_store(hxw, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

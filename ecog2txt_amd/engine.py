@@ -461,7 +461,7 @@ class _Lstm:
             nflag = RT * nd * 32 if kq <= 13 else ceil_div(RT, 2) * nd * 128
             ws['counters'] = torch.zeros(nflag + 1, dtype=torch.int32, device=dev)
             ws['dgx'] = _bf(2, nd, RT if kq <= 13 else 2 * ceil_div(RT, 2), 4 * kq, 64, 8, device=dev)
-        ws['hx'] = _bf(2, nd, 4 * ceil_div(B, 64), self.KB, 64, 8, device=dev)     # in-launch h exchange (persistent recurrence)
+        ws['hx'] = _bf(2 * nd * 4 * ceil_div(B, 64) * self.KB * 64 * 8 + 512, device=dev)     # in-launch h exchange (persistent recurrence)
         return ws
 
     def desc(self, ws, train):

@@ -153,7 +153,9 @@ def test_greedy_sequences_identical(name):
     assert diff.mean() < 0.02
 
 
-@pytest.mark.parametrize('name,B,T,L', [('small_dropout', 70, 50, 6), ('cfg2_widths', 130, 40, 5), ('mid', 256, 100, 8)])
+@pytest.mark.parametrize('name,B,T,L', [('small_dropout', 70, 50, 6), ('cfg2_widths', 130, 40, 5), ('mid', 256, 100, 8),
+                                        # 32-row blocks whose second row tile lies wholly beyond B (stamp state per cluster)
+                                        ('cfg2_widths', 200, 36, 9), ('cfg2_widths', 40, 24, 9)])
 def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypatch):
     """The one-launch weight-stationary recurrences (in-launch exchange between CUs) against the launch-per-step
     kernels.  Forward: bit for bit (outputs, dropped outputs, saved cell states, losses).  Backward: the K = 4H sum
@@ -170,7 +172,7 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
             assert all(lay.persistent_bwd_ok(B, eng.num_cus) for lay in eng.enc)
             if name == 'cfg2_widths':
                 assert eng.dec.persistent_bwd_ok(B, eng.num_cus), 'decoder BPTT (H=800, with the pseudo-step) must be persistent'
-        for _ in range(3):                       # repeated launches: flags / exchange buffers are reused
+        for _ in range(4):                       # repeated launches: flags / exchange buffers are reused
             eng.forward(ws, train=True)
             eng.backward(ws, train=True)
         torch.cuda.synchronize()
