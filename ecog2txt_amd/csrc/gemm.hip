@@ -168,23 +168,24 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     // page, columns beyond M/N are clamped (their products are never stored).  Fragments are then gathered with the
     // transposing LDS read (ds_read_b64_tr_b16, lane mapping verified by scripts/probes/trread_probe.hip).
     auto tn_swz = [](int row) { return (row & 3) | (((row >> 3) & 3) << 2); };
-    auto issue = [&](int t, int buf) {
+    // one DMA instruction (1 KiB) of tile t into stage buf: pieces 0..IA-1 belong to the A tile, IA..IA+IB-1 to the B tile
+    constexpr int NP = IA + IB;
+    auto issue_piece = [&](int t, int buf, int pc_) {
         const int k0 = t * BK;
         uint4* sa = smem + buf * STAGE;
         uint4* sb = sa + BM * 8;
+        const bool isA = pc_ < IA;
+        const int i = isA ? pc_ : pc_ - IA;
         if (TN) {
             constexpr int CA = BM / 8, CB = BN / 8;                // 16-B chunks per k-row
             constexpr int RA = 64 / CA, RB_ = 64 / CB;             // k-rows per DMA instruction
-#pragma unroll
-            for (int i = 0; i < IA; ++i) {
+            if (isA) {
                 const int rb = (wave * IA + i) * RA, r = rb + lane / CA, pc = lane % CA;
                 const int c = pc ^ (tn_swz(r) & (CA - 1));
                 const int gm = min(m0 + c * 8, (p.M - 1) & ~7);    // 8-column chunks; lda % 8 == 0 keeps them in the row
                 const bf16_t* src = (k0 + r < p.K) ? p.A + (size_t)(k0 + r) * p.lda + gm : p.zero_page;
                 dma16_to_lds(src, lds_addr_of(sa + rb * CA));
-            }
-#pragma unroll
-            for (int i = 0; i < IB; ++i) {
+            } else {
                 const int rb = (wave * IB + i) * RB_, r = rb + lane / CB, pc = lane % CB;
                 const int c = pc ^ (tn_swz(r) & (CB - 1));
                 const int gn = min(n0 + c * 8, (p.N - 1) & ~7);
@@ -193,24 +194,28 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
             }
             return;
         }
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
+        if (isA) {
             const int rb = (wave * IA + i) * 8;
             const int r = rb + drow;
             const int gm = min(m0 + r, p.M - 1);
             dma16_to_lds(p.A + (size_t)gm * p.lda + k0 + (dpc ^ (r & 7)) * 8, lds_addr_of(sa + rb * 8));
-        }
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
+        } else {
             const int rb = (wave * IB + i) * 8;
             const int r = rb + drow;
             const int gn = min(n0 + r, p.N - 1);
             dma16_to_lds(p.B + (size_t)gn * p.ldb + k0 + (dpc ^ (r & 7)) * 8, lds_addr_of(sb + rb * 8));
         }
     };
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(t, buf, q);
+    };
     const int frow = lane & 15, fq = lane >> 4;
     typedef short v4s16 __attribute__((ext_vector_type(4)));
-    auto compute = [&](int buf) {
+    // nt >= 0: the DMA pieces of tile nt (into the other stage) are issued between the MFMA rows of the first K block, so
+    // their issue cost (m0 set-up, address VALU, 60-180 cycles of issue each) overlaps MFMA execution instead of
+    // preceding it
+    auto compute = [&](int buf, int nt) {
         const uint4* sa = smem + buf * STAGE;
         const uint4* sb = sa + BM * 8;
 #pragma unroll
@@ -252,10 +257,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
                 for (int j = 0; j < TJ; ++j) { uint4 vb = sb[swz(wn + j * 16 + frow, ch)]; fb[j] = *(bf16x8*)&vb; }
             }
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < TI; ++i) {
+                if (nt >= 0) {
+                    constexpr int PER = (NP + TI - 1) / TI;        // pieces per row of the first K block
+#pragma unroll
+                    for (int q = 0; q < PER; ++q)
+                        if (kb == 0 && i * PER + q < NP) issue_piece(nt, buf ^ 1, i * PER + q);
+                }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -264,8 +276,11 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     for (int t = t0; t < t1; ++t) {
         dma_wait_all();                                        // tile t has landed (only tile t is in flight here)
         __syncthreads();                                       // ... for every wave; and buf[cur^1] is free again
-        if (t + 1 < t1) issue(t + 1, cur ^ 1);
-        compute(cur);
+        // interleaving pays on the 256x256 instance (one workgroup per CU: nobody else hides the issue phase, 4 % faster);
+        // with two workgroups per CU it only delays the loads (TN weight gradients 88 -> 107 us)
+        constexpr bool INTERLEAVE = (BM * BN > 128 * 128);
+        if (!INTERLEAVE && t + 1 < t1) issue(t + 1, cur ^ 1);
+        compute(cur, (INTERLEAVE && t + 1 < t1) ? t + 1 : -1);
         cur ^= 1;
     }
     if (my_tail) {
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
             sb[swz(r, schunk)] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
         }
         __syncthreads();
-        compute(cur);
+        compute(cur, -1);
     }
 
     // epilogue.  MFMA roles are (B-tile fragment, A-tile fragment), so D[i][j]: column j = lane&15 is the
@@ -345,10 +360,21 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p) {
     const EpiCtx ec = epi_ctx(p);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     const bool vec = (p.N & 3) == 0;
-    for (int s = 0; s < p.splits; ++s) {
-        const float* c = p.slab + ((size_t)s * p.M + gm) * p.N + gn0;
-        if (vec) { const float4 t = *(const float4*)c; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-        else for (int r = 0; r < nn; ++r) v[r] += c[r];
+    const size_t sstride = (size_t)p.M * p.N;
+    const float* c0 = p.slab + (size_t)gm * p.N + gn0;
+    auto ld4 = [&](int s) {
+        const float* c = c0 + (size_t)s * sstride;
+        if (vec) return *(const float4*)c;
+        return make_float4(c[0], nn > 1 ? c[1] : 0.f, nn > 2 ? c[2] : 0.f, nn > 3 ? c[3] : 0.f);
+    };
+    // 8 slabs in flight at a time (a dependent chain of 22 loads cost 36 us on a 3-block reduction); the sum keeps the
+    // split order
+    for (int s = 0; s < p.splits; s += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (s + u < p.splits) ? ld4(s + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (s + u < p.splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
     }
     if (p.bias) for (int r = 0; r < nn; ++r) if (gn0 + r < ec.Nst) v[r] += p.bias[gn0 + r];
     bool rowvalid = true;

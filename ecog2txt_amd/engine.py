@@ -891,7 +891,7 @@ class Seq2SeqEngine:
         # the auxiliary head only needs the encoder; it runs on the side stream under the (latency-bound) decoder
         join = None
         if ws['use_aux']:
-            if self.overlap and self._ovl in ('1', 'auxf'):
+            if self.overlap and self._ovl in ('1', 'auxf', 'tail'):
                 join = self.fork_side(aux_forward)
             else:
                 aux_forward()
@@ -986,8 +986,18 @@ class Seq2SeqEngine:
     def backward(self, ws, train=True, after_stage=None):
         ws['have_dy'] = [False] * len(self.enc)
         deferred = []
-        for i, (main, side, ranges) in enumerate(self.backward_stages(ws)):
-            if after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i > 0:
+        held = []
+        stages = self.backward_stages(ws)
+        for i, (main, side, ranges) in enumerate(stages):
+            if after_stage is None and self.overlap and self._ovl == 'tail' and i > 0:
+                # diagnostics: keep the BPTT chain alone on the chip, all weight gradients afterwards on both streams
+                if side is not None:
+                    held.append(side)
+                if i == len(stages) - 1:
+                    for sd in held:
+                        deferred.append(self.fork_side(lambda sd=sd: sd(train)))
+                main(train)
+            elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i > 0:
                 # nobody needs a layer's weight gradients before the optimiser: the side stream just queues them (it is
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
                 deferred.append(self.fork_side(lambda side=side: side(train)))
