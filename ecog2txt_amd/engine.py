@@ -501,9 +501,10 @@ class _Lstm:
             launch(0, 0, e.stream)
 
     def bwd_rec(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
-                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False):
+                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False, before_d_in=None):
         """BPTT + input gradient (the critical path of the backward pass).  d_in_bf16_mask=(src_ptr, ld): emit the input
-        gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue)."""
+        gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue).  d_in_ptr=None: BPTT
+        only (bwd_d_in() later, e.g. on another stream); before_d_in() runs between the two (a stream join)."""
         e = self.eng
         st = e.store
         M, Mk, S, B = ws['M'], ws['Mk'], ws['S'], ws['B']
@@ -525,13 +526,21 @@ class _Lstm:
                                             e.sync_err.data_ptr(), e.num_cus, e.stream)
         else:
             e.run_chains(B, launch)
+        if before_d_in is not None:
+            before_d_in()
         if d_in_ptr is not None:
-            if d_in_bf16_mask is not None:
-                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
-                       rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
-            else:
-                e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                       rk(self.N4), accumulate=d_in_accumulate)
+            self.bwd_d_in(ws, d_in_ptr, d_in_ld, d_in_bf16_mask, d_in_alpha, d_in_accumulate)
+
+    def bwd_d_in(self, ws, d_in_ptr, d_in_ld, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False):
+        """Input gradient dG . W_x of the dG that bwd_rec left in ws."""
+        e = self.eng
+        M = ws['M']
+        if d_in_bf16_mask is not None:
+            e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
+                   rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
+        else:
+            e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
+                   rk(self.N4), accumulate=d_in_accumulate)
 
     def bwd_weights(self, ws, x_ptr):
         """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the
@@ -985,6 +994,7 @@ class Seq2SeqEngine:
 
     def backward(self, ws, train=True, after_stage=None):
         ws['have_dy'] = [False] * len(self.enc)
+        ws['_aux_join'] = None
         deferred = []
         held = []
         stages = self.backward_stages(ws)
@@ -997,6 +1007,10 @@ class Seq2SeqEngine:
                     for sd in held:
                         deferred.append(self.fork_side(lambda sd=sd: sd(train)))
                 main(train)
+            elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i == 0:
+                # auxiliary head: joined where the main branch first touches dY[aux_layer] (_bwd_enc_rec)
+                ws['_aux_join'] = self.fork_side(lambda side=side: side(train))
+                main(train)
             elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i > 0:
                 # nobody needs a layer's weight gradients before the optimiser: the side stream just queues them (it is
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
@@ -1006,6 +1020,9 @@ class Seq2SeqEngine:
                 self.run_stage(main, side, train)
             if after_stage:
                 after_stage(i, ranges)
+        if ws.get('_aux_join') is not None:
+            self.join_side(ws['_aux_join'])
+            ws['_aux_join'] = None
         for j in deferred:
             self.join_side(j)
 
@@ -1016,12 +1033,14 @@ class Seq2SeqEngine:
         store.view('dec.emb', store.g).zero_()          # the embedding scatter-add accumulates by atomics
         self.proj.bwd_dx(ws['proj'], ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train)
         self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
-                         ws['de'].data_ptr(), self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
+                         None, self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
 
     def _bwd_head_weights(self, ws, train):
         """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them."""
         s, store = self.spec, self.store
         self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
+        # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
+        self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
         self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
         dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
         lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
@@ -1036,6 +1055,16 @@ class Seq2SeqEngine:
         x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
         dY = ws['dY'][l].data_ptr() if have_dy[l] else None
         fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
+        aj = ws.get('_aux_join')
+        if aj is not None and s.aux_layer is not None and (l == s.aux_layer or l == s.aux_layer + 1):
+            # the auxiliary head's backward runs on the side stream since the start of the backward pass; it writes
+            # dY[aux_layer], which this layer's input gradient accumulates onto (l = aux_layer + 1) or whose BPTT reads
+            # (l = aux_layer, when the head taps the top layer)
+            ws['_aux_join'] = None
+            if l == s.aux_layer:
+                self.join_side(aj)
+            else:
+                fin['before_d_in'] = lambda: self.join_side(aj)
         if l > 0:
             lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy,
                         d_in_accumulate=have_dy[l - 1], **fin)
