@@ -473,12 +473,17 @@ class _Lstm:
         d.drop_seed, d.drop_step, d.drop_stream = e.seed, e.step_t.data_ptr(), self.stream
         return d
 
-    def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None):
+    def fwd_gx(self, ws, x_ptr, src):
+        """Input projection of all time steps (no recurrence in it: may run ahead on another stream)."""
+        self.eng.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, ws['M'], self.N4,
+                      self.in_ld, bias=self.bias_ptr(src))
+
+    def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None, gx_done=False):
         e = self.eng
         M = ws['M']
         if steps is None:
-            e.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, M, self.N4, self.in_ld,
-                   bias=self.bias_ptr(src))
+            if not gx_done:
+                self.fwd_gx(ws, x_ptr, src)
             steps = (0, ws['S'])
         if e.persistent_fwd and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
             # whole sequence in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_fwd_persist)
@@ -846,7 +851,7 @@ class Seq2SeqEngine:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
 
     # ------------------------------------------------------------------ forward
-    def encode(self, ws, src, train):
+    def encode(self, ws, src, train, after_layer=None):
         s = self.spec
         B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
         st = self.stream
@@ -857,9 +862,11 @@ class Seq2SeqEngine:
                   bias=self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed), relu=s.conv_relu, out_bf16=True,
                   drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B))
         x = ws['E'].data_ptr()
-        for lay, lw in zip(self.enc, ws['enc']):
+        for l, (lay, lw) in enumerate(zip(self.enc, ws['enc'])):
             lay.fwd(lw, x, ws['lens_d'], src, train)
             x = lw['Ydrop'].data_ptr()
+            if after_layer is not None:
+                after_layer(l)
         last, lw = self.enc[-1], ws['enc'][-1]
         # encoder final state -> block 0 of the decoder's ext output array, and c0
         lib.e2t_final_state(lw['Yext'].data_ptr(), last.ldy, lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), B, last.H,
@@ -871,13 +878,11 @@ class Seq2SeqEngine:
         src = getattr(self.store, which or 'p')
         B, T, L, S, M, Md, N = ws['B'], ws['T'], ws['L'], ws['S'], ws['M'], ws['Md'], s.decimation
         st = self.stream
-        self.encode(ws, src, train)
         ws['use_aux'] = bool(self.aux and with_aux and s.aux_scale != 0.0)
+        cat = s.aux_dist == 'categorical'
 
-        def aux_forward():
+        def aux_targets():
             st = self.stream
-            cat = s.aux_dist == 'categorical'
-            k = s.aux_layer
             if cat:
                 lib.e2t_seq_lengths_i32(ws['auxT'].data_ptr(), B, T, PAD_ID, N, ws['tlens'].data_ptr(), ws['tlens_d'].data_ptr(), st)
                 lib.e2t_gather_rev_decim_i32(ws['auxT'].data_ptr(), ws['tlens'].data_ptr(), B, T, N, ws['At'].data_ptr(), st)
@@ -885,6 +890,10 @@ class Seq2SeqEngine:
                 lib.e2t_seq_lengths_f32(ws['auxT'].data_ptr(), B, T, s.aux_dim, N, ws['tlens'].data_ptr(), ws['tlens_d'].data_ptr(), st)
                 lib.e2t_gather_rev_decim_f32(ws['auxT'].data_ptr(), ws['tlens'].data_ptr(), B, T, s.aux_dim, N, ws['At'].data_ptr(), st)
             lib.e2t_sum_i32(ws['tlens_d'].data_ptr(), B, ws['nval'].data_ptr(), st)
+
+        def aux_forward():
+            st = self.stream
+            k = s.aux_layer
             out = self.aux.fwd(ws['aux'], ws['enc'][k]['Ydrop'].data_ptr(), src, train)
             if cat:
                 lib.e2t_softmax_ce(out.data_ptr(), s.aux_dim, M, s.aux_dim, ws['At'].data_ptr(), ws['tlens_d'].data_ptr(), B,
@@ -897,29 +906,48 @@ class Seq2SeqEngine:
                             rk(s.aux_dim), st)
                 lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0 / s.aux_dim,
                                 ws['loss'].data_ptr() + 4, st)
-        # the auxiliary head only needs the encoder; it runs on the side stream under the (latency-bound) decoder
-        join = None
-        if ws['use_aux']:
-            if self.overlap and self._ovl in ('1', 'auxf', 'tail'):
-                join = self.fork_side(aux_forward)
-            else:
-                aux_forward()
+
+        def dec_prep():
+            # teacher-forced decoder inputs (tokens, embedding, input projection) and the auxiliary targets: nothing of
+            # the encoder in them, so they run on the side stream next to the (HBM-bound) front-end instead of between
+            # encoder and decoder
+            st = self.stream
+            lib.e2t_seq_lengths_i32(ws['Y'].data_ptr(), B, L, PAD_ID, 1, ws['dlens'].data_ptr(), None, st)
+            lib.e2t_sum_i32(ws['dlens'].data_ptr(), B, ws['ntok'].data_ptr(), st)
+            lib.e2t_decoder_tokens(ws['Y'].data_ptr(), B, L, EOS_ID, ws['U'].data_ptr(), ws['Tg'].data_ptr(), st)
+            dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
+            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), 0, Md, s.dec_embed, ws['e'].data_ptr(), self.E8,
+                              C.byref(dr), st)
+            self.dec.fwd_gx(ws['dec'], ws['e'].data_ptr(), src)
+            if ws['use_aux']:
+                aux_targets()
+        ahead = self.overlap and self._ovl in ('1', 'auxf', 'tail')
+        jdec = self.fork_side(dec_prep) if ahead else None
+        joins = []
+
+        def after_layer(l):
+            # the auxiliary head taps layer aux_layer: its forward starts as soon as that layer is done (side stream,
+            # under the layers above), so that the decoder has the chip to itself
+            if ahead and ws['use_aux'] and l == s.aux_layer:
+                joins.append(self.fork_side(aux_forward))
+        self.encode(ws, src, train, after_layer)
+        if ws['use_aux'] and not ahead:
+            aux_targets()
+            aux_forward()
         # decoder (teacher forced)
-        lib.e2t_seq_lengths_i32(ws['Y'].data_ptr(), B, L, PAD_ID, 1, ws['dlens'].data_ptr(), None, st)
-        lib.e2t_sum_i32(ws['dlens'].data_ptr(), B, ws['ntok'].data_ptr(), st)
-        lib.e2t_decoder_tokens(ws['Y'].data_ptr(), B, L, EOS_ID, ws['U'].data_ptr(), ws['Tg'].data_ptr(), st)
-        dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
-        lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), 0, Md, s.dec_embed, ws['e'].data_ptr(), self.E8,
-                          C.byref(dr), st)
-        self.dec.fwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], src, train, c0=ws['c0'])
+        if jdec is not None:
+            self.join_side(jdec)
+        else:
+            dec_prep()
+        self.dec.fwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], src, train, c0=ws['c0'], gx_done=True)
         logits = self.proj.fwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), src, train)
         lib.e2t_softmax_ce(logits.data_ptr(), s.vocab, Md, s.vocab, ws['Tg'].data_ptr(), ws['dlens'].data_ptr(), B,
                            ws['ntok'].data_ptr(), s.dec_scale, ws['rowloss'].data_ptr(), ws['pred'].data_ptr(),
                            ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), rk(s.vocab), st)
         lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr(), st)
         lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr() + 8, st)
-        if join is not None:
-            self.join_side(join)
+        for j in joins:
+            self.join_side(j)
 
     # ------------------------------------------------------------------ backward
     def backward_stages(self, ws):
