@@ -253,16 +253,103 @@ __global__ __launch_bounds__(64) void k_pack_frag(const float* src, long sn, lon
 // workgroup; for sources that are contiguous along the destination's columns), kind 1 = MFMA fragment image
 // (4 fragments per workgroup), kind 2 = transposing cast (source contiguous along the destination's ROWS, s0 == 1):
 // 64x64 tiles through LDS so that both the fp32 reads and the bf16 writes are coalesced.
+// E2T_PACK_UNITS work units per workgroup: the descriptor search and the launch overhead of a workgroup are paid once
+// per 8 units (42 k single-unit workgroups spent most of their life searching)
+__device__ __forceinline__ int pack_units(const e2t_pack_desc& d) {
+    const int NT = (d.d0 + 15) / 16;
+    switch (d.kind) {
+        case 0: return d.d0 * ((d.d1 + 255) / 256);
+        case 3: return d.d0 * ((d.d1 + 1023) / 1024);
+        case 2: case 4: return ((d.d0 + 63) / 64) * ((d.d1 + 63) / 64);
+        case 5: return ((NT + 3) / 4) * d.ld;
+        case 6: return NT * d.ld;
+        default: return (NT * d.ld + 3) / 4;
+    }
+}
+__device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, const float* src, bf16_t* dst);
 __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, int ndesc, const float* base) {
     // binary search for the descriptor that owns this workgroup (uniform)
     int lo = 0, hi = ndesc - 1;
     const int bid = blockIdx.x;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1; }
     const e2t_pack_desc d = descs[lo];
-    const int lb = bid - d.first_block;
+    const int units = pack_units(d);
     const float* src = base + d.src_off;
     bf16_t* dst = (bf16_t*)d.dst;
-    if (d.kind == 2) {
+    if (d.kind == 3) {
+        // E2T_PACK_UNITS units per workgroup with all their loads in flight at once (a workgroup per unit is bound by its
+        // own start-up + one memory round trip)
+        const int u0 = (bid - d.first_block) * E2T_PACK_UNITS;
+        const int cb = (d.d1 + 1023) / 1024;
+        float4 v[E2T_PACK_UNITS]; size_t o[E2T_PACK_UNITS]; bool ok[E2T_PACK_UNITS];
+#pragma unroll
+        for (int j = 0; j < E2T_PACK_UNITS; ++j) {
+            const int u = u0 + j, r = u / cb, c = (u - r * cb) * 1024 + threadIdx.x * 4;
+            ok[j] = u < units && c < d.d1;
+            o[j] = (size_t)r * d.ld + c;
+            if (ok[j]) v[j] = *(const float4*)(src + (size_t)r * d.s0 + c);
+        }
+#pragma unroll
+        for (int j = 0; j < E2T_PACK_UNITS; ++j)
+            if (ok[j]) *(ushort4*)(dst + o[j]) = make_ushort4(f2bf(v[j].x), f2bf(v[j].y), f2bf(v[j].z), f2bf(v[j].w));
+        return;
+    }
+    if (d.kind == 1 && d.s1 == 1 && ((d.s0 | d.src_off | d.d1) & 3) == 0) {
+        // fragment images of a source contiguous along k: two 16-B loads per lane and fragment, E2T_PACK_UNITS x 4 fragments
+        // per workgroup in flight
+        const int u0 = (bid - d.first_block) * E2T_PACK_UNITS;
+        const int KB = d.ld, lane = threadIdx.x & 63, NT = (d.d0 + 15) / 16;
+        float4 a[E2T_PACK_UNITS], b2[E2T_PACK_UNITS]; bool ok[E2T_PACK_UNITS];
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < E2T_PACK_UNITS; ++j) {
+            const int f = (u0 + j) * 4 + (threadIdx.x >> 6);
+            ok[j] = f < NT * KB;
+            const int nt = f / KB, kb = f - nt * KB;
+            const int n = nt * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 8;
+            const float* sp = src + (size_t)n * d.s0 + k0;
+            a[j] = (ok[j] && n < d.d0 && k0 < d.d1) ? *(const float4*)sp : z;
+            b2[j] = (ok[j] && n < d.d0 && k0 + 4 < d.d1) ? *(const float4*)(sp + 4) : z;
+        }
+#pragma unroll
+        for (int j = 0; j < E2T_PACK_UNITS; ++j) {
+            if (!ok[j]) continue;
+            const int f = (u0 + j) * 4 + (threadIdx.x >> 6);
+            uint4 v;
+            v.x = f2bf(a[j].x) | ((unsigned)f2bf(a[j].y) << 16); v.y = f2bf(a[j].z) | ((unsigned)f2bf(a[j].w) << 16);
+            v.z = f2bf(b2[j].x) | ((unsigned)f2bf(b2[j].y) << 16); v.w = f2bf(b2[j].z) | ((unsigned)f2bf(b2[j].w) << 16);
+            ((uint4*)dst)[(size_t)f * 64 + lane] = v;
+        }
+        return;
+    }
+    const int G = (d.kind == 1) ? E2T_PACK_UNITS : 1;
+    const int u0 = (bid - d.first_block) * G;
+    for (int u = u0; u < min(units, u0 + G); ++u) pack_unit(d, u, src, dst);
+}
+__device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, const float* src, bf16_t* dst) {
+    if (d.kind == 4) {
+        // kind 2 with 16-B loads along the source's contiguous direction and 8-B stores (d0 % 4 == 0, d1 % 4 == 0, s1 % 4 == 0)
+        __shared__ float tile[64][65];                      // tile[c][r]
+        const int tcn = (d.d1 + 63) / 64;
+        const int tr = lb / tcn, tc = lb - tr * tcn;
+        const int a4 = (threadIdx.x & 15) * 4, b = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tc * 64 + b + 16 * i, r = tr * 64 + a4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < d.d0 && c < d.d1) v = *(const float4*)(src + (size_t)r + (size_t)c * d.s1);
+            float* t = &tile[b + 16 * i][a4];
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = tr * 64 + b + 16 * i, c = tc * 64 + a4;
+            if (r < d.d0 && c < d.d1)
+                *(ushort4*)(dst + (size_t)r * d.ld + c) = make_ushort4(f2bf(tile[a4][b + 16 * i]), f2bf(tile[a4 + 1][b + 16 * i]),
+                                                                         f2bf(tile[a4 + 2][b + 16 * i]), f2bf(tile[a4 + 3][b + 16 * i]));
+        }
+    } else if (d.kind == 2) {
         __shared__ float tile[64][65];
         const int tcn = (d.d1 + 63) / 64;
         const int tr = lb / tcn, tc = lb - tr * tcn;
@@ -282,6 +369,57 @@ __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, 
         const int cb = (d.d1 + 255) / 256;                 // column blocks per row
         const int r = lb / cb, c = (lb - r * cb) * 256 + threadIdx.x;
         if (r < d.d0 && c < d.d1) dst[(size_t)r * d.ld + c] = f2bf(src[(size_t)r * d.s0 + (size_t)c * d.s1]);
+    } else if (d.kind == 6) {
+        // the four per-gate fragment images of a gate-interleaved LSTM kernel (TF layout [k][unit*4 + gate]) from ONE pass
+        // over the source: a [32 k][16 units x 4 gates] block is staged with 16-B loads (256 B contiguous per k-row), wave g
+        // emits the fragment of gate g.  d0 = units, d1 = K, s1 = k stride, ld = KB; image g starts at fragment g*UT*KB.
+        __shared__ float blk[32][68];
+        const int KB = d.ld, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int UT = (d.d0 + 15) / 16;
+        const int ut = lb / KB, kb = lb - ut * KB;
+        const int n4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kl = (threadIdx.x >> 4) + 16 * i;
+            const int np = ut * 64 + n4, k = kb * 32 + kl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (np < 4 * d.d0 && k < d.d1) v = *(const float4*)(src + (size_t)np + (size_t)k * d.s1);
+            *(float4*)&blk[kl][n4] = v;
+        }
+        __syncthreads();
+        bf16_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(blk[(lane >> 4) * 8 + j][(lane & 15) * 4 + g]);
+        uint4 v;
+        v.x = o[0] | ((unsigned)o[1] << 16); v.y = o[2] | ((unsigned)o[3] << 16);
+        v.z = o[4] | ((unsigned)o[5] << 16); v.w = o[6] | ((unsigned)o[7] << 16);
+        ((uint4*)dst)[(((size_t)g * UT + ut) * KB + kb) * 64 + lane] = v;
+    } else if (d.kind == 5) {
+        // kind 1 for sources contiguous along n (s0 == 1): a workgroup stages a [32 k][64 n] block with 16-B loads (256 B
+        // contiguous per k-row) and each wave emits one of the 4 fragments (caller: s1, src_off, d0 multiples of 4)
+        __shared__ float blk[32][68];
+        const int KB = d.ld, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int NT = (d.d0 + 15) / 16;
+        const int ntq = lb / KB, kb = lb - ntq * KB;
+        const int n4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kl = (threadIdx.x >> 4) + 16 * i;
+            const int n = ntq * 64 + n4, k = kb * 32 + kl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < d.d0 && k < d.d1) v = *(const float4*)(src + (size_t)n + (size_t)k * d.s1);
+            *(float4*)&blk[kl][n4] = v;
+        }
+        __syncthreads();
+        const int nt = ntq * 4 + w;
+        if (nt >= NT) return;
+        bf16_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(blk[(lane >> 4) * 8 + j][w * 16 + (lane & 15)]);
+        uint4 v;
+        v.x = o[0] | ((unsigned)o[1] << 16); v.y = o[2] | ((unsigned)o[3] << 16);
+        v.z = o[4] | ((unsigned)o[5] << 16); v.w = o[6] | ((unsigned)o[7] << 16);
+        ((uint4*)dst)[((size_t)nt * KB + kb) * 64 + lane] = v;
     } else {
         const int KB = d.ld, lane = threadIdx.x & 63;
         const int f = lb * 4 + (threadIdx.x >> 6);          // fragment index nt*KB + kb
@@ -290,9 +428,10 @@ __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, 
         const int nt = f / KB, kb = f - nt * KB;
         const int n = nt * 16 + (lane & 15);
         bf16_t o[8];
+        const int k0 = kb * 32 + (lane >> 4) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = kb * 32 + (lane >> 4) * 8 + j;
+            const int k = k0 + j;
             o[j] = (n < d.d0 && k < d.d1) ? f2bf(src[(size_t)n * d.s0 + (size_t)k * d.s1]) : (bf16_t)0;
         }
         uint4 v;

@@ -410,8 +410,11 @@ class _Lstm:
             ops.append(('cast', st.ptr(self.name + '.Wx', src, r0 * N4), N4, 1, n, N4, self.WxB, 0, k0))
         for d in range(self.ndir):
             base = d * Hh * 4 * Hh
-            for g in range(4):
-                ops.append(('frag', st.ptr(self.name + '.Wh', src, base + g), 4, 4 * Hh, Hh, Hh, self.WhF[d, g]))
+            if (4 * Hh) % 4 == 0 and self.WhF[d].is_contiguous():
+                ops.append(('frag4', st.ptr(self.name + '.Wh', src, base), 4, 4 * Hh, Hh, Hh, self.WhF[d, 0]))
+            else:
+                for g in range(4):
+                    ops.append(('frag', st.ptr(self.name + '.Wh', src, base + g), 4, 4 * Hh, Hh, Hh, self.WhF[d, g]))
             ops.append(('frag', st.ptr(self.name + '.Wh', src, base), 4 * Hh, 1, Hh, 4 * Hh, self.WhB[d]))
 
     def bias_ptr(self, src):
@@ -758,6 +761,13 @@ class Seq2SeqEngine:
             ops.append(('cast', st.ptr('dec.emb', base), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
             self.dec.pack_ops(ops, base)
             self.proj.pack_ops(ops, base)
+            if os.environ.get('E2T_PACK_ONLY'):          # diagnostics (scripts/bench_pack.py): a subset of the images
+                want = os.environ['E2T_PACK_ONLY']
+                def kind_of(op):
+                    if op[0] != 'cast':
+                        return 'frag4' if op[0] == 'frag4' else 'fragK'
+                    return 'tr' if (op[2] == 1 and op[3] != 1) else 'cast'
+                ops = [op for op in ops if kind_of(op) == want]
             descs = (H.PackDesc * len(ops))()
             nblk = 0
             p0 = base.data_ptr()
@@ -768,15 +778,33 @@ class Seq2SeqEngine:
                     _, sp, rs, cs, R, Cn, dst, k0, r0 = op
                     ld = dst.shape[-1]
                     tr = rs == 1 and cs != 1                 # source contiguous along the image's rows: tiled transpose
-                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = (2 if tr else 0), (sp - p0) // 4, rs, cs, R, Cn, ld
-                    d.dst = dst.data_ptr() + 2 * (r0 * ld + k0)
-                    nblk += ceil_div(R, 64) * ceil_div(Cn, 64) if tr else R * ceil_div(Cn, 256)
+                    off = (sp - p0) // 4
+                    dptr = dst.data_ptr() + 2 * (r0 * ld + k0)
+                    al = off % 4 == 0 and ld % 4 == 0 and dptr % 8 == 0 and Cn % 4 == 0       # 16-B loads / 8-B stores
+                    if tr:
+                        kind = 4 if (al and R % 4 == 0 and cs % 4 == 0) else 2
+                        units = ceil_div(R, 64) * ceil_div(Cn, 64)
+                    else:
+                        kind = 3 if (al and cs == 1 and rs % 4 == 0) else 0
+                        units = R * ceil_div(Cn, 1024) if kind == 3 else R * ceil_div(Cn, 256)
+                    nblk += ceil_div(units, H.PACK_UNITS if kind == 3 else 1)
+                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = kind, off, rs, cs, R, Cn, ld
+                    d.dst = dptr
                 else:
                     _, sp, ns, ks, Nn, Kk, dst = op
                     KB = ceil_div(Kk, 32)
-                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = 1, (sp - p0) // 4, ns, ks, Nn, Kk, KB
+                    off = (sp - p0) // 4
+                    tiled = ns == 1 and ks % 4 == 0 and off % 4 == 0 and Nn % 4 == 0      # contiguous along n: staged via LDS
+                    four = op[0] == 'frag4' and off % 4 == 0                               # gate-interleaved: 4 images, one pass
+                    if op[0] == 'frag4' and not four:
+                        raise RuntimeError('unaligned gate-interleaved weight segment')
+                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = (6 if four else 5 if tiled else 1), off, ns, ks, Nn, Kk, KB
                     d.dst = dst.data_ptr()
-                    nblk += ceil_div(ceil_div(Nn, 16) * KB, 4)
+                    if four:
+                        units = ceil_div(Nn, 16) * KB
+                    else:
+                        units = ceil_div(ceil_div(Nn, 16), 4) * KB if tiled else ceil_div(ceil_div(Nn, 16) * KB, 4)
+                    nblk += ceil_div(units, 1 if (tiled or four) else H.PACK_UNITS)
             raw = bytes(descs)
             self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
             self._pack_table = (len(ops), nblk)

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip.so')
 
 GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK = 1, 2, 4, 8, 16
+PACK_UNITS = 4            # E2T_PACK_UNITS (include/ecog2txt_hip.h): work units of a pack descriptor per workgroup
 
 
 class Dropout(C.Structure):

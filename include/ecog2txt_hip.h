@@ -102,12 +102,23 @@ int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int l
 /* ---- weight packing: fp32 masters -> bf16 operand images (after every optimiser step) ---- */
 int e2t_cast_pack(const float* src, long row_stride, long col_stride, int R, int C, void* dst, int ld_dst, void* stream);
 int e2t_pack_frag(const float* src, long n_stride, long k_stride, int Nn, int Kk, void* dst, void* stream);
-/* every image in one launch: device table of descriptors (src = base + src_off) */
+/* every image in one launch: device table of descriptors (src = base + src_off).  A descriptor's work is cut into units
+ * (the workgroup counts quoted per kind below); for kinds 1 and 3 a workgroup processes E2T_PACK_UNITS consecutive
+ * units (all their loads in flight at once), so such a descriptor owns ceil(units / E2T_PACK_UNITS) workgroups. */
+#define E2T_PACK_UNITS 4
 typedef struct e2t_pack_desc {
     int kind;            /* 0: dst[r][c] = bf16(src[r*s0 + c*s1]), r < d0, c < d1, leading dim ld
                             1: MFMA fragment image of Bn[n][k] = src[n*s0 + k*s1], n < d0, k < d1, ld = ceil(d1/32)
                             2: as 0 for sources with s0 == 1 (contiguous along r): 64x64 tiles through LDS,
-                               ceil(d0/64)*ceil(d1/64) workgroups instead of d0*ceil(d1/256) */
+                               ceil(d0/64)*ceil(d1/64) workgroups instead of d0*ceil(d1/256)
+                            3: as 0, four columns per thread (s1 == 1; d1, s0, src_off, ld multiples of 4; dst 8-B aligned):
+                               d0*ceil(d1/1024) workgroups
+                            4: as 2 with 16-B loads / 8-B stores (d0, d1, s1, src_off, ld multiples of 4; dst 8-B aligned)
+                            5: as 1 for s0 == 1 (contiguous along n; d0, s1, src_off multiples of 4): [32 k][64 n] blocks
+                               through LDS, ceil(ceil(d0/16)/4) * ceil(d1/32) workgroups
+                            6: the four per-gate fragment images [4][ceil(d0/16)][ld] (contiguous at dst) of a gate-interleaved
+                               source Bn_g[n][k] = src[(n*4 + g) + k*s1], n < d0 units, k < d1 (s1, src_off multiples of 4):
+                               one pass over the source, ceil(d0/16) * ceil(d1/32) workgroups */
     int first_block;     /* first 256-thread workgroup of this descriptor (exclusive prefix, ascending) */
     long long src_off;   /* element offset into the fp32 base */
     long long s0, s1;
