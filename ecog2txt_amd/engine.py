@@ -879,11 +879,13 @@ class Seq2SeqEngine:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
 
     # ------------------------------------------------------------------ forward
-    def encode(self, ws, src, train, after_layer=None):
+    def encode(self, ws, src, train, after_layer=None, after_first=None):
         s = self.spec
         B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
         st = self.stream
         lib.e2t_seq_lengths_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
+        if after_first is not None:
+            after_first()
         lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
         self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
                   M, s.enc_embed, ws['Kc8'],
@@ -950,15 +952,26 @@ class Seq2SeqEngine:
             if ws['use_aux']:
                 aux_targets()
         ahead = self.overlap and self._ovl in ('1', 'auxf', 'tail')
-        jdec = self.fork_side(dec_prep) if ahead else None
         joins = []
+        pend = {}
+        ev0 = self.fork_point() if ahead else None
+
+        def after_first():
+            # (side work is enqueued AFTER the main branch's next kernel: see fork_point)
+            if ahead:
+                pend['dec'] = self.run_side(ev0, dec_prep)
 
         def after_layer(l):
             # the auxiliary head taps layer aux_layer: its forward starts as soon as that layer is done (side stream,
             # under the layers above), so that the decoder has the chip to itself
             if ahead and ws['use_aux'] and l == s.aux_layer:
-                joins.append(self.fork_side(aux_forward))
-        self.encode(ws, src, train, after_layer)
+                pend['aux_ev'] = self.fork_point()
+            elif 'aux_ev' in pend:
+                joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
+        self.encode(ws, src, train, after_layer, after_first)
+        if 'aux_ev' in pend:
+            joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
+        jdec = pend.get('dec')
         if ws['use_aux'] and not ahead:
             aux_targets()
             aux_forward()
@@ -1034,6 +1047,30 @@ class Seq2SeqEngine:
             join.record(self._wstream)
         return join
 
+    def fork_point(self):
+        """Event marking 'everything enqueued so far on the current stream'; run_side(ev, fn) later hangs fn off it.  Two
+        phases because the ORDER of enqueueing matters inside a captured graph: the branch whose first node is created
+        first keeps the parent's hardware queue, the other one pays a cross-queue hand-off (~10 us, measured) -- so the
+        critical branch is enqueued first and the side work afterwards."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def run_side(self, ev, fn):
+        """fn() on the side stream, ordered after fork_point() event ev.  Returns the event to pass to join_side()."""
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(device=self.device)
+        self._wstream.wait_event(ev)
+        with torch.cuda.stream(self._wstream):
+            self._on_side = True
+            try:
+                fn()
+            finally:
+                self._on_side = False
+            join = torch.cuda.Event()
+            join.record(self._wstream)
+        return join
+
     def join_side(self, join):
         torch.cuda.current_stream(self.device).wait_event(join)
 
@@ -1065,13 +1102,15 @@ class Seq2SeqEngine:
                 main(train)
             elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i == 0:
                 # auxiliary head: joined where the main branch first touches dY[aux_layer] (_bwd_enc_rec)
-                ws['_aux_join'] = self.fork_side(lambda side=side: side(train))
+                ev = self.fork_point()
                 main(train)
+                ws['_aux_join'] = self.run_side(ev, lambda side=side: side(train))
             elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i > 0:
                 # nobody needs a layer's weight gradients before the optimiser: the side stream just queues them (it is
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
-                deferred.append(self.fork_side(lambda side=side: side(train)))
+                ev = self.fork_point()
                 main(train)
+                deferred.append(self.run_side(ev, lambda side=side: side(train)))
             else:
                 self.run_stage(main, side, train)
             if after_stage:
