@@ -1079,15 +1079,22 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         }
     uint4* pre = lstm_smem + (size_t)wave * (2 * E2T_BWD_PRE16);              // wave-private prefetch double buffer
     float4* part = (float4*)(lstm_smem + 4 * 2 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
-    unsigned* flags = pa.flags + (size_t)cl * pa.fstride;
-    // flag words only ever grow: they count published steps over ALL launches (launch number x S + steps), so there is no
-    // reset pass.  The launch number is kept PER CLUSTER (last word of the cluster's flag row) and bumped by the cluster's
-    // first workgroup when it is done: a cluster cannot finish before every member has started (and read the number),
-    // whereas clusters are independent of each other -- with one global word, a cluster that finished early bumped it
-    // under workgroups of other clusters that the dispatcher had not started yet (CUs busy with side-stream GEMMs), and
-    // those then waited for flag values nobody would ever publish (seen: one 80-ms timeout every ~20 train steps)
-    unsigned* epoch = flags + (pa.fstride - 1);
-    const unsigned fbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (unsigned)S;
+    // Hand-off without flags (the forward kernels' protocol): every bf16 of the exchange copy carries a 1-bit stamp in
+    // bit 14 (the top exponent bit: free for |x| < 2; the exchange copy saturates there, the row-major dG does not) that
+    // toggles whenever its slot is rewritten.  A consumer loads its rows and retries until all stamps are the expected
+    // ones, then strips them: no store-ack wait and no flag round trip per step.  The stamps a launch starts from are
+    // the inverse of the ones the previous launch left behind, kept per buffer in one word per cluster (last word of the
+    // cluster's row in `flags`) that the cluster's first workgroup updates when it is done -- a cluster cannot finish
+    // before all its members have started and read the word (clusters are independent of each other).
+    unsigned* state = pa.flags + (size_t)cl * pa.fstride + (pa.fstride - 1);
+    const unsigned left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned sbase[2] = {(left & 1u) ^ 1u, ((left >> 1) & 1u) ^ 1u};
+    const int s_min = (p.dh0 != nullptr) ? 0 : 1;                              // steps S-1 .. s_min publish
+    // stamp of the publish of step s: writes to buffer q = s&1 happen at s = smax_q, smax_q - 2, ...
+    auto stamp_of = [&](int s) -> unsigned {
+        const int q = s & 1, smax = (S - 1) - ((((S - 1) & 1) != q) ? 1 : 0);
+        return sbase[q] ^ ((unsigned)((smax - s) >> 1) & 1u);
+    };
 
     // operands of step s that do not depend on the recurrence, by LDS-DMA into buffer s&1 (full exec, clamped addresses)
     const unsigned pre_lds = lds_addr_of(lstm_smem) + (unsigned)wave * (2 * E2T_BWD_PRE16 * 16);    // LDS byte address (integer math:
@@ -1172,34 +1179,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         const bool active = s >= 0 && s < len;
         f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (k > 0) {
-            // ---- wait until every producer wave of the cluster has published step s+1 ----
-            const int nfl = 4 * UG;
-            int spins = 0;
-            for (;;) {
-                bool ok = true;
-                for (int i = lane; i < nfl; i += 64)
-                    ok = ok && ((int)(__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fbase + (unsigned)k)) >= 0);
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
-                if ((spins & 1023) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1 << 18)) {
-                    // err[0] = code; err[1..7] = who waited for what (first reporter wins): diagnostics for the host
-                    if (lane == 0 && atomicCAS((int*)pa.err, 0, 3) == 0) {
-                        int badi = -1; unsigned badv = 0;
-                        for (int i = 0; i < nfl; ++i) {
-                            const unsigned v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((int)(v - (fbase + (unsigned)k)) < 0) { badi = i; badv = v; break; }
-                        }
-                        pa.err[1] = blockIdx.x; pa.err[2] = wave; pa.err[3] = k; pa.err[4] = badi; pa.err[5] = (int)badv;
-                        pa.err[6] = (int)fbase; pa.err[7] = (int)__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    break;
-                }
-            }
-            PSTAMP(1);
             // ---- this wave's K quarter of the dG rows of step s+1 (rows without a successor step hold zeros), one row
-            //      tile at a time (a wide layer's quarter is 25 KiB per tile: both would not fit the registers) ----
+            //      tile at a time (a wide layer's quarter is 25 KiB per tile: both would not fit the registers); loaded
+            //      until every stamp is the one step s+1 was published with ----
+            const unsigned E = stamp_of(s + 1) ? 0x40004000u : 0u;
             f32x4 acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1207,13 +1190,38 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             for (int r2 = 0; r2 < RW; ++r2) {
                 u32x4 st[KQ];
                 const bf16_t* src = pa.dgx + (((((size_t)((s + 1) & 1) * p.ndir + dir) * RTD + rg * RW + r2) * KBP + wave * KQ) * 64 + lane) * 8;
+                const bool rowok = (rg * RW + r2) * 16 + frow < B;             // rows beyond the batch are never published
+                int spins = 0;
+                for (;;) {
 #pragma unroll
-                for (int i = 0; i < KQ; ++i)        // the immediate offset field is 13-bit signed: one base per 4 k-blocks
-                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[i]) : "v"(src + (i >> 2) * 2048), "i"((i & 3) * 1024) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int i = 0; i < KQ; ++i)        // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[i]) : "v"(src + (i >> 2) * 2048), "i"((i & 3) * 1024) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int i = 0; i < KQ; ++i) asm volatile("" : "+v"(st[i]));
-                if (r2 == 0) { PSTAMP(2); if (s > 0) prefetch(s - 1); }    // lands while this step computes; drained by the publish wait
+                    for (int i = 0; i < KQ; ++i) asm volatile("" : "+v"(st[i]));
+                    unsigned bad = 0u;
+#pragma unroll
+                    for (int i = 0; i < KQ; ++i) {
+                        if (wave * KQ + i < KB4) {      // (k-blocks beyond 4H are never published: zero weights, zero data)
+                            st[i] = (u32x4){st[i][0] ^ E, st[i][1] ^ E, st[i][2] ^ E, st[i][3] ^ E};      // fresh: bit 14 now clear
+                            bad |= st[i][0] | st[i][1] | st[i][2] | st[i][3];
+                        } else {
+                            st[i] = (u32x4){0u, 0u, 0u, 0u};
+                        }
+                    }
+                    if (!__any(rowok && (bad & 0x40004000u) != 0u)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
+                    if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1 << 16)) {
+                        // err[0] = code; err[1..] = who waited at which step (first reporter wins): diagnostics for the host
+                        if (lane == 0 && atomicCAS((int*)pa.err, 0, 3) == 0) {
+                            pa.err[1] = blockIdx.x; pa.err[2] = wave; pa.err[3] = k; pa.err[4] = r2; pa.err[5] = (int)E; pa.err[6] = (int)left;
+                        }
+                        break;
+                    }
+                }
+                if (r2 == 0) { PSTAMP(1); PSTAMP(2); if (s > 0) prefetch(s - 1); }    // lands while this step computes; drained before the publish
 #pragma unroll
                 for (int i = 0; i < KQ; ++i)
 #pragma unroll
@@ -1258,18 +1266,28 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             og0 = make_uint4(og[0] | ((unsigned)og[1] << 16), og[2] | ((unsigned)og[3] << 16), og[4] | ((unsigned)og[5] << 16), og[6] | ((unsigned)og[7] << 16));
             og1 = make_uint4(og[8] | ((unsigned)og[9] << 16), og[10] | ((unsigned)og[11] << 16), og[12] | ((unsigned)og[13] << 16), og[14] | ((unsigned)og[15] << 16));
         }
+        // the prefetch DMA of the next step's operands was issued before the MFMAs: landed by now (cheap wait); from here
+        // on nothing of this step is ever waited for -- the stores below are fire-and-forget
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (s > 0 || want0) {
             if (own) {
                 // exchange copy for the next step's consumers: gate columns u0*4 .. u0*4+15 = k-block ut*2 + fq/2,
-                // k-groups (fq&1)*2 and +1; padded positions publish zeros.  Write-through (sc1) stores.
+                // k-groups (fq&1)*2 and +1; padded positions publish zeros.  Write-through (sc1) stores.  |x| >= 2 (or
+                // inf / nan) saturates to +-1.992 in THIS copy so that bit 14 is free for the stamp.
                 u32x4* hp = (u32x4*)(pa.dgx + (((((size_t)(s & 1) * p.ndir + dir) * RTD + rt) * KBP + ut * 2 + (fq >> 1)) * 64 + (fq & 1) * 32 + frow) * 8);
-                const u32x4 v0 = (u32x4){og0.x, og0.y, og0.z, og0.w}, v1 = (u32x4){og1.x, og1.y, og1.z, og1.w};
+                const unsigned PS = stamp_of(s) ? 0x40004000u : 0u;
+                unsigned x[8] = {og0.x, og0.y, og0.z, og0.w, og1.x, og1.y, og1.z, og1.w};
+                unsigned big = 0u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) big |= x[i];
+                if (__any((big & 0x40004000u) != 0u)) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = (x[i] | (((x[i] & 0x40004000u) >> 14) * 0x3FFFu)) & 0xBFFFBFFFu;
+                }
+                const u32x4 v0 = (u32x4){x[0] | PS, x[1] | PS, x[2] | PS, x[3] | PS}, v1 = (u32x4){x[4] | PS, x[5] | PS, x[6] | PS, x[7] | PS};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:256 sc1" :: "v"(hp), "v"(v0), "v"(v1) : "memory");
             }
             PSTAMP(4);
-            // ---- publish: drain this wave's stores (and the prefetch DMA), then raise this wave's flag ----
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(flags + ug * 4 + wave, fbase + (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PSTAMP(5);
         // ---- off the critical path: row-major dG for the weight-gradient GEMMs, factors of the next step ----
@@ -1284,7 +1302,12 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         if (p.dbg && s == S / 2 && lane == 0)
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
     }
-    if (ug == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ug == 0 && threadIdx.x == 0) {
+        // stamps the buffers are left with (= those of their last publish, steps s_min and s_min + 1)
+        unsigned nl = left;
+        for (int sl = s_min; sl <= s_min + 1 && sl <= S - 1; ++sl) nl = (nl & ~(1u << (sl & 1))) | (stamp_of(sl) << (sl & 1));
+        __hip_atomic_store(state, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #undef PSTAMP
 }
 
@@ -1446,7 +1469,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     // every workgroup must be resident at once (1 per CU); a K quarter of W_h^T for the workgroup's unit tiles must fit a
     // wave's registers (4 tiles x 13 k-blocks, or 2 tiles x 25)
     const int nwg = wide ? ((RT + 1) / 2) * d->ndir * ((p.UT + 1) / 2) : RT * d->ndir * ((p.UT + 3) / 4);
-    if (KQ == 0 || d->H % 4 != 0 || nwg > num_cus) {
+    if (KQ == 0 || d->H % 8 != 0 || nwg > num_cus) {
         e2t_set_error("persistent BPTT not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
         return E2T_ERR_ARG;
     }

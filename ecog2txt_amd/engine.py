@@ -433,7 +433,7 @@ class _Lstm:
         """Mirrors the checks in e2t_lstm_seq_bwd_persistent: 16-utterance x 64-unit workgroups up to H = 416,
         32 x 32 up to H = 800, one per CU."""
         kq = H.load().e2t_bwd_persist_kq(self.H)
-        if kq == 0 or self.H % 4 != 0:
+        if kq == 0 or self.H % 8 != 0:
             return False
         RT = ceil_div(B, 16)
         nwg = RT * self.ndir * ceil_div(self.UT, 4) if kq <= 13 else ceil_div(RT, 2) * self.ndir * ceil_div(self.UT, 2)

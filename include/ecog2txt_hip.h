@@ -158,13 +158,16 @@ int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg
                      const float* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
                      const float* dc_final, float* dc_carry, float* dh0, float* dc0, void* stream);
 /* Same gradients as e2t_lstm_seq_bwd (to fp32 round-off: the K = 4H sum is split in 4 quarters instead of 2 halves) in
- * ONE persistent launch, incl. the pseudo-step -1 when dh0/dc0 are given.  Applicable when H % 4 == 0 and the workgroups
+ * ONE persistent launch, incl. the pseudo-step -1 when dh0/dc0 are given.  Applicable when H % 8 == 0 and the workgroups
  * fit the CUs one-to-one: ceil(B/16) * ndir * ceil(ceil(H/16)/4) of them for H <= 416, ceil(B/32) * ndir * ceil(H/32) for
  * H <= 800; returns non-zero otherwise.  KQ = e2t_bwd_persist_kq(H) (0: not applicable).
+ * dG is handed from CU to CU inside the launch through dgx with a 1-bit stamp in bit 14 of every bf16, so the RECURRENT
+ * term saturates gate gradients at |x| < 2 (1.992); the dG written for the weight / input gradients is not touched.
  * dgx: bf16 exchange scratch [2][ndir][RTD][4*KQ][64][8] with RTD = ceil(B/16) (H <= 416) or 2*ceil(B/32), zero-filled
  * once by the caller; flags: uint32 [clusters*stride] with clusters*stride = ceil(B/16)*ndir*32 (H <= 416) or
- * ceil(B/32)*ndir*128 (the last word of each cluster's row counts launches), zero-filled once by the caller and afterwards only touched by this entry point with the same S
- * (zero it again after an error); err as for the forward. */
+ * ceil(B/32)*ndir*128 (only the last word of each cluster's row is used: the stamps its buffers were left with), both
+ * zero-filled once by the caller and afterwards only touched by this entry point with the same S, B, H (zero them again
+ * after an error); err as for the forward. */
 int e2t_bwd_persist_kq(int H);
 int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
                                 const float* Gs, const float* Cs, const int32_t* lens, const float* c0,
