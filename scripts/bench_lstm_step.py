@@ -49,7 +49,7 @@ if lay.persistent_ok(B, eng.num_cus):
         dbg = torch.zeros(256 * 8 * 8 + 2048, dtype=torch.int64, device='cuda')
         os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
         fwd_p(); torch.cuda.synchronize()
-            del os.environ['E2T_LSTM_DBG']
+        del os.environ['E2T_LSTM_DBG']
         raw = dbg.cpu().numpy()
         nw = 4 * ceil_div(B, 64) * lay.ndir * lay.UT
         tot = raw[nw * 8: nw * 8 + nw] / 100.0
@@ -81,7 +81,7 @@ if lay.persistent_bwd_ok(B, eng.num_cus):
         t = dbg.cpu().numpy()[:nw * 8].reshape(-1, 8)[:, :7]
         t = t[t[:, 0] > 0]
         rel = (t - t[:, :1]) / 100.0
-        names = ['step top', 'poll done', 'state landed', 'mma+reduce done', 'dG exchange stored', 'published', 'side work done']
+        names = ['step top', 'state landed (incl. retries)', '(same)', 'mma+reduce done', 'dG exchange stored', '(same)', 'side work done']
         dd = np.diff(rel, axis=1)
         print('  persistent bwd step %d, %d waves; phase durations (us): ' % (S // 2, len(t)) + ' | '.join('%s: min %.1f med %.1f p90 %.1f max %.1f' % (names[i + 1], dd[:, i].min(), np.median(dd[:, i]), np.percentile(dd[:, i], 90), dd[:, i].max()) for i in range(6)))
 print('launch per step: fwd %.2f us/step   bwd %.2f us/step' % (timeit(fwd, S), timeit(bwd, S)), flush=True)
