@@ -326,7 +326,7 @@ class _FFStack:
                 cur, ld = o.data_ptr(), rk(fout)
         return ws['out']
 
-    def bwd_dx(self, ws, d_out, d_in_ptr, d_in_ld, accumulate, train):
+    def bwd_dx(self, ws, d_out, d_in_ptr, d_in_ld, accumulate, train, d_in_drop=None):
         """Input-gradient chain (the critical path): d_out bf16 [M][rk(out)] -> hidden pre-activation gradients
         (ws['dpre'], masked by ReLU/dropout in the GEMM epilogue) -> fp32 gradient of the stack's input."""
         e = self.eng
@@ -343,7 +343,7 @@ class _FFStack:
                 d, ldd = dp.data_ptr(), rk(fin)
             else:
                 e.gemm(d, ldd, self.WB[0].data_ptr(), rk(fout), d_in_ptr, d_in_ld, M, kin, rk(fout),
-                       accumulate=accumulate)
+                       accumulate=accumulate, drop=d_in_drop)
 
     def bwd_dw(self, ws, x_ptr, d_out):
         """Weight (+ bias) gradients from the layer inputs and the gradients bwd_dx left in ws['dpre']: K = M rows of
@@ -379,10 +379,11 @@ class _FFStack:
                 e.gemm(ws['actT'][i].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
                        st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk, splitk=True)
 
-    def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train):
+    def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train, d_in_drop=None):
         """d_out: bf16 [M][rk(out)] gradient of the final linear output.  Writes weight grads
-        into the store and the input gradient (fp32) into d_in_ptr."""
-        self.bwd_dx(ws, d_out, d_in_ptr, d_in_ld, accumulate, train)
+        into the store and the input gradient (fp32) into d_in_ptr (d_in_drop: dropout mask of the input, applied in
+        the GEMM epilogue)."""
+        self.bwd_dx(ws, d_out, d_in_ptr, d_in_ld, accumulate, train, d_in_drop)
         self.bwd_dw(ws, x_ptr, d_out)
 
 
@@ -476,6 +477,16 @@ class _Lstm:
         d.drop_seed, d.drop_step, d.drop_stream = e.seed, e.step_t.data_ptr(), self.stream
         return d
 
+    def out_drop(self, train):
+        """(rate, stream, logical ld) of the dropout on this layer's output sequence, for a GEMM epilogue that produces a
+        gradient with respect to it: every producer of dY masks its own contribution (the mask is linear), so BPTT does
+        not spend a Philox evaluation per step and cell on the critical loop.  None: BPTT masks dY itself (no dropout, or
+        the padded column layout differs from the logical one)."""
+        rate = self.eng.spec.rnn_dropout if train else 0.0
+        if rate > 0 and self.H8 == self.H:
+            return (rate, self.stream, self.ndir * self.H)
+        return None
+
     def fwd_gx(self, ws, x_ptr, src):
         """Input projection of all time steps (no recurrence in it: may run ahead on another stream)."""
         self.eng.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, ws['M'], self.N4,
@@ -509,7 +520,8 @@ class _Lstm:
             launch(0, 0, e.stream)
 
     def bwd_rec(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
-                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False, before_d_in=None):
+                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False, before_d_in=None,
+                dy_masked=False, d_in_drop=None):
         """BPTT + input gradient (the critical path of the backward pass).  d_in_bf16_mask=(src_ptr, ld): emit the input
         gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue).  d_in_ptr=None: BPTT
         only (bwd_d_in() later, e.g. on another stream); before_d_in() runs between the two (a stream join)."""
@@ -521,6 +533,8 @@ class _Lstm:
 
         def launch(rb0, nrb, stream):
             d = self.desc(ws, train)
+            if dy_masked:
+                d.drop_rate = 0.0                 # the producers of dY applied the output dropout mask (out_drop)
             d.rb_begin, d.rb_count = rb0, nrb
             lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                  ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
@@ -528,6 +542,8 @@ class _Lstm:
         if e.persistent_bwd and self.persistent_bwd_ok(B, e.num_cus):
             # whole BPTT sweep in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_bwd_persist)
             d = self.desc(ws, train)
+            if dy_masked:
+                d.drop_rate = 0.0
             lib.e2t_lstm_seq_bwd_persistent(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                             ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final),
                                             p(dc_final), p(dh0), p(dc0), ws['dgx'].data_ptr(), ws['counters'].data_ptr(),
@@ -537,9 +553,9 @@ class _Lstm:
         if before_d_in is not None:
             before_d_in()
         if d_in_ptr is not None:
-            self.bwd_d_in(ws, d_in_ptr, d_in_ld, d_in_bf16_mask, d_in_alpha, d_in_accumulate)
+            self.bwd_d_in(ws, d_in_ptr, d_in_ld, d_in_bf16_mask, d_in_alpha, d_in_accumulate, d_in_drop)
 
-    def bwd_d_in(self, ws, d_in_ptr, d_in_ld, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False):
+    def bwd_d_in(self, ws, d_in_ptr, d_in_ld, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False, d_in_drop=None):
         """Input gradient dG . W_x of the dG that bwd_rec left in ws."""
         e = self.eng
         M = ws['M']
@@ -548,7 +564,7 @@ class _Lstm:
                    rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
         else:
             e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                   rk(self.N4), accumulate=d_in_accumulate)
+                   rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop)
 
     def bwd_weights(self, ws, x_ptr):
         """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the
@@ -1126,9 +1142,10 @@ class Seq2SeqEngine:
         encoder's final state and into the embedded tokens)."""
         s, store = self.spec, self.store
         store.view('dec.emb', store.g).zero_()          # the embedding scatter-add accumulates by atomics
-        self.proj.bwd_dx(ws['proj'], ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train)
+        dd = self.dec.out_drop(train)
+        self.proj.bwd_dx(ws['proj'], ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train, d_in_drop=dd)
         self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
-                         None, self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
+                         None, self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'], dy_masked=dd is not None)
 
     def _bwd_head_weights(self, ws, train):
         """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them."""
@@ -1160,9 +1177,10 @@ class Seq2SeqEngine:
                 self.join_side(aj)
             else:
                 fin['before_d_in'] = lambda: self.join_side(aj)
+        fin['dy_masked'] = lay.out_drop(train) is not None
         if l > 0:
             lay.bwd_rec(lw, x, ws['lens_d'], dY, lay.ldy, train, ws['dY'][l - 1].data_ptr(), self.enc[l - 1].ldy,
-                        d_in_accumulate=have_dy[l - 1], **fin)
+                        d_in_accumulate=have_dy[l - 1], d_in_drop=self.enc[l - 1].out_drop(train), **fin)
             have_dy[l - 1] = True
             return
         keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
@@ -1175,7 +1193,8 @@ class Seq2SeqEngine:
             return
         l = s.aux_layer
         lay, lw = self.enc[l], ws['enc'][l]
-        self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train)
+        self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train,
+                     d_in_drop=lay.out_drop(train))
         ws['have_dy'][l] = True
 
     def _bwd_enc_weights(self, ws, l):
