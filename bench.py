@@ -195,12 +195,12 @@ def main():
         flops = 2 * M * N * K
         ach = flops / (us * 1e-6) / 1e12
         alg_bytes = 2 * M * K + 2 * N * K + 4 * M * N
-        # HBM-side bytes per launch of THIS instance from the committed PMC run (profiles/r01d_pmc_gemm_gx.json:
+        # HBM-side bytes per launch of THIS instance from the committed PMC run (profiles/r01f_pmc_gemm_gx.json:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/roofline_gemm.py, FETCH_SIZE x2 as
         # MI355X_MICROARCH.md prescribes); a measured constant of this round, not live
         traffic = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01d_pmc_gemm_gx.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01f_pmc_gemm_gx.json')) as f:
                 t = json.load(f)['k_gemm_nt']
             if args.config == 'cfg2' and B == 256:
                 traffic = t['hbm_read_bytes'] + t['hbm_write_bytes']
