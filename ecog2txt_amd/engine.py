@@ -1344,21 +1344,44 @@ class Seq2SeqEngine:
             g[0].replay()
             return
         cur = torch.cuda.current_stream(self.device)
-        side_stream = self._wstream
-        for gm, gs, ranges in g[0]:
-            if gs is not None:
-                ev = torch.cuda.Event()
-                ev.record(cur)                       # everything the side work reads was enqueued on the main stream before
-                side_stream.wait_event(ev)
-                with torch.cuda.stream(side_stream):
-                    gs.replay()
-                    after(0, ranges)                 # the collective orders itself behind the side stream
-            gm.replay()
-            if gs is None:
-                after(0, ranges)
-        ev = torch.cuda.Event()
-        ev.record(side_stream)
-        cur.wait_event(ev)
+
+        def replay_stages(side_stream, exchange):
+            for gm, gs, ranges in g[0]:
+                if gs is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)                   # everything the side work reads was enqueued on the main stream before
+                    side_stream.wait_event(ev)
+                    with torch.cuda.stream(side_stream):
+                        gs.replay()
+                        if exchange:
+                            after(0, ranges)         # the collective orders itself behind the side stream
+                gm.replay()
+                if gs is None and exchange:
+                    after(0, ranges)
+            ev = torch.cuda.Event()
+            ev.record(side_stream)
+            cur.wait_event(ev)
+        if 'side_stream' not in ws['graph']:
+            # Which hardware queue the side stream lands on decides how well its GEMMs interleave with the persistent
+            # recurrences of the main stream (measured: 2.10 vs 2.31 ms per step between two stream objects of the same
+            # process).  HIP deals streams to its hardware queues round-robin, so try a few and keep the fastest; the
+            # trial replays run forward + backward only (no exchange, no optimiser: nothing the ranks must agree on).
+            cands = [self._wstream] + [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            best = None
+            for st in cands:
+                replay_stages(st, False)
+                torch.cuda.synchronize(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                for _ in range(3):
+                    replay_stages(st, False)
+                e1.record(cur)
+                torch.cuda.synchronize(self.device)
+                t = e0.elapsed_time(e1)
+                if best is None or t < best[0]:
+                    best = (t, st)
+            ws['graph']['side_stream'] = best[1]
+        replay_stages(ws['graph']['side_stream'], True)
         sync.wait()
         g[1].replay()
 
