@@ -215,10 +215,8 @@ def main():
             us_f = time_graph(lambda: lay.fwd(lw, x, ws['lens_d'], eng.store.p, True, steps=(0, S)), 3) / S
             extra['lstm_fwd_us_per_step'] = round(us_f, 3)
         if eng.persistent_bwd and lay.persistent_bwd_ok(B, eng.num_cus):
-            us_b = time_graph(lambda: lib.e2t_lstm_seq_bwd_persistent(
-                C.byref(d), lay.WhB.data_ptr(), lw['dG'].data_ptr(), lw['dG'].shape[1], ws['dY'][1].data_ptr(), lay.ldy,
-                lw['Gs'].data_ptr(), lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), None, None, None, None, None, lw['dgx'].data_ptr(),
-                lw['counters'].data_ptr(), eng.sync_err.data_ptr(), eng.num_cus, eng.stream), 3) / S
+            us_b = time_graph(lambda: lay.bwd_rec(lw, x, ws['lens_d'], ws['dY'][1].data_ptr(), lay.ldy, True, None, 0,
+                                                  dy_masked=lay.out_drop(True) is not None), 3) / S
             extra['lstm_bwd_us_per_step'] = round(us_b, 3)
         extra['lstm_step_flops'] = 2 * B * lay.H * 4 * lay.H * 2      # both directions, one time step of one layer
         assert int(eng.sync_err[0].item()) == 0
