@@ -436,7 +436,9 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         const int tiles = ntm * ntn;
         int s = 512 / tiles;                           // fill, but never exceed, the 2 x 256 resident workgroups: one block
                                                        // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
-        if (s > nfull / 6) s = nfull / 6;              // keep >= 6 K tiles per split
+        if (s > nfull / 16) s = nfull / 16;            // keep >= 16 K tiles per split: a workgroup's fixed cost (DMA fill, slab
+                                                       // store, its share of the reduction) is worth ~8 of them (measured on the
+                                                       // train step: 6 -> 16 tiles per split -1.2 %, 24 and more slower again)
         const size_t per = (size_t)M * N * sizeof(float);
         if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
         if (s < 1) s = 1;
