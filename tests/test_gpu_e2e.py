@@ -134,3 +134,44 @@ def test_staged_backward_graphs_match_single_graph():
     covered = sorted(per_step)
     assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
     assert covered[-1][1] == eng.store.seg_range('conv401.W')[1]
+
+
+def test_staged_step_with_a_real_rccl_group():
+    """Same, with the all-reduces issued through torch.distributed's "nccl" backend (= RCCL) on a one-rank group: the
+    collectives run behind the side stream's graphs exactly as on a multi-GPU node, only the peers are missing."""
+    import os
+    import torch.distributed as dist
+    from test_gpu_parity import build, SPECS
+    from ecog2txt_amd.parallel import GradSync
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    except Exception as e:                                   # no usable network interface on the box
+        pytest.skip('cannot create an RCCL group here: %r' % (e,))
+    try:
+        class OneRankAsMany(GradSync):
+            """world is reported as 2 so that the engine takes the data-parallel path; the sum over the one real rank
+            leaves the gradients unchanged, so the scale stays 1."""
+            def __init__(self, g):
+                super().__init__(g)
+                self.world = 2
+            def allreduce_range(self, a, b):
+                if b > a:
+                    self.pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            grad_scale = 1.0
+        eng, ws, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+        eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+        sync = OneRankAsMany(eng2.store.g)
+        for _ in range(4):
+            eng.train_step(ws, use_graph=True)
+            eng2.train_step(ws2, use_graph=True, sync=sync)
+        torch.cuda.synchronize()
+        assert int(eng2.sync_err[0].item()) == 0
+        np.testing.assert_allclose(eng.store.p.cpu().numpy(), eng2.store.p.cpu().numpy(), atol=1e-5)
+        assert eng.losses(ws)['total'] == pytest.approx(eng2.losses(ws2)['total'], rel=1e-5)
+    finally:
+        dist.destroy_process_group()
