@@ -427,7 +427,7 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     const bool want_split = have_ws && ((ep->flags & E2T_GEMM_SPLITK) || (t128 <= 160 && nfull >= 16));
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
-    bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 256;
+    bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 64;
     if (forced == 128) big = false;
     if (forced == 256 && !tn && !want_split && !rich) big = true;
     const int BM = big ? 256 : 128, BN = BM;
