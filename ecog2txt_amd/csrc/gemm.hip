@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
                 for (int j = 0; j < TJ; ++j) { uint4 vb = sb[swz(wn + j * 16 + frow, ch)]; fb[j] = *(bf16x8*)&vb; }
             }
             if (BOTH) continue;
+            if (TN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 if (nt >= 0) {
