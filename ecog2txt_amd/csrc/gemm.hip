@@ -53,7 +53,17 @@ struct GemmArgs {
     int splits;
     float* slab;               // split-K partials [splits][M][N] fp32 (dense), reduced by k_splitk_reduce
     const bf16_t* zero_page;   // TN: 512 zero bytes for k-rows beyond K
+    long long a_bs, b_bs, c_bs; // batched launch (grid.z): element strides of A, B, C between products
 };
+// product z of a batched launch: operands, output and slabs moved to that product's
+__device__ __forceinline__ GemmArgs gemm_batch_view(const GemmArgs& in, int z) {
+    GemmArgs p = in;
+    p.A = in.A + (size_t)z * in.a_bs;
+    p.B = in.B + (size_t)z * in.b_bs;
+    p.C = (char*)in.C + (size_t)z * in.c_bs * ((in.flags & E2T_GEMM_OUT_BF16) ? 2 : 4);
+    if (in.slab) p.slab = in.slab + (size_t)z * in.splits * in.M * in.N;
+    return p;
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
 
@@ -122,7 +132,8 @@ extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
 // RICH = false drops the ReLU / mask / dropout epilogue: with 32 accumulator tiles per wave the full epilogue body is too
 // large for hipcc to unroll, and a rolled loop indexes the accumulators dynamically (= scratch memory, 4x slower kernel).
 template <int BM, int BN, int WM, int WN, bool RICH, bool TN>
-__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void k_gemm_nt(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void k_gemm_nt(GemmArgs p_in) {
+    const GemmArgs p = gemm_batch_view(p_in, blockIdx.z);
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE = (BM + BN) * 8;         // 16-B units per stage: [A: BM rows | B: BN rows][8 chunks]
     constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
@@ -367,7 +378,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
 
 // C[m][n] (+)= epilogue(sum_s slab[s][m][n]) in fixed split order (deterministic); 4 consecutive columns per thread so
 // the dropout mask is the GEMM kernel's (one Philox counter per aligned group of 4)
-__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p) {
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
+    const GemmArgs p = gemm_batch_view(p_in, blockIdx.y);
     const int N4 = (p.N + 3) >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)p.M * N4) return;
@@ -448,14 +460,16 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     if (forced == 256 && !tn && !want_split && !rich) big = true;
     const int BM = big ? 256 : 128, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    const int batch = (ep && ep->batch > 1) ? ep->batch : 1;
+    if (batch > 1) { p.a_bs = ep->a_batch_stride; p.b_bs = ep->b_batch_stride; p.c_bs = ep->c_batch_stride; }
     if (want_split) {
-        const int tiles = ntm * ntn;
+        const int tiles = ntm * ntn * batch;
         int s = 512 / tiles;                           // fill, but never exceed, the 2 x 256 resident workgroups: one block
                                                        // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
         if (s > nfull / 16) s = nfull / 16;            // keep >= 16 K tiles per split: a workgroup's fixed cost (DMA fill, slab
                                                        // store, its share of the reduction) is worth ~8 of them (measured on the
                                                        // train step: 6 -> 16 tiles per split -1.2 %, 24 and more slower again)
-        const size_t per = (size_t)M * N * sizeof(float);
+        const size_t per = (size_t)M * N * sizeof(float) * batch;
         if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
         if (s < 1) s = 1;
         p.splits = s;
@@ -467,12 +481,12 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         if (e1 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e1)); return E2T_ERR_HIP; }
         attr_done = true;
     }
-    if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
-    else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
+    if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
+    else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     if (p.splits > 1) {
         const size_t n = (size_t)M * ((N + 3) / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;

@@ -581,11 +581,11 @@ class _Lstm:
         if e.tn and dense and self.ones_col_set:
             e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
                    self.D + 1, self.N4, M, splitk=True, tn=True)
-            for dd in range(nd):
-                # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction)
-                row_off = (2 * B if dd == 1 else 0) * self.ldy
-                e.gemm(ws['Yext'].data_ptr() + 2 * (row_off + dd * self.H8), self.ldy, ws['dG'].data_ptr() + 2 * dd * 4 * Hh,
-                       rk(self.N4), st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, M, splitk=True, tn=True)
+            # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction).  Both directions in ONE
+            # batched launch: twice the tiles, so half the K splits (slabs, workgroup start-ups) for the same fill
+            e.gemm(ws['Yext'].data_ptr(), self.ldy, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wh', st.g), 4 * Hh,
+                   Hh, 4 * Hh, M, splitk=True, tn=True,
+                   batch=(nd, 2 * B * self.ldy + self.H8, 4 * Hh, Hh * 4 * Hh) if nd > 1 else None)
             return
         lib.e2t_transpose_bf16(ws['dG'].data_ptr(), rk(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
@@ -702,8 +702,11 @@ class Seq2SeqEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
-             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False):
+             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False, batch=None):
+        """batch = (n, a_stride, b_stride, c_stride): n products of the same shape in one launch (element strides)."""
         ep = H.GemmEpilogue()
+        if batch is not None:
+            ep.batch, ep.a_batch_stride, ep.b_batch_stride, ep.c_batch_stride = batch
         ep.bias = bias
         ep.alpha = alpha
         ep.last_col_out = last_col_out

@@ -23,7 +23,8 @@ class GemmEpilogue(C.Structure):
                 ('row_lens', C.c_void_p), ('rows_per_step', C.c_int), ('alpha', C.c_float), ('flags', C.c_int),
                 ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong), ('drop_step', C.c_void_p),
                 ('drop_stream', C.c_uint), ('drop_ld', C.c_int), ('last_col_out', C.c_void_p),
-                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_size_t)]
+                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_size_t), ('batch', C.c_int),
+                ('a_batch_stride', C.c_longlong), ('b_batch_stride', C.c_longlong), ('c_batch_stride', C.c_longlong)]
 
 
 class LstmDesc(C.Structure):

@@ -88,6 +88,11 @@ typedef struct e2t_gemm_epilogue {
     void* splitk_ws;               /* device workspace for split-K partial slabs (or NULL: never split).  When offered, the
                                       library also splits on its own if the product has few 128x128 tiles and K >= 1024 */
     size_t splitk_ws_bytes;
+    int batch;                     /* > 1: that many independent products of the same shape in ONE launch; product z uses
+                                      A + z*a_batch_stride, B + z*b_batch_stride, C + z*c_batch_stride (strides in ELEMENTS of
+                                      the respective array; bias / masks / row_lens are shared).  0 or 1: a single product.
+                                      (The two directions of a recurrent weight gradient: twice the tiles, half the splits.) */
+    long long a_batch_stride, b_batch_stride, c_batch_stride;
 } e2t_gemm_epilogue;
 int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep /* host pointer or NULL */, void* stream);

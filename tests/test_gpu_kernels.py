@@ -116,6 +116,34 @@ def test_gemm_tn_k_major_operands(hl, M, N, K):
         assert np.all(host(c)[:, N:] == 7.0)
 
 
+@pytest.mark.parametrize('split', [False, True])
+def test_gemm_batched_products_in_one_launch(hl, split):
+    """epilogue.batch: z-th product reads A + z*a_stride, B + z*b_stride and writes C + z*c_stride (the two directions
+    of a recurrent weight gradient: shifted rows of one activation array, column blocks of one gradient array)."""
+    rng = np.random.default_rng(11)
+    M, N, K, nb = 72, 136, 1100, 2
+    lda, ldb = 2 * r8(M) + 8, nb * r8(N)
+    A = rng.standard_normal((K + 16, lda)); Bm = rng.standard_normal((K, ldb))
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    a_stride, b_stride, c_stride = 5 * lda + r8(M), r8(N), M * r8(N) + 40         # rows AND columns shift between the products
+    c = torch.full((nb * (M * r8(N) + 40),), 7.0, dtype=torch.float32, device='cuda')
+    wsb = torch.zeros(4 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue(); ep.alpha = 1.0
+    ep.batch, ep.a_batch_stride, ep.b_batch_stride, ep.c_batch_stride = nb, a_stride, b_stride, c_stride
+    if split:
+        ep.flags = hl.GEMM_SPLITK
+        ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), r8(N), M, N, K, C.byref(ep), st())
+    torch.cuda.synchronize()
+    out = host(c)
+    Ar, Br = round_bf16(A), round_bf16(Bm)
+    for z in range(nb):
+        want = Ar[5 * z:5 * z + K, z * r8(M):z * r8(M) + M].T @ Br[:, z * r8(N):z * r8(N) + N]
+        got = out[z * c_stride:z * c_stride + M * r8(N)].reshape(M, r8(N))
+        np.testing.assert_allclose(got[:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+    assert np.all(out[M * r8(N):c_stride] == 7.0)
+
+
 def test_gemm_splitk_runs_the_full_epilogue(hl):
     """Few output tiles + long K: the library splits K on its own when a workspace is offered, and the reduction
     applies the same bias / ReLU / dropout / row mask / bf16 epilogue (same Philox mask) as the direct store."""
