@@ -453,18 +453,22 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
     }
     float cst[4] = {0.f, 0.f, 0.f, 0.f};                          // c of this lane's 4 cells, carried in registers
     if (own && len > 0 && p.c0) { const float4 c = *(const float4*)(p.c0 + (size_t)b * NH + dir * H + u0); cst[0] = c.x; cst[1] = c.y; cst[2] = c.z; cst[3] = c.w; }
-    // Gx of the lane's 4 units at its utterance's time index: 64 contiguous bytes.  Prefetched one step ahead by
-    // LDS-DMA into a wave-private double buffer ([buffer][r][lane] float4) -- no registers are involved, so the
-    // compiler cannot pull the wait for it into the critical path; it is covered by the next step's state wait.
-    uint4* gxl = lstm_smem + (size_t)wave * (2 * 4 * 64);
+    // Gx of the lane's 4 units at its utterance's time index: 64 contiguous bytes.  Prefetched TWO steps ahead by
+    // LDS-DMA into a wave-private ring of three buffers ([buffer][r][lane] float4) -- no registers are involved, so the
+    // compiler cannot pull the wait for it into the critical path.  It is issued right after a step's state has landed
+    // (VMEM returns in order: issued in front of the state loads it would be waited for with them) and is covered by the
+    // state waits of the two following steps, which is enough for an HBM miss (long sequences: Gx no longer fits the
+    // 256-MB infinity cache; one step ahead cost 4.5 instead of 3.0 us per step at S = 167).
+    uint4* gxl = lstm_smem + (size_t)wave * (3 * 4 * 64);
     auto gx_load = [&](int s) {
         const bool act = own && s < len;
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
         const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s & 1) * 4 + r) * 64));
+        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s % 3) * 4 + r) * 64));
     };
     gx_load(0);
+    if (S > 1) gx_load(1);
     // Stamp convention (see the state loads below).  Every slot of an exchange buffer ends a launch on the same stamp
     // (all producers make the same number of writes); the new launch starts on the opposite one, so leftovers -- of the
     // previous launch or of the initial fill -- never look fresh, and no flag, counter or reset pass is needed.  The
@@ -546,6 +550,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             }
         }
         PSTAMP(2);
+        if (s + 2 < S) gx_load(s + 2);
 
         f32x4 acc[2][4];
 #pragma unroll
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         float gi[4], gj[4], gf[4], go[4], hv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint4 graw = gxl[((s & 1) * 4 + r) * 64 + lane];
+            const uint4 graw = gxl[((s % 3) * 4 + r) * 64 + lane];
             const float gxv[4] = {__uint_as_float(graw.x), __uint_as_float(graw.y), __uint_as_float(graw.z), __uint_as_float(graw.w)};
             gi[r] = fsigmoid((acc[0][0][r] + acc[1][0][r]) + gxv[0]);
             gj[r] = ftanh((acc[0][1][r] + acc[1][1][r]) + gxv[1]);
@@ -613,7 +618,6 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                 *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
             }
         }
-        if (s + 1 < S) gx_load(s + 1);
         PSTAMP(6);
         if (p.dbg && s == S / 2 && lane == 0)
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
@@ -1401,7 +1405,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
         e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
         return E2T_ERR_ARG;
     }
-#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist<K>, dim3(nwg), dim3(256), 4 * 2 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
+#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist<K>, dim3(nwg), dim3(256), 4 * 3 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
     switch (p.KB) {
         E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)
         E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10)
