@@ -700,16 +700,17 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
     }
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
     if (own && len > 0 && p.c0) { const float4 c = *(const float4*)(p.c0 + (size_t)b * NH + dir * H + u0); cst[0] = c.x; cst[1] = c.y; cst[2] = c.z; cst[3] = c.w; }
-    uint4* gxl = lstm_smem + (size_t)wave * (2 * 4 * 64);
-    float4* xbuf0 = (float4*)(lstm_smem + 4 * 2 * 4 * 64);        // [step parity][wave][gate][lane]
+    uint4* gxl = lstm_smem + (size_t)wave * (3 * 4 * 64);         // Gx ring: two steps ahead (see the narrow kernel)
+    float4* xbuf0 = (float4*)(lstm_smem + 4 * 3 * 4 * 64);        // [step parity][wave][gate][lane]
     auto gx_load = [&](int s) {
         const bool act = own && s < len;
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
         const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (own ? u0 : 0)) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s & 1) * 4 + r) * 64));
+        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s % 3) * 4 + r) * 64));
     };
     gx_load(0);
+    if (S > 1) gx_load(1);
     const size_t hx_slot = ((((size_t)dir) * RTP + rt) * KB + (ut >> 1)) * 512 + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4;
     const size_t hx_buf = (size_t)p.ndir * RTP * KB * 512;       // elements per step-parity buffer
     unsigned* hxw = (unsigned*)(pa.hx + 2 * hx_buf) + cl;       // leftover stamps of this cluster's buffers (see the narrow kernel)
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
 #pragma unroll
             for (int j = 0; j < KH; ++j)
                 if (j >= nk) st[r2][j] = (u32x4){0u, 0u, 0u, 0u};
+        if (s + 2 < S) gx_load(s + 2);       // (after the state has landed: VMEM returns in order)
         f32x4 acc[2][4];
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2)
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
         float gi[4], gj[4], gf[4], go[4], hv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint4 graw = gxl[((s & 1) * 4 + r) * 64 + lane];
+            const uint4 graw = gxl[((s % 3) * 4 + r) * 64 + lane];
             gi[r] = fsigmoid(z[0][r] + __uint_as_float(graw.x));
             gj[r] = ftanh(z[1][r] + __uint_as_float(graw.y));
             gf[r] = fsigmoid(z[2][r] + __uint_as_float(graw.z) + p.forget_bias);
@@ -860,7 +862,6 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
                 *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
             }
         }
-        if (s + 1 < S) gx_load(s + 1);
     }
     if (ug == 0 && threadIdx.x == 0) {
         unsigned nl = left;
@@ -1390,7 +1391,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
             e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwgw, num_cus);
             return E2T_ERR_ARG;
         }
-        const size_t ldsw = (size_t)(4 * 2 * 4 * 64 + 2 * 4 * 4 * 64) * 16;
+        const size_t ldsw = (size_t)(4 * 3 * 4 * 64 + 2 * 4 * 4 * 64) * 16;
 #define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist_wide<K>, dim3(nwgw), dim3(256), ldsw, (hipStream_t)stream, pw); break;
         switch (KH) { E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10) E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13) }
 #undef E2T_PERSIST_CASE
