@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             if (utu < p.UT && kb < KB4) v = ((const uint4*)p.WhB)[(((size_t)dir * p.UT + utu) * KB4 + kb) * 64 + lane];
             W[u][i] = *(bf16x8*)&v;
         }
-    uint4* pre = lstm_smem + (size_t)wave * (2 * E2T_BWD_PRE16);              // wave-private prefetch double buffer
-    float4* part = (float4*)(lstm_smem + 4 * 2 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
+    uint4* pre = lstm_smem + (size_t)wave * (3 * E2T_BWD_PRE16);              // wave-private prefetch ring (two steps ahead)
+    float4* part = (float4*)(lstm_smem + 4 * 3 * E2T_BWD_PRE16);              // [unit tile][source wave][lane]
     // Hand-off without flags (the forward kernels' protocol): every bf16 of the exchange copy carries a 1-bit stamp in
     // bit 14 (the top exponent bit: free for |x| < 2; the exchange copy saturates there, the row-major dG does not) that
     // toggles whenever its slot is rewritten.  A consumer loads its rows and retries until all stamps are the expected
@@ -1102,10 +1102,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     };
 
     // operands of step s that do not depend on the recurrence, by LDS-DMA into buffer s&1 (full exec, clamped addresses)
-    const unsigned pre_lds = lds_addr_of(lstm_smem) + (unsigned)wave * (2 * E2T_BWD_PRE16 * 16);    // LDS byte address (integer math:
+    const unsigned pre_lds = lds_addr_of(lstm_smem) + (unsigned)wave * (3 * E2T_BWD_PRE16 * 16);    // LDS byte address (integer math:
     auto prefetch = [&](int s) {                                                                     //  no generic->LDS casts in the loop)
         if (!tile_ok) return;
-        const unsigned dst = pre_lds + (unsigned)(s & 1) * (E2T_BWD_PRE16 * 16);
+        const unsigned dst = pre_lds + (unsigned)(s % 3) * (E2T_BWD_PRE16 * 16);
         const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dma16_to_lds(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, dst + r * 1024);
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     for (int r = 0; r < 4; ++r) f_add[r] = k1[r] = k2[r] = k3[r] = k4[r] = k5[r] = k6[r] = 0.f;
     auto precompute = [&](int s) {
         if (!own) return;
-        const uint4* src = pre + (s & 1) * E2T_BWD_PRE16;
+        const uint4* src = pre + (s % 3) * E2T_BWD_PRE16;
         float cp[4] = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
             const float2* cs = (const float2*)(src + 4 * 64);
@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     }
     dma_wait_all();
     precompute(S - 1);
+    if (S > 1) prefetch(S - 2);
     long long pts[8];
 #define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)
 
@@ -1226,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
                         break;
                     }
                 }
-                if (r2 == 0) { PSTAMP(1); PSTAMP(2); if (s > 0) prefetch(s - 1); }    // lands while this step computes; drained before the publish
+                if (r2 == 0) { PSTAMP(1); PSTAMP(2); if (s > 1) prefetch(s - 2); }    // two steps ahead: covered by the state waits of the next two steps
 #pragma unroll
                 for (int i = 0; i < KQ; ++i)
 #pragma unroll
@@ -1239,8 +1240,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             const float4 p0 = part[(wave * 4 + 0) * 64 + lane], p1 = part[(wave * 4 + 1) * 64 + lane];
             const float4 p2 = part[(wave * 4 + 2) * 64 + lane], p3 = part[(wave * 4 + 3) * 64 + lane];
             rec = (f32x4){(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)};
-        } else if (s > 0) {
-            prefetch(s - 1);
+        } else {
+            if (s > 1) prefetch(s - 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // first step only: the operands of step S-2 (issued in the prologue)
         }
         PSTAMP(3);
         if (s < 0) {
@@ -1271,9 +1273,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             og0 = make_uint4(og[0] | ((unsigned)og[1] << 16), og[2] | ((unsigned)og[3] << 16), og[4] | ((unsigned)og[5] << 16), og[6] | ((unsigned)og[7] << 16));
             og1 = make_uint4(og[8] | ((unsigned)og[9] << 16), og[10] | ((unsigned)og[11] << 16), og[12] | ((unsigned)og[13] << 16), og[14] | ((unsigned)og[15] << 16));
         }
-        // the prefetch DMA of the next step's operands was issued before the MFMAs: landed by now (cheap wait); from here
-        // on nothing of this step is ever waited for -- the stores below are fire-and-forget
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // nothing of this step is ever waited for from here on: the stores below are fire-and-forget, and the operands the
+        // side work reads were fetched two steps ago
         if (s > 0 || want0) {
             if (own) {
                 // exchange copy for the next step's consumers: gate columns u0*4 .. u0*4+15 = k-block ut*2 + fq/2,
@@ -1479,7 +1480,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
         return E2T_ERR_ARG;
     }
     pa.fstride = wide ? 128 : 32;
-    const size_t lds = (size_t)(4 * 2 * E2T_BWD_PRE16 + 16 * 64) * 16;
+    const size_t lds = (size_t)(4 * 3 * E2T_BWD_PRE16 + 16 * 64) * 16;
 #define E2T_PERSIST_CASE(K, W) case K: hipLaunchKernelGGL((k_lstm_seq_bwd_persist<K, W>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
     if (!wide) {
         switch (KQ) {
