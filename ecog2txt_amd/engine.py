@@ -492,12 +492,14 @@ class _Lstm:
         self.eng.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, ws['M'], self.N4,
                       self.in_ld, bias=self.bias_ptr(src))
 
-    def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None, gx_done=False):
+    def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None, gx_done=False, after_gx=None):
         e = self.eng
         M = ws['M']
         if steps is None:
             if not gx_done:
                 self.fwd_gx(ws, x_ptr, src)
+            if after_gx is not None:
+                after_gx()
             steps = (0, ws['S'])
         if e.persistent_fwd and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
             # whole sequence in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_fwd_persist)
@@ -898,7 +900,7 @@ class Seq2SeqEngine:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
 
     # ------------------------------------------------------------------ forward
-    def encode(self, ws, src, train, after_layer=None, after_first=None):
+    def encode(self, ws, src, train, after_layer=None, after_first=None, after_gx=None):
         s = self.spec
         B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
         st = self.stream
@@ -912,7 +914,7 @@ class Seq2SeqEngine:
                   drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B))
         x = ws['E'].data_ptr()
         for l, (lay, lw) in enumerate(zip(self.enc, ws['enc'])):
-            lay.fwd(lw, x, ws['lens_d'], src, train)
+            lay.fwd(lw, x, ws['lens_d'], src, train, after_gx=(lambda l=l: after_gx(l)) if after_gx is not None else None)
             x = lw['Ydrop'].data_ptr()
             if after_layer is not None:
                 after_layer(l)
@@ -980,14 +982,19 @@ class Seq2SeqEngine:
             if ahead:
                 pend['dec'] = self.run_side(ev0, dec_prep)
 
-        def after_layer(l):
-            # the auxiliary head taps layer aux_layer: its forward starts as soon as that layer is done (side stream,
-            # under the layers above), so that the decoder has the chip to itself
-            if ahead and ws['use_aux'] and l == s.aux_layer:
+        def after_gx(l):
+            # the auxiliary head taps layer aux_layer: its forward starts once the NEXT layer's input projection is done,
+            # i.e. under that layer's recurrence (latency-bound, 56 CUs idle) rather than next to the projection GEMM
+            # (which it slowed from 69 to 96 us), and long before the decoder, which then has the chip to itself
+            if ahead and ws['use_aux'] and l == s.aux_layer + 1:
                 pend['aux_ev'] = self.fork_point()
+
+        def after_layer(l):
+            if ahead and ws['use_aux'] and l == s.aux_layer and l == len(self.enc) - 1:
+                pend['aux_ev'] = self.fork_point()         # the head taps the top layer: under the decoder
             elif 'aux_ev' in pend:
                 joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
-        self.encode(ws, src, train, after_layer, after_first)
+        self.encode(ws, src, train, after_layer, after_first, after_gx)
         if 'aux_ev' in pend:
             joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
         jdec = pend.get('dec')
