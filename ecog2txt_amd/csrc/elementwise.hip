@@ -31,6 +31,16 @@ __global__ __launch_bounds__(1024) void k_seq_lengths_f32(const float* x, int T,
             for (int i = 0; i < 8; ++i)
                 if (__any((v[i].x != 0.f) | (v[i].y != 0.f) | (v[i].z != 0.f) | (v[i].w != 0.f))) cnt++;      // wave-uniform
         }
+    } else if (C <= 32) {
+        // narrow rows (the 13 MFCCs of the auxiliary targets): a wave per row is one dependent ~1-us load per row
+        // (54 us for 5 MB, slowing the GEMM it ran next to); here a LANE owns a row and its C loads are independent
+        for (int t = threadIdx.x; t < T; t += 1024) {
+            const float* row = xb + (size_t)t * C;
+            bool nz = false;
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) nz |= row[c] != 0.f;
+            cnt += __popcll(__ballot(nz)) ;            // wave-uniform count of this pass's non-zero rows
+        }
     } else {
         for (int t = wave; t < T; t += 16) {
             const float* row = xb + (size_t)t * C;
@@ -69,8 +79,12 @@ __global__ void k_seq_lengths_i32(const int* x, int B, int L, int pad, int div, 
 // out[0] = sum_b x[b]   (single block, deterministic)
 __global__ __launch_bounds__(256) void k_sum_i32(const int* x, int n, int* out) {
     __shared__ int sh[256];
-    int acc = 0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    // 4 loads in flight per thread (a single dependent chain over 8704 elements took 20 us); the association is fixed
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) { a0 += x[i]; a1 += x[i + 256]; a2 += x[i + 512]; a3 += x[i + 768]; }
+    for (; i < n; i += 256) a0 += x[i];
+    int acc = (a0 + a1) + (a2 + a3);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -83,8 +97,12 @@ __global__ __launch_bounds__(256) void k_sum_i32(const int* x, int n, int* out) 
 // out[slot] = scale * sum_i x[i] / max(*count,1)  (single block, fixed order => deterministic)
 __global__ __launch_bounds__(256) void k_sum_f32(const float* x, int n, const int* count, float scale, float* out) {
     __shared__ float sh[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    // 4 loads in flight per thread (a single dependent chain over 8704 elements took 20 us); the association is fixed
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) { a0 += x[i]; a1 += x[i + 256]; a2 += x[i + 512]; a3 += x[i + 768]; }
+    for (; i < n; i += 256) a0 += x[i];
+    float acc = (a0 + a1) + (a2 + a3);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
