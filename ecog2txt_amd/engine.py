@@ -900,7 +900,7 @@ class Seq2SeqEngine:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
 
     # ------------------------------------------------------------------ forward
-    def encode(self, ws, src, train, after_layer=None, after_first=None, after_gx=None):
+    def encode(self, ws, src, train, after_layer=None, after_first=None, after_gx=None, before_weights=None):
         s = self.spec
         B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
         st = self.stream
@@ -908,6 +908,8 @@ class Seq2SeqEngine:
         if after_first is not None:
             after_first()
         lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
+        if before_weights is not None:
+            before_weights()
         self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
                   M, s.enc_embed, ws['Kc8'],
                   bias=self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed), relu=s.conv_relu, out_bf16=True,
@@ -923,7 +925,7 @@ class Seq2SeqEngine:
         lib.e2t_final_state(lw['Yext'].data_ptr(), last.ldy, lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), B, last.H,
                             ws['dec']['Yext'].data_ptr(), self.dec.ldy, ws['c0'].data_ptr(), st)
 
-    def forward(self, ws, train=True, which=None, with_aux=True):
+    def forward(self, ws, train=True, which=None, with_aux=True, pack_first=False):
         """Teacher-forced forward incl. losses and d(logits); leaves everything backward needs in ws."""
         s = self.spec
         src = getattr(self.store, which or 'p')
@@ -980,7 +982,15 @@ class Seq2SeqEngine:
         def after_first():
             # (side work is enqueued AFTER the main branch's next kernel: see fork_point)
             if ahead:
+                if pack_first:
+                    # the operand re-pack of the optimiser step that came before runs here, next to the weight-free
+                    # start of the front-end (lengths, im2row) instead of in front of it
+                    pend['pack'] = self.run_side(ev0, lambda: self.pack(which or 'p'))
                 pend['dec'] = self.run_side(ev0, dec_prep)
+
+        def before_weights():
+            if 'pack' in pend:
+                self.join_side(pend.pop('pack'))
 
         def after_gx(l):
             # the auxiliary head taps layer aux_layer: its forward starts once the NEXT layer's input projection is done,
@@ -994,7 +1004,9 @@ class Seq2SeqEngine:
                 pend['aux_ev'] = self.fork_point()         # the head taps the top layer: under the decoder
             elif 'aux_ev' in pend:
                 joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
-        self.encode(ws, src, train, after_layer, after_first, after_gx)
+        if (pack_first and not ahead) or (not pack_first and self._packed != (which or 'p')):
+            self.pack(which or 'p')        # (a captured train step leaves the images one update behind: see train_step)
+        self.encode(ws, src, train, after_layer, after_first, after_gx, before_weights)
         if 'aux_ev' in pend:
             joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
         jdec = pend.get('dec')
@@ -1247,8 +1259,9 @@ class Seq2SeqEngine:
         return ws['dX']
 
     # ------------------------------------------------------------------ optimiser
-    def adam_step(self, sid=None):
-        """Adam + EMA on the shared body and (if given) subject `sid`'s conv; then re-pack operands."""
+    def adam_step(self, sid=None, repack=True):
+        """Adam + EMA on the shared body and (if given) subject `sid`'s conv; then re-pack operands (repack=False: the
+        caller does it at the start of its next forward pass, see forward(pack_first=True))."""
         store = self.store
         st = self.stream
         lib.e2t_inc_step(self.step_t.data_ptr(), st)
@@ -1260,7 +1273,10 @@ class Seq2SeqEngine:
             lib.e2t_adam_ema_step(store.p.data_ptr() + o, store.g.data_ptr() + o, store.m.data_ptr() + o,
                                   store.v.data_ptr() + o, store.ema.data_ptr() + o, b - a, self.step_t.data_ptr(),
                                   C.byref(h), st)
-        self.pack('p')
+        if repack:
+            self.pack('p')
+        else:
+            self._packed = None
 
     def trainable_ranges(self, sid=None):
         """Contiguous [a,b) element ranges of the flat buffers that receive updates."""
@@ -1287,9 +1303,10 @@ class Seq2SeqEngine:
 
         sync: optional parallel.GradSync; each backward stage's gradient ranges are all-reduced
         asynchronously right after the stage is enqueued, and Adam waits for all of them."""
-        if self._packed != 'p':
-            self.pack('p')
         dp = sync is not None and sync.world > 1
+        lazy = use_graph and not dp and self.overlap and self._ovl in ('1', 'auxf', 'tail')      # re-pack inside the graph
+        if self._packed != 'p' and not lazy:
+            self.pack('p')
         self.grad_scale = sync.grad_scale if dp else 1.0
 
         def after(i, ranges):
@@ -1308,7 +1325,7 @@ class Seq2SeqEngine:
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture
-            self.forward(ws, train=True)
+            self.forward(ws, train=True, pack_first=lazy)
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
             if dp:
@@ -1345,13 +1362,14 @@ class Seq2SeqEngine:
             else:
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
-                    self.forward(ws, train=True)
+                    self.forward(ws, train=True, pack_first=True)
                     self.backward(ws, train=True)
-                    self.adam_step(ws['sid'])
+                    self.adam_step(ws['sid'], repack=False)
                 g = (g1,)
             ws['graph'][key] = g
         if not dp:
             g[0].replay()
+            self._packed = None          # the images are those of the weights BEFORE this step's update
             return
         cur = torch.cuda.current_stream(self.device)
 
