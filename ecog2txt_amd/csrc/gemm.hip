@@ -178,7 +178,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     // 16-B chunk position inside a row is XOR-swizzled with tn_swz(k-row) on the SOURCE side, rows k >= K come from a zero
     // page, columns beyond M/N are clamped (their products are never stored).  Fragments are then gathered with the
     // transposing LDS read (ds_read_b64_tr_b16, lane mapping verified by scripts/probes/trread_probe.hip).
-    auto tn_swz = [](int row) { return (row & 3) | (((row >> 3) & 3) << 2); };
+    // The 32 lanes of one read phase take 32 B from each of 8 k-rows (4 consecutive ones of two fq groups, 8 rows apart); a
+    // k-row is a multiple of 256 B = the 64-bank window, so the swizzle must send those 8 rows to 8 different 32-B slots,
+    // i.e. act on chunk bits 1..3 (SQ_LDS_BANK_CONFLICT: 50 % of the LDS cycles with the swizzle on bits 0..3 -> 0).
+    auto tn_swz = [](int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); };
     // one DMA instruction (1 KiB) of tile t into stage buf: pieces 0..IA-1 belong to the A tile, IA..IA+IB-1 to the B tile
     constexpr int NP = IA + IB;
     auto issue_piece = [&](int t, int buf, int pc_) {
