@@ -34,3 +34,18 @@ for mode in ('1', '0'):
     b = timeit(lambda: lay.bwd_rec(lw, x, ws['dlens'], ws['dHd'].data_ptr(), lay.ldy, True, None, 0, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0']))
     print('decoder S=%d persistent=%s: fwd %.1f us (%.2f us/step)   bwd %.1f us (%.2f us/step incl. pseudo-step)' % (S, mode, f, f / S, b, b / (S + 1)))
 assert int(eng.sync_err[0].item()) == 0
+if os.environ.get('TIMELINE'):
+    # per-wave phase stamps of the persistent BPTT (wide instance) at step S/2
+    import numpy as np
+    eng.persistent_fwd = eng.persistent_bwd = True
+    dbg = torch.zeros(256 * 8 * 8 + 2048, dtype=torch.int64, device='cuda')
+    os.environ['E2T_LSTM_DBG'] = str(dbg.data_ptr())
+    lay.bwd_rec(lw, x, ws['dlens'], ws['dHd'].data_ptr(), lay.ldy, True, None, 0, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'])
+    torch.cuda.synchronize()
+    del os.environ['E2T_LSTM_DBG']
+    t = dbg.cpu().numpy()[:200 * 4 * 8].reshape(-1, 8)[:, :7]
+    t = t[t[:, 0] > 0]
+    dd = np.diff((t - t[:, :1]) / 100.0, axis=1)
+    names = ['state of row tile 0 landed', '(same)', 'mma + reduce', 'exchange stored', '(same)', 'side work']
+    print('decoder BPTT step %d, %d waves; phase durations (us): ' % (S // 2, len(t)) +
+          ' | '.join('%s: med %.2f p90 %.2f' % (names[i], np.median(dd[:, i]), np.percentile(dd[:, i], 90)) for i in range(6)))
