@@ -605,8 +605,8 @@ __global__ void k_inc_step(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0)
 
 __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n,
                                                    const int* step, float lr, float b1, float b2, float eps, float decay,
-                                                   float gscale) {
-    const float t = (float)(*step);
+                                                   float gscale, int step_offset) {
+    const float t = (float)(*step + step_offset);
     const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * gscale;
@@ -756,6 +756,6 @@ extern "C" int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, f
     if (n == 0) return E2T_OK;
     size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adam_ema, dim3((unsigned)blocks), dim3(256), 0, ST, p, g, m, v, ema, n, step, h->lr, h->beta1, h->beta2,
-                       h->eps, h->ema_decay, h->grad_scale);
+                       h->eps, h->ema_decay, h->grad_scale, h->step_offset);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }

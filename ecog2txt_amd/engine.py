@@ -1123,7 +1123,10 @@ class Seq2SeqEngine:
         main(train)
         self.join_side(join)
 
-    def backward(self, ws, train=True, after_stage=None):
+    def backward(self, ws, train=True, after_stage=None, early=None):
+        """early = (stage index, fn): fn() is queued on the side stream right behind that stage's side work (the optimiser
+        update of the parameter ranges whose gradients are complete by then: HBM-bound, next to the compute-bound
+        weight-gradient GEMMs of the remaining stages)."""
         ws['have_dy'] = [False] * len(self.enc)
         ws['_aux_join'] = None
         deferred = []
@@ -1149,6 +1152,8 @@ class Seq2SeqEngine:
                 ev = self.fork_point()
                 main(train)
                 deferred.append(self.run_side(ev, lambda side=side: side(train)))
+                if early is not None and early[0] == i:
+                    deferred.append(self.run_side(ev, early[1]))
             else:
                 self.run_stage(main, side, train)
             if after_stage:
@@ -1259,9 +1264,23 @@ class Seq2SeqEngine:
         return ws['dX']
 
     # ------------------------------------------------------------------ optimiser
-    def adam_step(self, sid=None, repack=True):
+    def adam_ranges(self, ranges, step_offset=0):
+        """Adam + EMA on [a,b) element ranges of the flat buffers (step_offset=1: before this step's e2t_inc_step)."""
+        store = self.store
+        st = self.stream
+        h = H.AdamHyper()
+        h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
+        h.ema_decay, h.grad_scale, h.step_offset = self.hyper['ema_decay'], self.grad_scale, step_offset
+        for a, b in ranges:
+            o = 4 * a
+            lib.e2t_adam_ema_step(store.p.data_ptr() + o, store.g.data_ptr() + o, store.m.data_ptr() + o,
+                                  store.v.data_ptr() + o, store.ema.data_ptr() + o, b - a, self.step_t.data_ptr(),
+                                  C.byref(h), st)
+
+    def adam_step(self, sid=None, repack=True, skip_below=0):
         """Adam + EMA on the shared body and (if given) subject `sid`'s conv; then re-pack operands (repack=False: the
-        caller does it at the start of its next forward pass, see forward(pack_first=True))."""
+        caller does it at the start of its next forward pass, see forward(pack_first=True)).  skip_below: elements
+        [0, skip_below) were already updated by adam_ranges(..., step_offset=1)."""
         store = self.store
         st = self.stream
         lib.e2t_inc_step(self.step_t.data_ptr(), st)
@@ -1269,6 +1288,9 @@ class Seq2SeqEngine:
         h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
         h.ema_decay, h.grad_scale = self.hyper['ema_decay'], self.grad_scale
         for a, b in self.trainable_ranges(sid):
+            a = max(a, skip_below)
+            if b <= a:
+                continue
             o = 4 * a
             lib.e2t_adam_ema_step(store.p.data_ptr() + o, store.g.data_ptr() + o, store.m.data_ptr() + o,
                                   store.v.data_ptr() + o, store.ema.data_ptr() + o, b - a, self.step_t.data_ptr(),
@@ -1360,11 +1382,22 @@ class Seq2SeqEngine:
                     self.adam_step(ws['sid'])
                 g = (graphs, ga)
             else:
+                # parameters whose gradients are final two stages before the end (head, decoder, top encoder layers, an
+                # auxiliary head above the bottom layers) are updated on the side stream under the remaining stages
+                nl = len(self.enc)
+                early_end, early = 0, None
+                if nl >= 2 and self.overlap and self._ovl == '1' and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
+                    early_end = self.store.seg_range('enc%d.Wx' % (nl - 2))[0]
+                    er = [(a, min(b, early_end)) for a, b in self.trainable_ranges(ws['sid']) if a < early_end]
+                    if er:
+                        early = (2, lambda: self.adam_ranges(er, step_offset=1))      # stage 2's side = weights of the top layer
+                    else:
+                        early_end = 0
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     self.forward(ws, train=True, pack_first=True)
-                    self.backward(ws, train=True)
-                    self.adam_step(ws['sid'], repack=False)
+                    self.backward(ws, train=True, early=early)
+                    self.adam_step(ws['sid'], repack=False, skip_below=early_end)
                 g = (g1,)
             ws['graph'][key] = g
         if not dp:

@@ -40,7 +40,7 @@ class PackDesc(C.Structure):
 
 class AdamHyper(C.Structure):
     _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
-                ('ema_decay', C.c_float), ('grad_scale', C.c_float)]
+                ('ema_decay', C.c_float), ('grad_scale', C.c_float), ('step_offset', C.c_int)]
 
 
 _p, _i, _f, _l, _z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t

@@ -197,7 +197,11 @@ int e2t_mse(const float* P, int ldp, const float* At, int M, int K, const int32_
             const int32_t* nval, float weight, float* rowloss, void* dP, int lddp, void* stream);
 
 /* ---- a10: Adam + EMA (EMA_decay, mocha-1_word_sequence.yaml:5) ---- */
-typedef struct e2t_adam_hyper { float lr, beta1, beta2, eps, ema_decay, grad_scale; } e2t_adam_hyper;
+typedef struct e2t_adam_hyper {
+    float lr, beta1, beta2, eps, ema_decay, grad_scale;
+    int step_offset;       /* the update uses t = *step + step_offset (1: a range updated before e2t_inc_step has run, while
+                              other kernels of the same train step still key their dropout masks on *step) */
+} e2t_adam_hyper;
 int e2t_inc_step(int32_t* step, void* stream);
 int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,
                       const e2t_adam_hyper* h /* host pointer */, void* stream);
