@@ -1124,7 +1124,7 @@ class Seq2SeqEngine:
         self.join_side(join)
 
     def backward(self, ws, train=True, after_stage=None, early=None):
-        """early = (stage index, fn): fn() is queued on the side stream right behind that stage's side work (the optimiser
+        """early = {stage index: fn}: fn() is queued on the side stream right behind that stage's side work (the optimiser
         update of the parameter ranges whose gradients are complete by then: HBM-bound, next to the compute-bound
         weight-gradient GEMMs of the remaining stages)."""
         ws['have_dy'] = [False] * len(self.enc)
@@ -1152,8 +1152,8 @@ class Seq2SeqEngine:
                 ev = self.fork_point()
                 main(train)
                 deferred.append(self.run_side(ev, lambda side=side: side(train)))
-                if early is not None and early[0] == i:
-                    deferred.append(self.run_side(ev, early[1]))
+                if early is not None and i in early:
+                    deferred.append(self.run_side(ev, early[i]))
             else:
                 self.run_stage(main, side, train)
             if after_stage:
@@ -1387,12 +1387,19 @@ class Seq2SeqEngine:
                 nl = len(self.enc)
                 early_end, early = 0, None
                 if nl >= 2 and self.overlap and self._ovl == '1' and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
-                    early_end = self.store.seg_range('enc%d.Wx' % (nl - 2))[0]
-                    er = [(a, min(b, early_end)) for a, b in self.trainable_ranges(ws['sid']) if a < early_end]
-                    if er:
-                        early = (2, lambda: self.adam_ranges(er, step_offset=1))      # stage 2's side = weights of the top layer
-                    else:
-                        early_end = 0
+                    # stage i (2 <= i <= nl) queues the weight gradients of layer nl-i+1 on the side stream: behind them,
+                    # everything in front of layer nl-i's segment is final
+                    early, lo = {}, 0
+                    tr = self.trainable_ranges(ws['sid'])
+                    for i in range(2, nl + 1):
+                        hi = self.store.seg_range('enc%d.Wx' % (nl - i))[0]
+                        er = [(max(a, lo), min(b, hi)) for a, b in tr if a < hi and b > lo]
+                        if er:
+                            early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
+                        lo = hi
+                    early_end = lo
+                    if not early:
+                        early, early_end = None, 0
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     self.forward(ws, train=True, pack_first=True)
