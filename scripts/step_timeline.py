@@ -3,8 +3,16 @@ import csv, sys
 tr = list(csv.DictReader(open(sys.argv[1])))
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(tr) if r['Kernel_Name'].startswith('k_adam_ema')]
-seg = tr[adam[-5] + 1:adam[-4] + 1]
+# a step ends with k_inc_step + the final optimiser launch(es) (earlier k_adam_ema launches of a step belong to ranges that
+# are updated under the remaining backward stages)
+ends = []
+for i, r in enumerate(tr):
+    if r['Kernel_Name'].startswith('k_inc_step'):
+        j = i
+        while j + 1 < len(tr) and tr[j + 1]['Kernel_Name'].startswith('k_adam_ema'):
+            j += 1
+        ends.append(j)
+seg = tr[ends[-5] + 1:ends[-4] + 1]
 t0 = int(seg[0]['Start_Timestamp'])
 busy = 0.0
 for r in seg:
