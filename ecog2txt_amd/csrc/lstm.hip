@@ -407,8 +407,8 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
 //     publishing, so nothing is overwritten early.  The protocol is placement-independent; clusters are laid on XCDs
 //     (workgroup id % 8 = XCC id, read back from HW_REG_XCC_ID by scripts/probes/xchg_probe.hip) only for speed;
 //   * everything that is not on the h_t -> h_{t+1} critical path (gate / cell saves, the Philox mask and the
-//     dropped copy for the next layer, the Gx prefetch of the next step) is issued AFTER the exchange store and runs
-//     while the other workgroups' stores are in flight.
+//     dropped copy for the next layer) is issued AFTER the exchange store and runs while the other workgroups' stores
+//     are in flight; Gx is prefetched two steps ahead, right after a step's state has landed.
 // All workgroups must be co-resident (one per CU: checked on the host against the CU count); every spin is
 // bounded and raises err[0] instead of hanging.
 // ---------------------------------------------------------------------------
@@ -1027,10 +1027,11 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
 //                the step-parity exchange buffer `dgx` in MFMA operand order, sc1);
 //   reduction  : the 4 partial 16x16 tiles per unit tile go through LDS (one barrier), summed as (P0+P1)+(P2+P3);
 //   cell phase : wave w finishes unit tile ug*4 + w: lane (frow, fq) = utterance rt*16+frow, units u0..u0+3.
-// Everything that does not depend on dh_rec -- the saved gates and cells, dY, the Philox mask, tanh(c) and the
-// gate-derivative factors -- is fetched by LDS-DMA one step ahead and folded into 7 factors per cell after the
-// publish, so the critical path per step is: poll, KQ loads, 4*KQ MFMAs, LDS reduce, ~12 FMAs per cell, store, ack.
-// The hand-off protocol is the forward kernel's (per-wave flag words, bounded spins, err[0] on timeout); dc is
+// Everything that does not depend on dh_rec -- the saved gates and cells, dY, tanh(c) and the gate-derivative
+// factors -- is fetched by LDS-DMA two steps ahead (ring of three buffers) and folded into 7 factors per cell after
+// the publish, so the critical path per step is: KQ stamped loads (retried until fresh), 4*KQ MFMAs, LDS reduce,
+// ~12 FMAs per cell, stamped store.  The hand-off protocol is the forward kernel's (a 1-bit stamp in bit 14 of every
+// bf16, bounded retries, err[0] on timeout; the exchange copy saturates at |x| < 2); dc is
 // carried in registers; the row-major time-indexed dG for the weight-gradient GEMMs is written off the critical
 // path.  The summation order differs from k_lstm_step_bwd (4 K-quarters vs 2 interleaved halves), so results
 // agree with it to fp32 round-off, not bit for bit.
@@ -1038,9 +1039,9 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
 struct LstmBwdPersistArgs {
     LstmBwdArgs a;
     bf16_t* dgx;            // [2 step parities][ndir][RT][4*KQ][64 lanes][8]  dG exchange, MFMA operand order; zero-filled once
-    unsigned* flags;        // [clusters][fstride]: per-producer-wave published-step counts (never reset); last word of a row = launch count
+    unsigned* flags;        // [clusters][fstride]: only the last word of a row is used: the stamps the cluster's buffers were left with
     int* err;
-    int fstride;            // flag words per cluster (>= 4 waves x workgroups of a cluster)
+    int fstride;            // words per cluster row
 };
 #define E2T_BWD_PRE16 (6 * 64)              // 16-B units of one prefetch buffer: Gs 4 KiB, Cs 1 KiB, dY 1 KiB
 

@@ -460,7 +460,7 @@ class _Lstm:
         ws['xT'][self.D, :M] = 1.0
         ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
         kq = H.load().e2t_bwd_persist_kq(Hh)
-        if kq:      # persistent BPTT: per-wave step flags + launch count, and the in-launch dG exchange (include/ecog2txt_hip.h)
+        if kq:      # persistent BPTT: per-cluster stamp state and the in-launch dG exchange (include/ecog2txt_hip.h)
             RT = ceil_div(B, 16)
             nflag = RT * nd * 32 if kq <= 13 else ceil_div(RT, 2) * nd * 128
             ws['counters'] = torch.zeros(nflag + 1, dtype=torch.int32, device=dev)
@@ -1034,8 +1034,9 @@ class Seq2SeqEngine:
         head -> BPTT(top) -> dX -> BPTT(next) -> ...; the weight gradients of a layer (operand transposes + split-K
         GEMMs, ~as long as a BPTT sweep) depend only on that layer's dG, so stage k runs BPTT + input gradient of
         layer l on the main stream and the weight gradients of layer l+1 on a side stream (a parallel branch of the
-        captured hipGraph).  The persistent recurrence is latency-bound and leaves most MFMA cycles (and 30-50 CUs)
-        idle; the GEMM workgroups co-reside with it (register / LDS budgets add up to less than a CU)."""
+        captured hipGraph).  The persistent recurrence is latency-bound and leaves most MFMA cycles (and 32-56 CUs)
+        idle; the side stream's GEMMs run on those CUs (the K-major instance needs more registers than a CU with a
+        BPTT workgroup has left: DESIGN.md 8.4)."""
         store = self.store
         nl = len(self.enc)
         stages = []
@@ -1456,7 +1457,7 @@ class Seq2SeqEngine:
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()
         if int(self.sync_err[0].item()) != 0:
-            # the exchange buffers / flag words of the persistent recurrences are now inconsistent: reset them so that
+            # the exchange buffers / stamp words of the persistent recurrences are now inconsistent: reset them so that
             # the next step starts clean, then fail loudly (E2T_PERSISTENT=0 selects the launch-per-step kernels)
             self.sync_err.zero_()
             for lw in list(ws['enc']) + [ws['dec']]:
