@@ -1,36 +1,31 @@
-// bf16 MFMA GEMM, "NT" form:  C[M][N] (+)= alpha * A[M][K] . B[N][K]^T  (+ fused epilogue)
+// bf16 MFMA GEMM with fp32 accumulation and a fused epilogue, in two operand forms:
+//   NT  C[M][N] (+)= alpha * A[M][K] . B[N][K]^T   both operands K-contiguous, the natural MFMA fragment order (each lane
+//       reads 8 consecutive k of its row / column with one ds_read_b128);
+//   TN  C[M][N] (+)= alpha * sum_k A[k][M] B[k][N]  both operands K-major -- the shape of every weight gradient (K = S*B
+//       rows of activations and of their gradients exactly as the layers wrote them): fragments are gathered from the
+//       K-major LDS tile with the transposing read ds_read_b64_tr_b16, no operand is transposed in memory.
 //
-// Both operands are K-contiguous, which is the natural MFMA fragment order
-// (each lane reads 8 consecutive k for its row/column), so no transposing read
-// is ever needed; callers that hold an operand in the other orientation run
-// e2t_transpose_bf16 first (DESIGN.md "GEMM orientation").
+// Instances of ONE template (tile BM x BN x 64, WM x WN waves):
+//   128 x 128, 4 waves as 2x2 (64x64 per wave, 64 fp32 accumulators per lane), 2 workgroups per CU -- small, split-K
+//              and epilogue-rich products, NT and TN;
+//   256 x 256, 8 waves as 2x4 (128x64 per wave, 128 accumulators), 1 workgroup per CU, 128 KiB of LDS -- large plain
+//              NT products (input projections): 128 flop per staged byte.
+// Staging: direct-to-LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction), two LDS stages, ONE barrier
+// per K tile: tile t+1 is in flight while tile t is multiplied.  NT image per operand: [rows][8 x 16-B chunks], chunk
+// index XOR-swizzled by (row & 7); TN image: [64 k-rows][BM columns], chunk index XOR-swizzled so that the 8 k-rows of a
+// transposing-read phase hit 8 different 32-B slots.  The DMA writes LDS linearly (wave base + lane*16), so the swizzle
+// is applied to the per-lane SOURCE address and again on the fragment read (cdna_hip_programming.md rule 21).  Both
+// layouts are conflict-free (SQ_LDS_BANK_CONFLICT = 0).  Rows beyond M/N are clamped to the last valid row (their
+// products land in output rows/columns that are never stored); an NT K tail (K % 64 != 0) is staged through registers
+// with zero fill, TN k-rows beyond K come from a zero page.
 //
-// Tile: TBM x TBN x 64 per workgroup of WM x WN waves (template).  Two instances:
-//   128 x 128, 4 waves as 2x2 (64x64 per wave, 64 fp32 accumulators per lane), 2 workgroups per CU -- small /
-//              split-K products; needs 64 B/clk of LDS-DMA per CU at MFMA peak, which IS the CU's fill rate;
-//   256 x 256, 8 waves as 2x4 (128x64 per wave, 128 accumulators), 1 workgroup per CU, 128 KiB of LDS -- large
-//              products: 128 flop per staged byte, so the DMA hides behind the MFMAs.
-// Staging: direct-to-LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave
-// instruction), two LDS buffers, ONE barrier per K tile: tile t+1 is in flight
-// while tile t is multiplied.  LDS image per operand: [128 rows][8 x 16-B
-// chunks] with the chunk index XOR-swizzled by (row & 7).  The DMA writes LDS
-// linearly (wave base + lane*16), so the swizzle is applied to the per-lane
-// SOURCE address and again on the fragment read (cdna_hip_programming.md rule
-// 21); the 8 lanes of a row still cover the same 128 B, so coalescing is kept.
-// Conflict-free for ds_read_b128 against the gfx950 lane-group table.
-// Rows beyond M/N are clamped to the last valid row (their products land in
-// output rows/columns that are never stored); a K tail (K % 64 != 0) is staged
-// through registers with zero fill.
+// Split-K (grid.y): weight-gradient GEMMs have K = S*B (8704) but only a few dozen output tiles; splitting K fills the
+// 256 CUs.  Partial tiles go to dense fp32 slabs in a caller-provided workspace and are summed in fixed order by
+// k_splitk_reduce, which applies the whole epilogue (deterministic; fp32 atomics were measured 5-10x slower: ~12 M
+// atomics per GEMM).  Batched launch (grid.z): several products of one shape with strided operands in one launch.
 //
-// Split-K (grid.y): weight-gradient GEMMs have K = S*B (8704) but only a few
-// dozen output tiles; splitting K fills the 256 CUs and shortens each block's
-// serial K loop.  Partial tiles go to dense fp32 slabs in a caller-provided
-// workspace and are summed in fixed order by k_splitk_reduce (deterministic;
-// fp32 atomics were measured 5-10x slower: ~12 M atomics per GEMM).
-//
-// Used for every non-recurrent matmul of the path (reference rows: conv a6,
-// LSTM input projections a7, aux head a8, vocab projection a9 and all their
-// weight/input gradients; SURVEY.md 2.3 K2,K3,K7,K8).
+// Used for every non-recurrent matmul of the path (reference rows: conv a6, LSTM input projections a7, aux head a8,
+// vocab projection a9 and all their weight/input gradients; SURVEY.md 2.3 K2,K3,K7,K8).
 #include "common.h"
 #include "ecog2txt_hip.h"
 #include <stdlib.h>
