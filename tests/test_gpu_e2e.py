@@ -175,3 +175,35 @@ def test_staged_step_with_a_real_rccl_group():
         assert eng.losses(ws)['total'] == pytest.approx(eng2.losses(ws2)['total'], rel=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_forward_after_a_captured_step_sees_the_updated_weights():
+    """The captured train step re-packs the bf16 operand images at its START (next to the weight-free front-end), so
+    after it returns they are one update behind the fp32 masters: a forward pass that follows must re-pack first."""
+    from test_gpu_parity import build, SPECS
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    eng, ws, ospec, P, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=3)
+    for _ in range(3):
+        eng.train_step(ws, use_graph=True)
+    eng.forward(ws, train=False)
+    torch.cuda.synchronize()
+    got = eng.losses(ws)
+    ref = Seq2SeqEngine(NetSpec(**SPECS['small_dropout']), device='cuda:0', seed=11)
+    ref.store.p.copy_(eng.store.p); ref.store.ema.copy_(eng.store.ema)
+    ref.pack('p')
+    ws2 = ref.workspace(401, 19, 26, 6)
+    ref.set_batch(ws2, batch)
+    ref.forward(ws2, train=False)
+    torch.cuda.synchronize()
+    want = ref.losses(ws2)
+    assert got['total'] == pytest.approx(want['total'], rel=1e-6)
+    # and the weights did move
+    assert got['total'] < 0.999 * eng_initial_loss(SPECS['small_dropout'], batch)
+
+
+def eng_initial_loss(kw, batch):
+    from test_gpu_parity import build
+    eng, ws, *_ = build(kw, 19, 26, 6, seed=3)
+    eng.forward(ws, train=False)
+    torch.cuda.synchronize()
+    return eng.losses(ws)['total']
