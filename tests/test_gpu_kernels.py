@@ -306,3 +306,71 @@ def test_gemm_splitk_and_bias_column(hl, M, N, K):
     want = round_bf16(A) @ round_bf16(Bm).T
     np.testing.assert_allclose(host(c), want[:, :N], rtol=1e-5, atol=2e-4 * np.sqrt(K))
     np.testing.assert_allclose(host(colv), want[:, N], rtol=1e-5, atol=2e-4 * np.sqrt(K))
+
+
+def test_pack_batch_all_kinds(hl):
+    """Every descriptor kind of e2t_pack_batch against NumPy: strided cast (scalar and 16-B), transposing cast (scalar
+    and 16-B), MFMA fragment images (k-strided, k-contiguous, n-contiguous via LDS, gate-interleaved four-in-one)."""
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal(400000).astype(np.float32)
+    bt = torch.tensor(base, device='cuda')
+    U = hl.PACK_UNITS
+
+    def frag_image(Bn, Nn, Kk):                       # [NT][KB][64 lanes][8]: lane (n = l&15, kgroup = l>>4)
+        NT, KB = -(-Nn // 16), -(-Kk // 32)
+        out = np.zeros((NT, KB, 64, 8))
+        for nt in range(NT):
+            for kb in range(KB):
+                for l in range(64):
+                    n, k0 = nt * 16 + (l & 15), kb * 32 + (l >> 4) * 8
+                    for j in range(8):
+                        if n < Nn and k0 + j < Kk:
+                            out[nt, kb, l, j] = Bn[n, k0 + j]
+        return round_bf16(out)
+
+    cases = []          # (kind, src_off, s0, s1, d0, d1, ld, units, expected builder)
+    # 0 / 3: dst[r][c] = src[r*s0 + c*s1]
+    cases.append((0, 3, 37, 1, 20, 30, 32, 20 * 1, lambda off, s0, s1, d0, d1, ld: ('mat', np.array([[base[off + r * s0 + c * s1] for c in range(d1)] for r in range(d0)]))))
+    cases.append((3, 8, 1200, 1, 20, 1100, 1104, 20 * 2, cases[0][8]))
+    # 2 / 4: same mapping, source contiguous along r
+    cases.append((2, 5, 1, 70, 66, 50, 56, 2 * 1, cases[0][8]))
+    cases.append((4, 16, 1, 72, 68, 52, 56, 2 * 1, cases[0][8]))
+    # 1: fragment image of Bn[n][k] = src[n*s0 + k*s1]
+    fr = lambda off, s0, s1, d0, d1, ld: ('frag', np.array([[base[off + n * s0 + k * s1] for k in range(d1)] for n in range(d0)]))
+    cases.append((1, 7, 3, 61, 20, 40, 2, -(-(2 * 2) // 4), fr))                      # scalar path
+    cases.append((1, 12, 100, 1, 36, 72, 3, -(-(3 * 3) // 4), fr))                    # k-contiguous: 16-B loads
+    cases.append((5, 20, 1, 44, 40, 70, 3, -(-3 // 4) * 3, fr))                        # n-contiguous via LDS
+    descs = (hl.PackDesc * (len(cases) + 1))()
+    outs, nblk = [], 0
+    for i, (kind, off, s0, s1, d0, d1, ld, units, _) in enumerate(cases):
+        n_out = (-(-d0 // 16) * ld * 512) if kind in (1, 5) else d0 * ld
+        o = torch.full((n_out + 64,), 7.0, dtype=torch.bfloat16, device='cuda')
+        outs.append(o)
+        d = descs[i]
+        d.kind, d.first_block, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld, d.dst = kind, nblk, off, s0, s1, d0, d1, ld, o.data_ptr()
+        nblk += -(-units // U) if kind in (1, 3) else units
+    # 6: four gate images from a gate-interleaved source [k][unit*4 + gate]
+    Hh, Kk, s1 = 24, 40, 4 * 24
+    off6 = 100000
+    UT, KB = -(-Hh // 16), -(-Kk // 32)
+    o6 = torch.full((4 * UT * KB * 512 + 64,), 7.0, dtype=torch.bfloat16, device='cuda')
+    d = descs[len(cases)]
+    d.kind, d.first_block, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld, d.dst = 6, nblk, off6, 4, s1, Hh, Kk, KB, o6.data_ptr()
+    nblk += UT * KB
+    dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to('cuda')
+    hl.lib.e2t_pack_batch(dev.data_ptr(), len(cases) + 1, nblk, bt.data_ptr(), st())
+    torch.cuda.synchronize()
+    for (kind, off, s0, s1_, d0, d1, ld, units, build), o in zip(cases, outs):
+        what, ref = build(off, s0, s1_, d0, d1, ld)
+        got = o.float().cpu().numpy()
+        if what == 'mat':
+            g = got[:d0 * ld].reshape(d0, ld)
+            np.testing.assert_array_equal(g[:, :d1], round_bf16(ref), err_msg='kind %d' % kind)
+            assert np.all(g[:, d1:] == 7.0) and np.all(got[d0 * ld:] == 7.0)
+        else:
+            want = frag_image(ref, d0, d1)
+            np.testing.assert_array_equal(got[:want.size].reshape(want.shape), want, err_msg='kind %d' % kind)
+    got6 = o6.float().cpu().numpy()[:4 * UT * KB * 512].reshape(4, UT, KB, 64, 8)
+    for g in range(4):
+        Bn = np.array([[base[off6 + (n * 4 + g) + k * s1] for k in range(Kk)] for n in range(Hh)])
+        np.testing.assert_array_equal(got6[g], frag_image(Bn, Hh, Kk), err_msg='kind 6 gate %d' % g)
