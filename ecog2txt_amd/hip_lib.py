@@ -75,7 +75,7 @@ SIGNATURES = {
     'e2t_inc_step': [_p, _p],
     'e2t_adam_ema_step': [_p, _p, _p, _p, _p, _z, _p, C.POINTER(AdamHyper), _p],
 }
-PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int),
+PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_sizeof': ([_i], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int),
          'e2t_bwd_persist_kq': ([_i], C.c_int)}
 
 _lib = None

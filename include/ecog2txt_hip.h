@@ -36,6 +36,9 @@ extern "C" {
 #define E2T_ABI_VERSION 1
 
 int e2t_abi_version(void);
+/* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
+ * which = 0 e2t_gemm_epilogue, 1 e2t_lstm_desc, 2 e2t_pack_desc, 3 e2t_adam_hyper, 4 e2t_dropout; -1 for any other value */
+int e2t_sizeof(int which);
 const char* e2t_last_error(void);          /* thread-local, host pointer */
 /* number of compute units / XCDs of `device`, 0 if no device is usable */
 int e2t_device_cus(int device);

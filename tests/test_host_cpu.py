@@ -1,5 +1,6 @@
 """CPU-only checks of the host side: C-ABI library loads and exports every declared
 symbol; parameter store TF-layout import/export round-trips; oracle misc."""
+import ctypes
 import os
 import re
 
@@ -22,6 +23,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(hip_lib.SIGNATURES) | set(hip_lib.PLAIN)
     assert lib.e2t_abi_version() == 1
+    # the ctypes mirrors of the boundary structs have the C layouts' sizes
+    for which, cls in enumerate([hip_lib.GemmEpilogue, hip_lib.LstmDesc, hip_lib.PackDesc, hip_lib.AdamHyper, hip_lib.Dropout]):
+        assert lib.e2t_sizeof(which) == ctypes.sizeof(cls), cls.__name__
+    assert lib.e2t_sizeof(99) == -1
 
 
 def test_engine_refuses_without_gpu():
