@@ -1327,7 +1327,7 @@ class Seq2SeqEngine:
         sync: optional parallel.GradSync; each backward stage's gradient ranges are all-reduced
         asynchronously right after the stage is enqueued, and Adam waits for all of them."""
         dp = sync is not None and sync.world > 1
-        lazy = use_graph and not dp and self.overlap and self._ovl in ('1', 'auxf', 'tail')      # re-pack inside the graph
+        lazy = use_graph and self.overlap and self._ovl in ('1', 'auxf', 'tail')      # re-pack inside the (first) graph
         if self._packed != 'p' and not lazy:
             self.pack('p')
         self.grad_scale = sync.grad_scale if dp else 1.0
@@ -1363,7 +1363,7 @@ class Seq2SeqEngine:
                     gm = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gm):
                         if i == 0:
-                            self.forward(ws, train=True)
+                            self.forward(ws, train=True, pack_first=lazy)
                             ws['have_dy'] = [False] * len(self.enc)
                             self.run_stage(main, side, True)         # the aux head's backward feeds the chain: joined here
                         else:
@@ -1380,7 +1380,7 @@ class Seq2SeqEngine:
                     graphs.append((gm, gs, ranges))
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
-                    self.adam_step(ws['sid'])
+                    self.adam_step(ws['sid'], repack=not lazy)
                 g = (graphs, ga)
             else:
                 # parameters whose gradients are final two stages before the end (head, decoder, top encoder layers, an
@@ -1453,6 +1453,8 @@ class Seq2SeqEngine:
         replay_stages(ws['graph']['side_stream'], True)
         sync.wait()
         g[1].replay()
+        if lazy:
+            self._packed = None          # the images are those of the weights BEFORE this step's update
 
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()
