@@ -1451,6 +1451,20 @@ class Seq2SeqEngine:
                     best = (t, st)
             ws['graph']['side_stream'] = best[1]
         replay_stages(ws['graph']['side_stream'], True)
+        pend = getattr(sync, 'pending_ranges', None)
+        if pend and lazy and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
+            # the optimiser follows the exchange range by range (the ranges complete in backward order): only the last
+            # range's update is exposed behind its all-reduce, the earlier ones run under the later collectives
+            tr = self.trainable_ranges(ws['sid'])
+            for w, a, b in list(pend):
+                w.wait()                         # the current stream waits for this collective only
+                er = [(max(a, x), min(b, y)) for x, y in tr if x < b and y > a]
+                if er:
+                    self.adam_ranges(er, step_offset=1)
+            sync.wait()                          # (all done: clears the lists)
+            lib.e2t_inc_step(self.step_t.data_ptr(), self.stream)
+            self._packed = None
+            return
         sync.wait()
         g[1].replay()
         if lazy:

@@ -22,17 +22,21 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pending = []
+        self.pending_ranges = []           # (work, a, b) in issue order: lets the optimiser follow range by range
 
     def allreduce_range(self, a, b):
         """Asynchronously sum flat_grad[a:b] over ranks (no-op for one rank)."""
         if self.world == 1 or b <= a:
             return
-        self.pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        w = dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append(w)
+        self.pending_ranges.append((w, a, b))
 
     def wait(self):
         for w in self.pending:
             w.wait()
         self.pending = []
+        self.pending_ranges = []
 
     @property
     def grad_scale(self):

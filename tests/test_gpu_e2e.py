@@ -161,7 +161,9 @@ def test_staged_step_with_a_real_rccl_group():
                 self.world = 2
             def allreduce_range(self, a, b):
                 if b > a:
-                    self.pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                    w = dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True)
+                    self.pending.append(w)
+                    self.pending_ranges.append((w, a, b))        # the optimiser follows the exchange range by range
             grad_scale = 1.0
         eng, ws, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
         eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
