@@ -1,10 +1,23 @@
 #!/usr/bin/env bash
 # Build libecog2txt_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+# One object per source, compiled in parallel and only when the source (or a header) is newer; then one link.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 inc="$here/../../include"
 out="$here/../libecog2txt_hip.so"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$inc" -I"$here" \
-    "$here/runtime.hip" "$here/gemm.hip" "$here/lstm.hip" "$here/elementwise.hip" \
-    -o "$out" "$@"
+obj="$here/build"
+mkdir -p "$obj"
+srcs=(runtime gemm lstm elementwise comm)
+pids=()
+for s in "${srcs[@]}"; do
+    o="$obj/$s.o"
+    if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$inc/ecog2txt_hip.h" -nt "$o" ]; then
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$inc" -I"$here" -c "$here/$s.hip" -o "$o" "$@" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+objs=()
+for s in "${srcs[@]}"; do objs+=("$obj/$s.o"); done
+hipcc --offload-arch=gfx950 -fPIC -shared "${objs[@]}" -ldl -o "$out"
 echo "built $out"

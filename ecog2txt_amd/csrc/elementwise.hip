@@ -601,11 +601,12 @@ __global__ void k_greedy_update(const int* pred, int B, int l, int Lmax, int eos
 // ---------------------------------------------------------------------------
 // a10: fused Adam (TF1 AdamOptimizer form) + EMA shadow over a flat fp32 range
 // ---------------------------------------------------------------------------
-__global__ void k_inc_step(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+__global__ void k_inc_step(int* step, const int* skip) { if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip != 0)) step[0] += 1; }
 
 __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n,
                                                    const int* step, float lr, float b1, float b2, float eps, float decay,
-                                                   float gscale, int step_offset) {
+                                                   float gscale, int step_offset, const int* skip) {
+    if (skip && *skip != 0) return;          // the step's gradients are invalid (in-kernel wait timed out): no update
     const float t = (float)(*step + step_offset);
     const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -619,10 +620,42 @@ __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, floa
 }
 
 // ---------------------------------------------------------------------------
+// a2/a3 batch assembly: rows of a partition kept resident in HBM -> the step's batch buffers.  One workgroup column
+// per destination row; idx < 0 (or beyond the list) = padding utterance: the row is zero-filled, which is exactly what
+// the length kernels read as "no samples".  16-B accesses when the row size allows, HBM-bound copy.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rows(const unsigned* src, const int* idx, int n, size_t row_words, unsigned* dst) {
+    const int r = blockIdx.y;
+    const int i = (r < n) ? idx[r] : -1;
+    unsigned* d = dst + (size_t)r * row_words;
+    const unsigned* sp = (i >= 0) ? src + (size_t)i * row_words : nullptr;
+    const bool v4 = (row_words & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (v4) {
+        const size_t n4 = row_words >> 2;
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (size_t)gridDim.x * 256) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+            if (sp) v = __builtin_nontemporal_load((const u32x4_t*)sp + k);      // read once: keep it out of the caches
+            ((u32x4_t*)d)[k] = v;
+        }
+    } else {
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < row_words; k += (size_t)gridDim.x * 256) d[k] = sp ? sp[k] : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // C ABI wrappers
 // ---------------------------------------------------------------------------
 #define ST ((hipStream_t)stream)
 
+extern "C" int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, void* dst, void* stream) {
+    E2T_CHECK_ARG(src && dst && (idx || n == 0) && n >= 0 && rows_out >= n);
+    if (rows_out == 0 || row_words == 0) return E2T_OK;
+    size_t per = ((row_words & 3) == 0 ? row_words >> 2 : row_words);
+    unsigned bx = (unsigned)((per + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_gather_rows, dim3(bx, rows_out), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src, idx, n, row_words, (unsigned*)dst);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
 extern "C" int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream) {
     E2T_CHECK_ARG(x && lens && B > 0 && T > 0 && C > 0 && div > 0);
     hipLaunchKernelGGL(k_seq_lengths_f32, dim3(B), dim3(1024), 0, ST, x, T, C, div, lens, lens_div);
@@ -745,9 +778,9 @@ extern "C" int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, in
     hipLaunchKernelGGL(k_greedy_update, dim3((B + 255) / 256), dim3(256), 0, ST, pred, B, l, Lmax, eos, pad, done, out, next_tok);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
-extern "C" int e2t_inc_step(int32_t* step, void* stream) {
+extern "C" int e2t_inc_step(int32_t* step, const int32_t* skip_if_nonzero, void* stream) {
     E2T_CHECK_ARG(step);
-    hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(64), 0, ST, step);
+    hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(64), 0, ST, step, skip_if_nonzero);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,
@@ -756,6 +789,6 @@ extern "C" int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, f
     if (n == 0) return E2T_OK;
     size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adam_ema, dim3((unsigned)blocks), dim3(256), 0, ST, p, g, m, v, ema, n, step, h->lr, h->beta1, h->beta2,
-                       h->eps, h->ema_decay, h->grad_scale, h->step_offset);
+                       h->eps, h->ema_decay, h->grad_scale, h->step_offset, h->skip_if_nonzero);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }

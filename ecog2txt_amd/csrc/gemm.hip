@@ -47,7 +47,6 @@ struct GemmArgs {
     float* last_col_out;       // if set: column N-1 of the product goes to last_col_out[row] instead of C
     int splits;
     float* slab;               // split-K partials [splits][M][N] fp32 (dense), reduced by k_splitk_reduce
-    const bf16_t* zero_page;   // TN: 512 zero bytes for k-rows beyond K
     long long a_bs, b_bs, c_bs; // batched launch (grid.z): element strides of A, B, C between products
 };
 // product z of a batched launch: operands, output and slabs moved to that product's
@@ -59,6 +58,10 @@ __device__ __forceinline__ GemmArgs gemm_batch_view(const GemmArgs& in, int z) {
     if (in.slab) p.slab = in.slab + (size_t)z * in.splits * in.M * in.N;
     return p;
 }
+
+// 512 zero bytes for the k-rows of a K-major tile beyond K: a device global of this code object (zero-initialised when
+// the module is loaded), so no entry point ever allocates
+__device__ __attribute__((aligned(512))) bf16_t g_gemm_zero_page[256];
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ (row & 7)); }
 
@@ -192,13 +195,13 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
                 const int rb = (wave * IA + i) * RA, r = rb + lane / CA, pc = lane % CA;
                 const int c = pc ^ (tn_swz(r) & (CA - 1));
                 const int gm = min(m0 + c * 8, (p.M - 1) & ~7);    // 8-column chunks; lda % 8 == 0 keeps them in the row
-                const bf16_t* src = (k0 + r < p.K) ? p.A + (size_t)(k0 + r) * p.lda + gm : p.zero_page;
+                const bf16_t* src = (k0 + r < p.K) ? p.A + (size_t)(k0 + r) * p.lda + gm : g_gemm_zero_page;
                 dma16_to_lds(src, lds_addr_of(sa + rb * CA));
             } else {
                 const int rb = (wave * IB + i) * RB_, r = rb + lane / CB, pc = lane % CB;
                 const int c = pc ^ (tn_swz(r) & (CB - 1));
                 const int gn = min(n0 + c * 8, (p.N - 1) & ~7);
-                const bf16_t* src = (k0 + r < p.K) ? p.B + (size_t)(k0 + r) * p.ldb + gn : p.zero_page;
+                const bf16_t* src = (k0 + r < p.K) ? p.B + (size_t)(k0 + r) * p.ldb + gn : g_gemm_zero_page;
                 dma16_to_lds(src, lds_addr_of(sb + rb * CB));
             }
             return;
@@ -408,11 +411,6 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
     epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
 }
 
-static const bf16_t* gemm_zero_page() {
-    static bf16_t* zp = nullptr;
-    if (!zp) { if (hipMalloc(&zp, 512) != hipSuccess || hipMemset(zp, 0, 512) != hipSuccess) zp = nullptr; }
-    return zp;
-}
 
 static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
@@ -428,7 +426,6 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = 1.0f;
     p.splits = 1;
-    if (tn) { p.zero_page = gemm_zero_page(); if (!p.zero_page) { e2t_set_error("hipMalloc of the zero page failed"); return E2T_ERR_HIP; } }
     if (ep) {
         p.bias = ep->bias;
         p.mask_src = (const bf16_t*)ep->relu_bwd_src; p.ld_mask = ep->ld_relu_bwd_src;
@@ -442,8 +439,7 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     }
     E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
     // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("E2T_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+    static const int forced = [] { const char* e = getenv("E2T_GEMM_TILE"); return e ? atoi(e) : 0; }();      // (thread-safe init)
     // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
     // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
     // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
@@ -473,12 +469,9 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         p.splits = s;
         p.slab = (float*)ep->splitk_ws;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
-        if (e1 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e1)); return E2T_ERR_HIP; }
-        attr_done = true;
-    }
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
+    if (attr_rc != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); return E2T_ERR_HIP; }
     if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);

@@ -1334,8 +1334,8 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && d->ldy % 8 == 0 && d->ldy >= d->ndir * ((d->H + 7) / 8) * 8);
     E2T_CHECK_ARG(0 <= step_begin && step_begin <= step_end && step_end <= d->S);
-    static bool attr_done = false;
-    if (!attr_done) { if (int rc = set_big_lds((const void*)k_lstm_step_fwd)) return rc; attr_done = true; }
+    static const int attr_rc = set_big_lds((const void*)k_lstm_step_fwd);          // (thread-safe one-time init)
+    if (attr_rc) return attr_rc;
     LstmFwdArgs p{};
     p.Gx = Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
     p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
@@ -1427,8 +1427,8 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
     E2T_CHECK_ARG((dh0 == nullptr) == (dc0 == nullptr));
-    static bool attr_done = false;
-    if (!attr_done) { if (int rc = set_big_lds((const void*)k_lstm_step_bwd)) return rc; attr_done = true; }
+    static const int attr_rc = set_big_lds((const void*)k_lstm_step_bwd);
+    if (attr_rc) return attr_rc;
     LstmBwdArgs p{};
     p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
     p.dh_final = dh_final; p.dc_final = dc_final; p.dc_carry = dc_carry; p.dh0 = dh0; p.dc0 = dc0;

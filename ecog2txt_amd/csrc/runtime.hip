@@ -31,3 +31,24 @@ extern "C" int e2t_device_cus(int device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return prop.multiProcessorCount;
 }
+
+// CRC-32C of a host buffer with the SSE4.2 crc32 instruction (TFRecord / TF-checkpoint framing: rows a3, f1, f2)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const unsigned char* p, size_t n, uint32_t crc) {
+    unsigned long long c = crc ^ 0xFFFFFFFFu;
+    while (n && ((uintptr_t)p & 7)) { c = __builtin_ia32_crc32qi((unsigned)c, *p++); --n; }
+    for (; n >= 8; n -= 8, p += 8) c = __builtin_ia32_crc32di(c, *(const unsigned long long*)p);
+    while (n--) c = __builtin_ia32_crc32qi((unsigned)c, *p++);
+    return (uint32_t)c ^ 0xFFFFFFFFu;
+}
+static uint32_t crc32c_sw(const unsigned char* p, size_t n, uint32_t crc) {
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    while (n--) {
+        c ^= *p++;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+    }
+    return c ^ 0xFFFFFFFFu;
+}
+extern "C" uint32_t e2t_crc32c(const void* data, size_t n, uint32_t crc) {
+    static const bool hw = __builtin_cpu_supports("sse4.2");
+    return hw ? crc32c_hw((const unsigned char*)data, n, crc) : crc32c_sw((const unsigned char*)data, n, crc);
+}

@@ -8,6 +8,8 @@ stay abstract.  MFCC extraction / word-piece encoding are offline preprocessing 
 hot path and are not restated."""
 import os
 
+import zlib
+
 import numpy as np
 
 from . import text_dir as _default_text_dir
@@ -172,9 +174,13 @@ class ECoGDataGenerator:
     def _write_to_Protobuf(self, block):
         path = self.tf_record_partial_path.format(block)
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
-        with tfrecord.TFRecordWriter(path) as w:
+        # written under a private name and moved into place: the ranks of a data-parallel run may all find the file missing
+        # at once (their generators are deterministic, so the contents agree) and must never read a half-written one
+        tmp = '%s.tmp.%d' % (path, os.getpid())
+        with tfrecord.TFRecordWriter(tmp) as w:
             for example in self._ecog_token_generator(block):
                 w.write(tfrecord.encode_example(example))
+        os.replace(tmp, path)
 
     def write_to_Protobuf_maybe(self, sequence_type, block_set):
         """Write missing block files, then return the unique tokens of `sequence_type` in them."""
@@ -210,7 +216,8 @@ class SyntheticSpeechDataGenerator(ECoGDataGenerator):
     vocab_words = None        # optional explicit word list (without specials)
 
     def _rng(self, *key):
-        return np.random.default_rng([abs(hash(str(k))) % (2 ** 31) for k in (self.subj_id,) + key])
+        # (zlib.crc32, not hash(): PYTHONHASHSEED randomises str hashes per process, and every rank must see the same participant)
+        return np.random.default_rng([zlib.crc32(str(k).encode()) for k in (self.subj_id,) + key])
 
     def _sentences(self):
         vocab = self.vocab_words

@@ -874,6 +874,7 @@ class Seq2SeqEngine:
         Md = L * B
         ws['Md'] = Md
         ws['dlens'], ws['ntok'] = _i32(B, device=dev), _i32(1, device=dev)
+        ws['cnt_g'] = _i32(2, device=dev)         # data parallel: GLOBAL (all ranks) token / aux-sample counts of the batch
         ws['U'], ws['Tg'] = _i32(Md, device=dev), _i32(Md, device=dev)
         ws['e'] = _bf(Md, self.E8, device=dev)
         if self.E8 > s.dec_embed:
@@ -898,6 +899,24 @@ class Seq2SeqEngine:
         ws['Y'].copy_(torch.as_tensor(np.asarray(batch['decoder_targets']), dtype=torch.int32))
         if self.aux and 'encoder_targets' in batch:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
+
+    def set_global_counts(self, ws, ntok, nval=0):
+        """Data parallel: the batch's token count and auxiliary-sample count over ALL ranks (host integers; every rank
+        holds the targets of the whole global batch, or sums its own counts over the ranks once)."""
+        ws['cnt_g'].copy_(torch.tensor([max(int(ntok), 1), max(int(nval), 1)], dtype=torch.int32))
+        ws['global_counts'] = True
+
+    def local_counts(self, batch_Y, batch_A=None):
+        """(tokens, auxiliary samples) this rank's slice contributes, counted on the host exactly as the kernels do:
+        non-pad target tokens; ceil(valid target length / decimation) per utterance (non-zero rows / non-pad ids)."""
+        Y = np.asarray(batch_Y)
+        ntok = int((Y != PAD_ID).sum())
+        nval = 0
+        if batch_A is not None and self.aux is not None:
+            A = np.asarray(batch_A)
+            tl = (A != PAD_ID).sum(1) if A.ndim == 2 else (np.abs(A).max(axis=2) > 0).sum(1)
+            nval = int((-(-tl // self.spec.decimation)).sum())
+        return ntok, nval
 
     # ------------------------------------------------------------------ forward
     def encode(self, ws, src, train, after_layer=None, after_first=None, after_gx=None, before_weights=None):
@@ -925,14 +944,19 @@ class Seq2SeqEngine:
         lib.e2t_final_state(lw['Yext'].data_ptr(), last.ldy, lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), B, last.H,
                             ws['dec']['Yext'].data_ptr(), self.dec.ldy, ws['c0'].data_ptr(), st)
 
-    def forward(self, ws, train=True, which=None, with_aux=True, pack_first=False):
-        """Teacher-forced forward incl. losses and d(logits); leaves everything backward needs in ws."""
+    def forward(self, ws, train=True, which=None, with_aux=True, pack_first=False, global_counts=False):
+        """Teacher-forced forward incl. losses and d(logits); leaves everything backward needs in ws.
+        global_counts: normalise the losses by the counts in ws['cnt_g'] (set_global_counts: the token / auxiliary-sample
+        counts of the batch over ALL ranks) instead of this rank's own, so that the SUM of the ranks' gradients is the
+        gradient of the global mean loss whatever the shard sizes are."""
         s = self.spec
         src = getattr(self.store, which or 'p')
         B, T, L, S, M, Md, N = ws['B'], ws['T'], ws['L'], ws['S'], ws['M'], ws['Md'], s.decimation
         st = self.stream
         ws['use_aux'] = bool(self.aux and with_aux and s.aux_scale != 0.0)
         cat = s.aux_dist == 'categorical'
+        ntokp = ws['cnt_g'].data_ptr() if global_counts else ws['ntok'].data_ptr()
+        nvalp = (ws['cnt_g'].data_ptr() + 4) if global_counts else (ws['nval'].data_ptr() if self.aux else None)
 
         def aux_targets():
             st = self.stream
@@ -950,14 +974,14 @@ class Seq2SeqEngine:
             out = self.aux.fwd(ws['aux'], ws['enc'][k]['Ydrop'].data_ptr(), src, train)
             if cat:
                 lib.e2t_softmax_ce(out.data_ptr(), s.aux_dim, M, s.aux_dim, ws['At'].data_ptr(), ws['tlens_d'].data_ptr(), B,
-                                   ws['nval'].data_ptr(), s.aux_scale, ws['aux_rowloss'].data_ptr(), None, None,
+                                   nvalp, s.aux_scale, ws['aux_rowloss'].data_ptr(), None, None,
                                    ws['dP'].data_ptr(), rk(s.aux_dim), st)
-                lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0, ws['loss'].data_ptr() + 4, st)
+                lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, nvalp, 1.0, ws['loss'].data_ptr() + 4, st)
             else:
                 lib.e2t_mse(out.data_ptr(), s.aux_dim, ws['At'].data_ptr(), M, s.aux_dim, ws['tlens_d'].data_ptr(), B,
-                            ws['nval'].data_ptr(), s.aux_scale, ws['aux_rowloss'].data_ptr(), ws['dP'].data_ptr(),
+                            nvalp, s.aux_scale, ws['aux_rowloss'].data_ptr(), ws['dP'].data_ptr(),
                             rk(s.aux_dim), st)
-                lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, ws['nval'].data_ptr(), 1.0 / s.aux_dim,
+                lib.e2t_sum_f32(ws['aux_rowloss'].data_ptr(), M, nvalp, 1.0 / s.aux_dim,
                                 ws['loss'].data_ptr() + 4, st)
 
         def dec_prep():
@@ -1021,10 +1045,10 @@ class Seq2SeqEngine:
         self.dec.fwd(ws['dec'], ws['e'].data_ptr(), ws['dlens'], src, train, c0=ws['c0'], gx_done=True)
         logits = self.proj.fwd(ws['proj'], ws['dec']['Ydrop'].data_ptr(), src, train)
         lib.e2t_softmax_ce(logits.data_ptr(), s.vocab, Md, s.vocab, ws['Tg'].data_ptr(), ws['dlens'].data_ptr(), B,
-                           ws['ntok'].data_ptr(), s.dec_scale, ws['rowloss'].data_ptr(), ws['pred'].data_ptr(),
+                           ntokp, s.dec_scale, ws['rowloss'].data_ptr(), ws['pred'].data_ptr(),
                            ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), rk(s.vocab), st)
-        lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr(), st)
-        lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ws['ntok'].data_ptr(), 1.0, ws['loss'].data_ptr() + 8, st)
+        lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ntokp, 1.0, ws['loss'].data_ptr(), st)
+        lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ntokp, 1.0, ws['loss'].data_ptr() + 8, st)
         for j in joins:
             self.join_side(j)
 
@@ -1272,6 +1296,7 @@ class Seq2SeqEngine:
         h = H.AdamHyper()
         h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
         h.ema_decay, h.grad_scale, h.step_offset = self.hyper['ema_decay'], self.grad_scale, step_offset
+        h.skip_if_nonzero = self.sync_err.data_ptr()      # a step whose in-kernel wait timed out must not reach the weights
         for a, b in ranges:
             o = 4 * a
             lib.e2t_adam_ema_step(store.p.data_ptr() + o, store.g.data_ptr() + o, store.m.data_ptr() + o,
@@ -1284,10 +1309,11 @@ class Seq2SeqEngine:
         [0, skip_below) were already updated by adam_ranges(..., step_offset=1)."""
         store = self.store
         st = self.stream
-        lib.e2t_inc_step(self.step_t.data_ptr(), st)
+        lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), st)
         h = H.AdamHyper()
         h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
         h.ema_decay, h.grad_scale = self.hyper['ema_decay'], self.grad_scale
+        h.skip_if_nonzero = self.sync_err.data_ptr()
         for a, b in self.trainable_ranges(sid):
             a = max(a, skip_below)
             if b <= a:
@@ -1327,28 +1353,29 @@ class Seq2SeqEngine:
         sync: optional parallel.GradSync; each backward stage's gradient ranges are all-reduced
         asynchronously right after the stage is enqueued, and Adam waits for all of them."""
         dp = sync is not None and sync.world > 1
+        gc = bool(dp and ws.get('global_counts'))          # losses normalised by the global counts: the exchange is a plain sum
         lazy = use_graph and self.overlap and self._ovl in ('1', 'auxf', 'tail')      # re-pack inside the (first) graph
         if self._packed != 'p' and not lazy:
             self.pack('p')
-        self.grad_scale = sync.grad_scale if dp else 1.0
+        self.grad_scale = (1.0 if gc else sync.grad_scale) if dp else 1.0
 
         def after(i, ranges):
             for a, b in ranges:
                 sync.allreduce_range(a, b)
         if not use_graph:
-            self.forward(ws, train=True)
+            self.forward(ws, train=True, global_counts=gc)
             self.backward(ws, train=True, after_stage=after if dp else None)
             if dp:
                 sync.wait()
             self.adam_step(ws['sid'])
             return
         # the captured Adam launches bake in the trainable ranges and the gradient scale
-        key = ('train_dp' if dp else 'train', tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
+        key = ('train_dp' if dp else 'train', gc, tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
                tuple(sorted(self.hyper.items())))
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture
-            self.forward(ws, train=True, pack_first=lazy)
+            self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
             if dp:
@@ -1363,7 +1390,7 @@ class Seq2SeqEngine:
                     gm = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gm):
                         if i == 0:
-                            self.forward(ws, train=True, pack_first=lazy)
+                            self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
                             ws['have_dy'] = [False] * len(self.enc)
                             self.run_stage(main, side, True)         # the aux head's backward feeds the chain: joined here
                         else:
@@ -1462,7 +1489,7 @@ class Seq2SeqEngine:
                 if er:
                     self.adam_ranges(er, step_offset=1)
             sync.wait()                          # (all done: clears the lists)
-            lib.e2t_inc_step(self.step_t.data_ptr(), self.stream)
+            lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
             self._packed = None
             return
         sync.wait()
@@ -1470,17 +1497,26 @@ class Seq2SeqEngine:
         if lazy:
             self._packed = None          # the images are those of the weights BEFORE this step's update
 
-    def losses(self, ws):
-        v = ws['loss'].cpu().numpy()
-        if int(self.sync_err[0].item()) != 0:
-            # the exchange buffers / stamp words of the persistent recurrences are now inconsistent: reset them so that
-            # the next step starts clean, then fail loudly (E2T_PERSISTENT=0 selects the launch-per-step kernels)
-            self.sync_err.zero_()
-            for lw in list(ws['enc']) + [ws['dec']]:
+    def check_sync(self, ws=None):
+        """Raise if a bounded in-kernel wait of the persistent recurrences gave up since the last check (results since
+        then are invalid; the optimiser kernels skipped their updates on the device: e2t_adam_hyper.skip_if_nonzero).
+        The exchange buffers / stamp words are reset so that the next launch starts clean.  Costs one device->host read:
+        callers use it where they synchronise anyway (losses, assessment, checkpoints, predictions)."""
+        if int(self.sync_err[0].item()) == 0:
+            return
+        info = self.sync_err.cpu().numpy().tolist()
+        self.sync_err.zero_()
+        for w in ([ws] if ws is not None else list(self._ws.values())):
+            for lw in list(w['enc']) + [w['dec']]:
                 for k in ('hx', 'dgx', 'counters'):
                     if k in lw:
                         lw[k].zero_()
-            raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid)')
+        raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid, the '
+                           'weights were not updated; E2T_PERSISTENT=0 selects the launch-per-step kernels) %r' % (info,))
+
+    def losses(self, ws):
+        v = ws['loss'].cpu().numpy()
+        self.check_sync(ws)
         out = dict(decoder=float(v[0]), accuracy=float(v[2]))
         if ws.get('use_aux'):
             out['aux'] = float(v[1])

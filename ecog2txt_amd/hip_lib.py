@@ -40,13 +40,14 @@ class PackDesc(C.Structure):
 
 class AdamHyper(C.Structure):
     _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
-                ('ema_decay', C.c_float), ('grad_scale', C.c_float), ('step_offset', C.c_int)]
+                ('ema_decay', C.c_float), ('grad_scale', C.c_float), ('step_offset', C.c_int), ('skip_if_nonzero', C.c_void_p)]
 
 
 _p, _i, _f, _l, _z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
 # name -> argtypes; the list mirrors include/ecog2txt_hip.h one to one
 SIGNATURES = {
+    'e2t_gather_rows_u32': [_p, _p, _i, _i, _z, _p, _p],
     'e2t_seq_lengths_f32': [_p, _i, _i, _i, _i, _p, _p, _p],
     'e2t_seq_lengths_i32': [_p, _i, _i, _i, _i, _p, _p, _p],
     'e2t_sum_i32': [_p, _i, _p, _p],
@@ -72,11 +73,20 @@ SIGNATURES = {
     'e2t_softmax_ce': [_p, _i, _i, _i, _p, _p, _i, _p, _f, _p, _p, _p, _p, _i, _p],
     'e2t_greedy_update': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     'e2t_mse': [_p, _i, _p, _i, _i, _p, _i, _p, _f, _p, _p, _i, _p],
-    'e2t_inc_step': [_p, _p],
+    'e2t_inc_step': [_p, _p, _p],
     'e2t_adam_ema_step': [_p, _p, _p, _p, _p, _z, _p, C.POINTER(AdamHyper), _p],
+    'e2t_comm_unique_id': [_p],
+    'e2t_comm_init': [C.POINTER(_p), _i, _i, _p, _i],
+    'e2t_comm_destroy': [_p],
+    'e2t_comm_allreduce_f32': [_p, _p, _z, _p, C.POINTER(_i)],
+    'e2t_comm_allreduce_i32': [_p, _p, _z, _p, C.POINTER(_i)],
+    'e2t_comm_broadcast': [_p, _p, _z, _i, _p, C.POINTER(_i)],
+    'e2t_comm_wait': [_p, _i, _p],
 }
+COMM_ID_BYTES = 128
 PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_sizeof': ([_i], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int),
-         'e2t_bwd_persist_kq': ([_i], C.c_int)}
+         'e2t_bwd_persist_kq': ([_i], C.c_int), 'e2t_comm_rank': ([_p], C.c_int), 'e2t_comm_size': ([_p], C.c_int),
+         'e2t_crc32c': ([_p, _z, C.c_uint32], C.c_uint32)}
 
 _lib = None
 

@@ -9,10 +9,12 @@ against a registry of DataGenerator classes instead (falling back to the TF-free
 ECoGDataGenerator shell), so the reference's own manifests load unchanged."""
 import importlib
 import os
+import sys
 
 import yaml
 
 _REGISTRY = {}
+_ALLOW_IMPORT = False
 
 
 def register_data_generator(dotted_name, cls):
@@ -38,11 +40,18 @@ def _resolve(dotted):
     from . import data_generators as dg
     if hasattr(dg, tail):
         return getattr(dg, tail)
-    try:
-        mod, name = dotted.rsplit('.', 1)
-        return getattr(importlib.import_module(mod), name)
-    except Exception:
-        return UnresolvedName(dotted)
+    # like yaml.full_load (the reference, trainers.py:60-61): only names of modules that are ALREADY imported; loading a
+    # manifest never imports -- i.e. executes -- a module (allow_import=True in load_manifest opts in)
+    mod, _, name = dotted.rpartition('.')
+    m = sys.modules.get(mod)
+    if m is None and _ALLOW_IMPORT:
+        try:
+            m = importlib.import_module(mod)
+        except Exception:
+            m = None
+    if m is not None and hasattr(m, name):
+        return getattr(m, name)
+    return UnresolvedName(dotted)
 
 
 class ManifestLoader(yaml.SafeLoader):
@@ -61,10 +70,16 @@ ManifestLoader.add_multi_constructor('tag:yaml.org,2002:python/name:', _name_con
 ManifestLoader.add_constructor('tag:yaml.org,2002:python/tuple', _tuple_constructor)
 
 
-def load_manifest(path_or_name, text_dir=None):
-    """Load an experiment manifest: {subject_id: {key: value}}."""
+def load_manifest(path_or_name, text_dir=None, allow_import=False):
+    """Load an experiment manifest: {subject_id: {key: value}}.  allow_import: let a
+    `!!python/name:` tag import the module it names (off by default: a manifest is data)."""
+    global _ALLOW_IMPORT
     path = path_or_name
     if text_dir is not None and not os.path.isabs(path_or_name):
         path = os.path.join(text_dir, path_or_name)
-    with open(path) as f:
-        return yaml.load(f, Loader=ManifestLoader)
+    prev, _ALLOW_IMPORT = _ALLOW_IMPORT, bool(allow_import)
+    try:
+        with open(path) as f:
+            return yaml.load(f, Loader=ManifestLoader)
+    finally:
+        _ALLOW_IMPORT = prev

@@ -1,28 +1,64 @@
-"""Data parallelism for the hot path: one process per GPU, utterances sharded by
-rank, gradients summed with bucketed all-reduce (RCCL over xGMI on the GPU box:
-torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" in the CPU tests).
+"""Data parallelism for the hot path: one process per GPU, utterances sharded by rank, gradients summed range by
+range (RCCL over xGMI).
 
-The reference trains on one device only (`training_GPUs=[0]`,
-ecog2txt/trainers.py:131); this exchange step is what SURVEY.md 8e adds.
-Buckets are contiguous ranges of the flat gradient buffer in the order backward
-produces them (vocab projection/decoder -> encoder top ... bottom -> conv), so
-each all-reduce is issued as soon as its stage of backward has been enqueued and
-runs on the communicator's stream underneath the remaining BPTT launches.
-xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is
-per-link bound: buckets are kept large (one per backward stage, 7-20 MB at the
-default sizes) rather than many small ones.
+The reference trains on one device only (`training_GPUs=[0]`, ecog2txt/trainers.py:131); this exchange step is what
+SURVEY.md 8e adds.  Buckets are contiguous ranges of the flat gradient buffer in the order backward produces them
+(vocab projection/decoder -> encoder top ... bottom -> conv), so each all-reduce is issued as soon as its stage of
+backward has been enqueued and runs on the communicator's stream underneath the remaining BPTT launches.  xGMI is
+point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound: buckets are kept large (one per
+backward stage, 7-20 MB at the default sizes) rather than many small ones.
+
+Two transports with one interface (`allreduce_range`, `wait`, `pending_ranges`, `world`, `grad_scale`):
+  * `RcclSync`  -- the product path on GPUs: librccl called directly through the C ABI (e2t_comm_*), on a stream the
+    communicator owns, ordered by events; torch.distributed is not involved in the step.  The 128-byte unique id is
+    handed from rank 0 to the others through a torch TCPStore (or an existing process group) -- bootstrap only.
+  * `GradSync`  -- torch.distributed ("gloo" in the CPU tests, where there is no device to run RCCL on).
+
+Sharding (`global_batches` / `rank_slice`): every GLOBAL batch of world x B utterances is cut into `world` slices of
+B, so all ranks run the same number of steps whatever n is; a rank whose slice is short or empty pads with
+zero-length utterances (the kernels ignore them) and still takes part in every collective.  Losses are normalised by
+the GLOBAL token counts of the batch (every rank holds the host copy of the targets and can count), so the SUM of the
+ranks' gradients is exactly the gradient of the global mean loss -- `grad_scale` is then 1.
 """
+import ctypes as C
+import os
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
 
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [lo, hi) slice of n_items utterances for `rank`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_batches(n, B, world, rng=None):
+    """Index arrays of the global batches (world * B utterances each, the last one possibly short) of one pass over
+    n utterances; the permutation comes from `rng`, which every rank seeds alike."""
+    order = np.arange(n) if rng is None else rng.permutation(n)
+    G = B * world
+    return [order[i:i + G] for i in range(0, n, G)]
+
+
+def rank_slice(idx, B, rank):
+    """Rank `rank`'s share of one global batch: utterances [rank*B, (rank+1)*B) of it (possibly fewer, possibly none)."""
+    return idx[rank * B:(rank + 1) * B]
+
+
 class GradSync:
-    def __init__(self, flat_grad, group=None):
+    """torch.distributed transport (gloo on CPU; also works on "nccl")."""
+
+    def __init__(self, flat_grad, group=None, sum_of_global_means=False):
         self.g = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.pending = []
         self.pending_ranges = []           # (work, a, b) in issue order: lets the optimiser follow range by range
+        self.sum_of_global_means = sum_of_global_means
 
     def allreduce_range(self, a, b):
         """Asynchronously sum flat_grad[a:b] over ranks (no-op for one rank)."""
@@ -40,9 +76,138 @@ class GradSync:
 
     @property
     def grad_scale(self):
-        """Every rank's loss is a mean over its own shard; the global mean over equal shards
-        is the rank-average of the per-rank gradients."""
-        return 1.0 / self.world
+        """1 when every rank normalised its loss by the GLOBAL token counts (the sum of the ranks' gradients is the
+        global gradient); 1/world when each rank averaged over its own shard (rank-average of per-rank means: exact
+        only for equal token counts)."""
+        return 1.0 if self.sum_of_global_means else 1.0 / self.world
+
+    # small host-side exchanges (assessment: token ids, counts)
+    def allreduce_numpy(self, arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if self.world > 1:
+            if dist.get_backend(self.group) == 'nccl':
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def broadcast_(self, tensors, src=0):
+        broadcast_flat(tensors, src, self.group)
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
+class _Ticket:
+    def __init__(self, sync, t):
+        self.sync, self.t = sync, t
+
+    def wait(self):
+        """The CURRENT stream waits for this collective (nothing blocks on the host)."""
+        self.sync.lib.e2t_comm_wait(self.sync.comm, self.t, torch.cuda.current_stream().cuda_stream)
+
+
+class RcclSync:
+    """RCCL called directly through the C ABI (include/ecog2txt_hip.h, e2t_comm_*): the exchange step of the
+    data-parallel path without torch.distributed."""
+
+    def __init__(self, flat_grad, rank, world, unique_id, device, sum_of_global_means=True):
+        from .hip_lib import lib
+        self.lib = lib
+        self.g = flat_grad
+        self.rank, self.world = rank, world
+        self.sum_of_global_means = sum_of_global_means
+        comm = C.c_void_p()
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
+        lib.e2t_comm_init(C.byref(comm), rank, world, unique_id, int(device))
+        self.comm = comm
+        self.pending_ranges = []
+        self._i32 = None
+
+    @staticmethod
+    def unique_id():
+        from .hip_lib import lib, COMM_ID_BYTES
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        lib.e2t_comm_unique_id(buf)
+        return buf.raw
+
+    def allreduce_range(self, a, b):
+        if b <= a:
+            return
+        t = C.c_int(-1)
+        self.lib.e2t_comm_allreduce_f32(self.comm, self.g.data_ptr() + 4 * a, b - a, torch.cuda.current_stream().cuda_stream,
+                                        C.byref(t))
+        self.pending_ranges.append((_Ticket(self, t.value), a, b))
+
+    def wait(self):
+        if self.pending_ranges:
+            self.lib.e2t_comm_wait(self.comm, -1, torch.cuda.current_stream().cuda_stream)
+        self.pending_ranges = []
+
+    @property
+    def grad_scale(self):
+        return 1.0 if self.sum_of_global_means else 1.0 / self.world
+
+    def allreduce_numpy(self, arr):
+        """Sum a small host array over ranks (int32 / float32 on the wire; counts and token ids fit)."""
+        a = np.ascontiguousarray(arr)
+        st = torch.cuda.current_stream().cuda_stream
+        if a.dtype.kind in 'iub':
+            t = torch.from_numpy(a.astype(np.int32)).cuda()
+            self.lib.e2t_comm_allreduce_i32(self.comm, t.data_ptr(), t.numel(), st, None)
+        else:
+            t = torch.from_numpy(a.astype(np.float32)).cuda()
+            self.lib.e2t_comm_allreduce_f32(self.comm, t.data_ptr(), t.numel(), st, None)
+        self.lib.e2t_comm_wait(self.comm, -1, st)
+        torch.cuda.current_stream().synchronize()
+        return t.cpu().numpy().astype(a.dtype)
+
+    def broadcast_(self, tensors, src=0):
+        st = torch.cuda.current_stream().cuda_stream
+        for t in tensors:
+            self.lib.e2t_comm_broadcast(self.comm, t.data_ptr(), t.numel() * t.element_size(), src, st, None)
+        self.lib.e2t_comm_wait(self.comm, -1, st)
+
+    def barrier(self):
+        self.allreduce_numpy(np.zeros(1, np.int32))
+
+    def close(self):
+        if self.comm is not None:
+            self.lib.e2t_comm_destroy(self.comm)
+            self.comm = None
+
+
+def bootstrap_unique_id(rank, world, group=None, port_offset=1):
+    """Rank 0 makes the RCCL unique id; everybody gets it -- through an existing torch.distributed group if there is
+    one, else through a TCPStore at MASTER_ADDR:(MASTER_PORT + port_offset)."""
+    uid = RcclSync.unique_id() if rank == 0 else None
+    if world == 1:
+        return uid
+    if dist.is_available() and dist.is_initialized():
+        box = [uid]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ.get('MASTER_PORT', '29500')) + port_offset
+    store = dist.TCPStore(addr, port, world, is_master=(rank == 0), timeout=__import__('datetime').timedelta(seconds=300))
+    if rank == 0:
+        store.set('e2t_rccl_uid', uid)
+    return store.get('e2t_rccl_uid')
+
+
+def make_sync(flat_grad, group=None, sum_of_global_means=True):
+    """The gradient exchange for the current process layout, or None for a single process: RcclSync when the gradients
+    live on a GPU (rank / world from torch.distributed if initialised, else from RANK / WORLD_SIZE), GradSync else."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return None
+    if flat_grad.is_cuda and os.environ.get('E2T_COMM', 'rccl') == 'rccl':
+        uid = bootstrap_unique_id(rank, world, group)
+        return RcclSync(flat_grad, rank, world, uid, flat_grad.device.index or 0, sum_of_global_means)
+    return GradSync(flat_grad, group, sum_of_global_means)
 
 
 def broadcast_flat(tensors, src=0, group=None):
@@ -50,10 +215,3 @@ def broadcast_flat(tensors, src=0, group=None):
         return
     for t in tensors:
         dist.broadcast(t, src=src, group=group)
-
-
-def shard_range(n_items, rank, world):
-    """Contiguous, balanced [lo, hi) slice of n_items utterances for `rank`."""
-    base, rem = divmod(n_items, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)

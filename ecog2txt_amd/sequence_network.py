@@ -122,7 +122,9 @@ class SequenceNetwork:
         key = repr(spec)
         if self._engine is None or self._engine_key != key:
             dev = 'cuda:%d' % (self.training_GPUs[0] if self.training_GPUs else 0)
-            self._engine = Seq2SeqEngine(spec, device=dev, seed=self.seed, lr=self.learning_rate, ema_decay=self.EMA_decay or 0.0)
+            # (dropout masks differ between the ranks of a data-parallel fit; the initial weights do not: fit() broadcasts them)
+            self._engine = Seq2SeqEngine(spec, device=dev, seed=self.seed + 7919 * int(os.environ.get('RANK', '0')),
+                                         lr=self.learning_rate, ema_decay=self.EMA_decay or 0.0)
             self._engine.init_params(self.seed)
             self._engine_key = key
         return self._engine
@@ -154,7 +156,15 @@ class SequenceNetwork:
             if A is not None:
                 a = np.asarray(e[aux_key])[:T]
                 A[i, :a.shape[0]] = a if A.ndim == 3 else a.reshape(-1)
-        return dict(X=X, Y=Y, A=A, n=n, T=T, L=L)
+        # per-utterance loss-normalisation counts (what the kernels count on the device): non-pad target tokens, and
+        # ceil(valid auxiliary-target length / decimation) samples -- data parallel: every rank can sum them over a
+        # GLOBAL batch without any exchange
+        tok = (Y != 0).sum(1).astype(np.int64)
+        val = np.zeros(n, np.int64)
+        if A is not None:
+            tl = (A != 0).sum(1) if A.ndim == 2 else (np.abs(A).max(axis=2) > 0).sum(1)
+            val = -(-tl // N)
+        return dict(X=X, Y=Y, A=A, n=n, T=T, L=L, tok=tok, val=val)
 
     def _batches(self, data, rng=None):
         B = self.N_cases
@@ -162,17 +172,56 @@ class SequenceNetwork:
         for i in range(0, data['n'], B):
             yield order[i:i + B]
 
-    def _load_batch(self, eng, ws, data, idx):
+    def _resident(self, eng, data):
+        """The partition's padded arrays as device tensors, kept in HBM for the whole fit (a MOCHA-TIMIT subject is
+        ~0.5 GB of fp32 ECoG against 288 GB): a step's batch is then assembled by e2t_gather_rows_u32 at HBM speed
+        instead of a 105-MB pageable host->device copy per step.  Partitions beyond E2T_RESIDENT_GB (default 64) stay on
+        the host and go through a pinned staging buffer."""
         import torch
+        if 'dev' not in data:
+            nbytes = sum(a.nbytes for a in (data['X'], data['Y'], data['A']) if a is not None)
+            if nbytes > float(os.environ.get('E2T_RESIDENT_GB', '64')) * 2 ** 30:
+                data['dev'] = None
+            else:
+                data['dev'] = {k: torch.from_numpy(data[k]).to(eng.device) for k in ('X', 'Y', 'A') if data[k] is not None}
+        return data['dev']
+
+    def _load_batch(self, eng, ws, data, idx, idx_dev=None):
+        """Batch rows `idx` (host index array; -1 = padding utterance) into the workspace.  idx_dev: the same indices
+        already on the device (an epoch's plan is uploaded once), so the step issues no host->device copy at all."""
+        import torch
+        from .hip_lib import lib
         B = ws['B']
+        dev = self._resident(eng, data)
+        if dev is not None:
+            if idx_dev is None:
+                full = np.full(B, -1, np.int32)
+                full[:len(idx)] = idx
+                idx_dev = torch.from_numpy(full).to(eng.device)
+            st = eng.stream
+            pairs = [(dev['X'], ws['X']), (dev['Y'], ws['Y'])]
+            if 'A' in dev and eng.aux is not None:
+                pairs.append((dev['A'], ws['auxT']))
+            for src, dst in pairs:
+                lib.e2t_gather_rows_u32(src.data_ptr(), idx_dev.data_ptr(), B, B, src[0].numel(), dst.data_ptr(), st)
+            ws['_keep'] = idx_dev            # alive until the next batch replaces it
+            return
+        keep = np.asarray(idx)[np.asarray(idx) >= 0]
 
         def put(dst, src):
-            dst.zero_()
-            dst[:len(idx)].copy_(torch.from_numpy(np.ascontiguousarray(src[idx])))
+            if '_pin' not in ws:
+                ws['_pin'] = {}
+            pin = ws['_pin'].get(dst.data_ptr())
+            if pin is None:
+                pin = ws['_pin'][dst.data_ptr()] = torch.zeros(dst.shape, dtype=dst.dtype).pin_memory()
+            pin.zero_()
+            np.take(src, keep, axis=0, out=pin.numpy()[:len(keep)])
+            dst.copy_(pin, non_blocking=True)
         put(ws['X'], data['X'])
         put(ws['Y'], data['Y'])
         if data['A'] is not None and eng.aux is not None:
             put(ws['auxT'], data['A'])
+        torch.cuda.current_stream(eng.device).synchronize()      # the pinned buffers are reused by the next batch
 
     # ------------------------------------------------------------------ fit
     def fit(self, subjects, _restore_epoch=None, train_vars_scope=None, reuse_vars_scope=None):
@@ -189,31 +238,23 @@ class SequenceNetwork:
             eng.trainable = {seg for seg, tf in names.items() if re.match(train_vars_scope, tf)}
         else:
             eng.trainable = None
-        sync = None
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            from .parallel import GradSync, broadcast_flat, shard_range
-            sync = GradSync(eng.store.g, self.process_group)
-            broadcast_flat([eng.store.p, eng.store.ema], group=self.process_group)
+        from .parallel import make_sync, global_batches, rank_slice
+        sync = self._get_sync(eng)
+        rank, world = (sync.rank, sync.world) if sync is not None else (0, 1)
+        if sync is not None:
+            sync.broadcast_([eng.store.p, eng.store.ema])
             eng.pack('p')
         staged = {s.subnet_id: {part: self._stage(s, part) for part in ('training', 'validation')} for s in subjects}
-        if sync is not None:       # shard utterances by rank
-            r, w = torch.distributed.get_rank(), torch.distributed.get_world_size()
-            for sid, parts in staged.items():
-                d = parts['training']
-                lo, hi = shard_range(d['n'], r, w)
-                for k in ('X', 'Y', 'A'):
-                    if d[k] is not None:
-                        d[k] = d[k][lo:hi]
-                d['n'] = hi - lo
         last = subjects[-1]
         res = {p: AssessmentTuple(decoder_accuracies=[], decoder_word_error_rates=[], decoder_confusions=None, losses=[])
                for p in ('training', 'validation')}
-        rng = np.random.default_rng(self.seed + start)
+        rng = np.random.default_rng(self.seed + start)           # the same permutations on every rank
         interval = self.assessment_epoch_interval or self.N_epochs
+        B = self.N_cases
         for epoch in range(self.N_epochs):
             if epoch % interval == 0:
                 for part in res:
-                    a = self._assess(eng, last, staged[last.subnet_id][part])
+                    a = self._assess(eng, last, staged[last.subnet_id][part], sync)
                     res[part].decoder_accuracies.append(a.accuracy)
                     res[part].decoder_word_error_rates.append(a.word_error_rate)
                     res[part].decoder_confusions = a.decoder_confusions
@@ -221,20 +262,40 @@ class SequenceNetwork:
                 self.vprint('epoch %4d  train acc %.3f WER %.3f | valid acc %.3f WER %.3f' % (
                     start + epoch, res['training'].decoder_accuracies[-1], res['training'].decoder_word_error_rates[-1],
                     res['validation'].decoder_accuracies[-1], res['validation'].decoder_word_error_rates[-1]))
-            iters = [(s.subnet_id, self._batches(staged[s.subnet_id]['training'], rng)) for s in subjects]
-            live = list(iters)
-            while live:                                   # round-robin over subjects (multi-task 'parallel' learning)
-                for item in list(live):
-                    sid, it = item
-                    idx = next(it, None)
-                    if idx is None:
-                        live.remove(item)
+            # the epoch's plan: per subject, the global batches (world x N_cases utterances), this rank's slice of each as
+            # a row of device-resident indices (-1 = padding utterance) and the global loss-normalisation counts.  Every
+            # rank runs every step -- also one whose slice is short or empty -- so the exchange always matches up.
+            plans = []
+            for s in subjects:
+                d = staged[s.subnet_id]['training']
+                if d is None or d['n'] == 0:
+                    continue
+                gb = global_batches(d['n'], B, world, rng)
+                idx = np.full((len(gb), B), -1, np.int32)
+                cnt = np.zeros((len(gb), 2), np.int64)
+                for k, g in enumerate(gb):
+                    mine = rank_slice(g, B, rank)
+                    idx[k, :len(mine)] = mine
+                    cnt[k] = (d['tok'][g].sum(), d['val'][g].sum())
+                plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt))
+            ws = None
+            for k in range(max((len(p[2]) for p in plans), default=0)):      # round-robin over subjects ('parallel' learning)
+                for sid, d, idx, idx_dev, cnt in plans:
+                    if k >= len(idx):
                         continue
-                    d = staged[sid]['training']
-                    ws = eng.workspace(sid, self.N_cases, d['T'], d['L'])
-                    self._load_batch(eng, ws, d, idx)
+                    ws = eng.workspace(sid, B, d['T'], d['L'])
+                    self._load_batch(eng, ws, d, idx[k], idx_dev[k])
+                    if sync is not None:
+                        eng.set_global_counts(ws, int(cnt[k, 0]), int(cnt[k, 1]))
                     eng.train_step(ws, sync=sync)
-            res['training'].losses.append(eng.losses(ws))
+            if ws is not None:
+                lo = eng.losses(ws)                                  # (also raises if an in-kernel wait timed out this epoch)
+                if sync is not None:
+                    # every rank holds its share of the globally normalised sums: the global losses are their sum
+                    keys = sorted(lo)
+                    lo = dict(zip(keys, sync.allreduce_numpy(np.array([lo[k] for k in keys], np.float32)).tolist()))
+                res['training'].losses.append(lo)
+        eng.check_sync()                                             # never checkpoint the results of an invalid step
         self._epoch = start + self.N_epochs
         self._save(eng, self._epoch)
         for part in res:
@@ -242,38 +303,61 @@ class SequenceNetwork:
             res[part].decoder_word_error_rates = np.array(res[part].decoder_word_error_rates)
         return res
 
+    def _get_sync(self, eng):
+        """The gradient exchange of this process layout (None for one process); made once per engine."""
+        if getattr(self, '_sync_for', None) is not eng:
+            from .parallel import make_sync
+            self._sync = make_sync(eng.store.g, self.process_group)
+            self._sync_for = eng
+        return self._sync
+
     # ------------------------------------------------------------------ assessment (row a11)
-    def _assess(self, eng, subject, data):
+    def _assess(self, eng, subject, data, sync=None):
+        """Token accuracy (teacher forced), greedy hypotheses, WER, confusions on one partition with the EMA weights.
+        Data parallel: the utterances are sharded like the training batches, every rank decodes its slice,
+        the token ids / counts are summed over the ranks and every rank computes the same metrics."""
         import torch
+        from .parallel import global_batches, rank_slice
         out = AssessmentTuple()
         if data is None:
             out.accuracy = out.word_error_rate = float('nan')
             return out
         feats = list(subject.data_manifests['decoder_targets'].get_feature_list())
         V = len(feats)
-        ws = eng.workspace(subject.subnet_id, self.N_cases, data['T'], data['L'])
-        hyps, refs, ncorrect, ntok = [], [], 0.0, 0
+        rank, world = (sync.rank, sync.world) if sync is not None else (0, 1)
+        B, n, L = self.N_cases, data['n'], data['L']
+        ws = eng.workspace(subject.subnet_id, B, data['T'], L)
+        hyp_all = np.zeros((n, L), np.int32)
+        counts = np.zeros(2, np.int64)                       # correct tokens, tokens
         conf = np.zeros((V, V), np.int64) if V < 100 else None
-        for idx in self._batches(data):
+        for g in global_batches(n, B, world):
+            idx = rank_slice(g, B, rank)
+            if len(idx) == 0:
+                continue
             self._load_batch(eng, ws, data, idx)
             if eng._packed != 'ema':
                 eng.pack('ema')
             eng.forward(ws, train=False, which='ema', with_aux=False)
             torch.cuda.synchronize(eng.device)
             nt = int(ws['ntok'].item())
-            ncorrect += float(ws['loss'][2].item()) * max(nt, 1)
-            ntok += nt
+            counts += (int(round(float(ws['loss'][2].item()) * max(nt, 1))), nt)
             if conf is not None:
-                pred = ws['pred'].cpu().numpy().reshape(data['L'], -1)[:, :len(idx)].T
+                pred = ws['pred'].cpu().numpy().reshape(L, -1)[:, :len(idx)].T
                 for b, i in enumerate(idx):
                     y = data['Y'][i]
                     for l in range(int((y != 0).sum())):
                         conf[y[l], pred[b, l]] += 1
-            hyp = eng.greedy_decode(ws, which='ema').cpu().numpy()[:len(idx)]
-            hyps += target_inds_to_sequences(hyp, feats)
-            refs += target_inds_to_sequences(data['Y'][idx], feats)
+            hyp_all[idx] = eng.greedy_decode(ws, which='ema').cpu().numpy()[:len(idx)]
+        eng.check_sync(ws)                                   # a timed-out forward pass must not be reported as a result
         eng.pack('p')
-        out.accuracy = ncorrect / max(ntok, 1)
+        if sync is not None:
+            hyp_all = sync.allreduce_numpy(hyp_all)
+            counts = sync.allreduce_numpy(counts)
+            if conf is not None:
+                conf = sync.allreduce_numpy(conf)
+        hyps = target_inds_to_sequences(hyp_all, feats)
+        refs = target_inds_to_sequences(data['Y'], feats)
+        out.accuracy = float(counts[0]) / max(int(counts[1]), 1)
         out.word_error_rate = float(np.mean(wer_vector(refs, hyps))) if refs else float('nan')
         out.decoder_confusions, out.hypotheses, out.references = conf, hyps, refs
         return out
@@ -282,7 +366,8 @@ class SequenceNetwork:
         eng = self._get_engine(subjects)
         self._restore(eng, restore_epoch, None)
         last = subjects[-1]
-        return {part: self._assess(eng, last, self._stage(last, part)) for part in ('training', 'validation')}
+        sync = self._get_sync(eng)
+        return {part: self._assess(eng, last, self._stage(last, part), sync) for part in ('training', 'validation')}
 
     def restore_and_get_saliencies(self, subjects, restore_epoch, data_partition='validation', assessment_type='norms'):
         """Back-propagate the (penalty-weighted) loss into the inputs (reference trainers.py:703-732).
@@ -371,6 +456,7 @@ class SequenceNetwork:
             ws['X'][:, :x.shape[1]].copy_(torch.from_numpy(np.ascontiguousarray(x)))
             ws['Y'].zero_()
             hyp = eng.greedy_decode(ws, which='ema').cpu().numpy()
+            eng.check_sync(ws)
             return target_inds_to_sequences(hyp, list(targets_list)) if targets_list is not None else hyp
         return predict
 
@@ -398,10 +484,13 @@ class SequenceNetwork:
 
     def _save(self, eng, epoch):
         import torch
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+        sync = getattr(self, '_sync', None)
+        if (sync.rank if sync is not None else int(os.environ.get('RANK', '0'))) != 0:
             return
-        arrays = dict(eng.store.export_tf('p'))
-        arrays.update({k + EMA_SUFFIX: v for k, v in eng.store.export_tf('ema').items()})
+        # float32, as the reference's TF1 Saver stores (and restores into) its variables: a DT_DOUBLE entry would be
+        # rejected by the reference on restore
+        arrays = {k: v.astype(np.float32) for k, v in eng.store.export_tf('p').items()}
+        arrays.update({k + EMA_SUFFIX: v.astype(np.float32) for k, v in eng.store.export_tf('ema').items()})
         arrays['__adam_m'] = eng.store.m.cpu().numpy()
         arrays['__adam_v'] = eng.store.v.cpu().numpy()
         arrays['__step'] = eng.step_t.cpu().numpy()

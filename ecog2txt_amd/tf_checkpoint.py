@@ -78,7 +78,15 @@ def _crc_shift_op(nbytes):
 
 
 def crc32c(data):
-    """CRC-32C (Castagnoli) of a bytes-like object; 4096 lanes in NumPy for large inputs, combined as zlib does."""
+    """CRC-32C (Castagnoli) of a bytes-like object: the shared library's e2t_crc32c (SSE4.2 instruction) when it is
+    built, else crc32c_numpy."""
+    from . import tfrecord
+    return tfrecord.crc32c(data)
+
+
+def crc32c_numpy(data):
+    """CRC-32C in NumPy: 4096 lanes for large inputs, combined as zlib does (kept as the independent second
+    implementation the C one is tested against)."""
     if isinstance(data, np.ndarray):
         buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
     else:
@@ -313,13 +321,14 @@ def read_checkpoint(prefix, check_crc=False, names=None):
     return out
 
 
-def list_variables(prefix):
-    """[(name, shape)] without touching the data files (what recover_model_sizes needs)."""
+def list_variables(prefix, with_dtype=False):
+    """[(name, shape)] without touching the data files (what recover_model_sizes needs); with_dtype: [(name, TF DataType
+    enum (1 = DT_FLOAT, 2 = DT_DOUBLE, 3 = DT_INT32, ...), shape)]."""
     out = []
     for key, value in read_table(prefix + '.index'):
         if key:
             e = _parse_entry(value)
-            out.append((key.decode('utf-8'), tuple(e['shape'])))
+            out.append((key.decode('utf-8'), e['dtype'], tuple(e['shape'])) if with_dtype else (key.decode('utf-8'), tuple(e['shape'])))
     return out
 
 

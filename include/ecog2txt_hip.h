@@ -14,8 +14,9 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
  *    stated otherwise; the caller owns all buffers; `stream` is a hipStream_t.
- *  - all launches are asynchronous on `stream`; no entry point synchronises,
- *    allocates or frees, so every call is hipGraph-capturable.
+ *  - all launches are asynchronous on `stream`; no compute entry point synchronises,
+ *    allocates or frees, so every call is hipGraph-capturable.  (Only e2t_comm_init /
+ *    e2t_comm_destroy create and release resources: a communicator, its stream, its events.)
  *  - return 0 on success, non-zero on failure; e2t_last_error() gives the text.
  *    Nothing throws across the boundary.
  *  - "bf16" buffers are raw uint16 bfloat16 bits.  Every bf16 matrix has a leading
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 1
+#define E2T_ABI_VERSION 2
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -50,6 +51,11 @@ typedef struct e2t_dropout {
     const int32_t* step;        /* device step counter or NULL */
     unsigned stream;            /* tensor id (oracle/seq2seq.py STREAM_*) */
 } e2t_dropout;
+
+/* ---- a2/a3: batch assembly from a partition kept resident in HBM (role of the tf.data pipeline that feeds net.fit,
+ *      trainers.py:896-900): dst row r = src row idx[r] for r < n with idx[r] >= 0, else zeros (a padding utterance:
+ *      zero samples = zero length, subjects.py:386-390).  Rows are row_words 32-bit words; idx is a DEVICE array. ---- */
+int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, void* dst, void* stream);
 
 /* ---- a4: nn.sequences_tools (trainers.py:789-790, 806-807) ---- */
 int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream);
@@ -204,10 +210,36 @@ typedef struct e2t_adam_hyper {
     float lr, beta1, beta2, eps, ema_decay, grad_scale;
     int step_offset;       /* the update uses t = *step + step_offset (1: a range updated before e2t_inc_step has run, while
                               other kernels of the same train step still key their dropout masks on *step) */
+    const int32_t* skip_if_nonzero;   /* device word or NULL: when *skip_if_nonzero != 0 the launch leaves p, m, v, ema untouched
+                              (the err word of the persistent recurrences: a step whose in-kernel wait timed out has
+                              invalid gradients and must not reach the weights) */
 } e2t_adam_hyper;
-int e2t_inc_step(int32_t* step, void* stream);
+/* *step += 1 unless skip_if_nonzero (device word or NULL) is non-zero */
+int e2t_inc_step(int32_t* step, const int32_t* skip_if_nonzero, void* stream);
 int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,
                       const e2t_adam_hyper* h /* host pointer */, void* stream);
+
+/* ---- e1: the exchange step of the utterance-sharded data-parallel path (new: the reference trains on one device,
+ *      trainers.py:131).  RCCL over xGMI, one communicator per process / GPU.  Collectives run on a stream the
+ *      communicator owns, ordered AFTER everything enqueued so far on `after_stream`; *ticket (may be NULL) names the
+ *      collective for e2t_comm_wait.  At most 32 collectives may be outstanding (un-waited) at a time. ---- */
+#define E2T_COMM_ID_BYTES 128
+typedef struct e2t_comm e2t_comm;
+int e2t_comm_unique_id(void* id128 /* host, E2T_COMM_ID_BYTES out: made on one rank, handed to all by the caller */);
+int e2t_comm_init(e2t_comm** out, int rank, int nranks, const void* id128 /* host */, int device);
+int e2t_comm_destroy(e2t_comm* c);
+int e2t_comm_rank(const e2t_comm* c);
+int e2t_comm_size(const e2t_comm* c);
+/* in-place sum over ranks of buf[0..n) (a contiguous range of the flat gradient buffer) */
+int e2t_comm_allreduce_f32(e2t_comm* c, float* buf, size_t n, void* after_stream, int* ticket);
+int e2t_comm_allreduce_i32(e2t_comm* c, int32_t* buf, size_t n, void* after_stream, int* ticket);   /* token ids / counts */
+int e2t_comm_broadcast(e2t_comm* c, void* buf, size_t bytes, int root, void* after_stream, int* ticket);
+/* `stream` waits for collective `ticket` (-1: for every collective issued so far) */
+int e2t_comm_wait(e2t_comm* c, int ticket, void* stream);
+
+/* ---- host helper: CRC-32C (Castagnoli) of a HOST buffer, for the TFRecord / checkpoint framing of rows a3, f1, f2
+ *      (SSE4.2 crc32 instruction); crc = 0 starts a new checksum, or pass a previous result to continue it ---- */
+uint32_t e2t_crc32c(const void* data, size_t n, uint32_t crc);
 
 #ifdef __cplusplus
 }

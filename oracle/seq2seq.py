@@ -305,9 +305,12 @@ def ff_bwd(P, cache, dout, spec, q, grads):
 # --------------------------------------------------------------------------
 # full forward
 # --------------------------------------------------------------------------
-def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False):
+def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False, counts=None):
     """batch: dict(subnet_id, encoder_inputs [B,T,C], decoder_targets [B,L] int,
     optional encoder_targets [B,T,K] float (Gaussian) or [B,T] int (categorical)).
+    counts = (tokens, auxiliary samples): normalise the losses by these instead of the batch's
+    own counts (data parallel: the counts of the GLOBAL batch, so that the sum of the shards'
+    gradients is the gradient of the global mean loss).
     Returns (losses dict, cache)."""
     q = round_bf16 if emulate_bf16 else _identity
     sid = batch['subnet_id']
@@ -375,7 +378,7 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False):
         names = ff_names('encoder_%d_projection' % spec.aux_layer,
                          [2 * spec.enc_rnn[spec.aux_layer]] + list(spec.aux_hidden) + [spec.aux_dim])
         Pout, ffc = ff_fwd(P, names, enc[spec.aux_layer]['Ydrop'], spec, q, train, seed, STREAM_AUX)
-        nval = max(int(avalid.sum()), 1)
+        nval = max(int(avalid.sum()), 1) if counts is None else max(int(counts[1]), 1)
         if cat:
             ids = At[..., 0].astype(np.int64)
             mx = Pout.max(-1, keepdims=True)
@@ -412,7 +415,7 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False):
     pnames = ff_names('decoder_projection', [spec.dec_rnn] + list(spec.dec_proj_hidden) + [spec.vocab])
     logits, pffc = ff_fwd(P, pnames, Hdrop, spec, q, train, seed, STREAM_DEC_OUT + 1)
     tvalid = (np.arange(L)[:, None] < dlens[None, :])
-    ntok = max(int(tvalid.sum()), 1)
+    ntok = max(int(tvalid.sum()), 1) if counts is None else max(int(counts[0]), 1)
     mx = logits.max(-1, keepdims=True)
     lse = mx[..., 0] + np.log(np.exp(logits - mx).sum(-1))
     tgt = Yt.T

@@ -278,7 +278,7 @@ def test_adam_ema_matches_oracle(hl):
     step = torch.zeros(1, dtype=torch.int32, device='cuda')
     h = hl.AdamHyper(1e-2, 0.9, 0.999, 1e-8, 0.99, 1.0)
     for g in (g1, g2):
-        hl.lib.e2t_inc_step(step.data_ptr(), st())
+        hl.lib.e2t_inc_step(step.data_ptr(), None, st())
         hl.lib.e2t_adam_ema_step(p.data_ptr(), t(g).data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n,
                                  step.data_ptr(), C.byref(h), st())
     torch.cuda.synchronize()

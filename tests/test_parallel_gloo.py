@@ -89,3 +89,99 @@ def test_shard_range_covers_everything():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# uneven shards: n % (world * B) != 0 -- every rank runs the same number of steps, the empty / short slices
+# are padding utterances, and with the losses normalised by the GLOBAL counts the plain SUM of the ranks' gradients is
+# the gradient of the global mean loss although the ranks hold different token counts
+# ---------------------------------------------------------------------------------------------------------------------
+def test_global_batches_give_every_rank_the_same_number_of_steps():
+    from ecog2txt_amd.parallel import global_batches, rank_slice
+    for n, world, B in ((257, 2, 128), (9, 2, 2), (1, 8, 4), (256, 8, 32), (300, 3, 7)):
+        rng = np.random.default_rng(5)
+        gb = global_batches(n, B, world, rng)
+        assert len(gb) == -(-n // (B * world))
+        seen = []
+        for g in gb:
+            parts = [rank_slice(g, B, r) for r in range(world)]
+            assert all(len(p) <= B for p in parts)
+            assert sum(len(p) for p in parts) == len(g)
+            seen += [i for p in parts for i in p]
+        assert sorted(seen) == list(range(n))                # disjoint cover
+
+
+def _uneven_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import seq2seq as O
+    from helpers import tiny_spec, make_batch
+    from ecog2txt_amd.engine import ParamStore, NetSpec
+    from ecog2txt_amd.parallel import GradSync, global_batches, rank_slice
+    ospec = tiny_spec()
+    spec = NetSpec(**{k: getattr(ospec, k) for k in NetSpec.__dataclass_fields__})
+    P = O.init_params(ospec, seed=3)
+    n, B = 9, 2                                              # global batches of 4, 4 and 1: rank 1's last slice is empty
+    data = make_batch(ospec, B=n, T=11, L=5, seed=1, ragged=True)       # ragged: unequal token counts per rank
+    store = ParamStore(spec, 'cpu')
+    sync = GradSync(store.g, sum_of_global_means=True)
+    assert sync.grad_scale == 1.0
+    errs = []
+    steps = 0
+    for g in global_batches(n, B, world, np.random.default_rng(0)):
+        mine = rank_slice(g, B, rank)
+        # this rank's batch: its slice, padded to B rows with zero-length utterances (what e2t_gather_rows_u32 makes of idx -1)
+        shard = {}
+        for k, v in data.items():
+            if isinstance(v, np.ndarray):
+                a = np.zeros((B,) + v.shape[1:], v.dtype)
+                a[:len(mine)] = v[mine]
+                shard[k] = a
+            else:
+                shard[k] = v
+        Yg = data['decoder_targets'][g]
+        Ag = data['encoder_targets'][g]
+        counts = (int((Yg != 0).sum()), int((-(-(np.abs(Ag).max(axis=2) > 0).sum(1) // ospec.decimation)).sum()))
+        _, cache = O.forward(P, ospec, shard, counts=counts)
+        G = O.backward(P, cache)
+        store.g.zero_()
+        store.import_tf(G, bufs=('g',))
+        for nm in store.order:                               # every rank issues every collective, also with an empty slice
+            a, b = store.seg_range(nm)
+            sync.allreduce_range(a, b)
+        sync.wait()
+        steps += 1
+        out = store.export_tf('g')
+        whole = {k: (v[g] if isinstance(v, np.ndarray) else v) for k, v in data.items()}
+        _, cache_all = O.forward(P, ospec, whole)
+        Gall = O.backward(P, cache_all)
+        errs.append(max(np.abs(out[k] - Gall[k]).max() / (np.abs(Gall[k]).max() + 1e-12) for k in Gall))
+    # sharded assessment: every rank "decodes" its slice, the sum over ranks is the whole partition on every rank
+    hyp = np.zeros((n, 3), np.int32)
+    for g in global_batches(n, B, world):
+        for i in rank_slice(g, B, rank):
+            hyp[i] = (i, 2 * i, 7)
+    hyp = sync.allreduce_numpy(hyp)
+    ok = bool((hyp == np.stack([np.arange(n), 2 * np.arange(n), np.full(n, 7)], 1)).all())
+    q.put((steps, float(max(errs)), ok))
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_two_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for steps, err, ok in res:
+        assert steps == 3                  # ceil(9 / (2 * 2)) on BOTH ranks
+        assert err < 1e-6                  # sum of globally-normalised shard gradients == gradient of the global batch
+        assert ok

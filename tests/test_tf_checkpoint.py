@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from ecog2txt_amd import tf_checkpoint as T
-from ecog2txt_amd.tfrecord import crc32c as crc_serial
+from ecog2txt_amd.tfrecord import crc32c_python as crc_serial
 
 
 def test_crc32c_known_answers_and_lane_combination():
@@ -17,7 +17,7 @@ def test_crc32c_known_answers_and_lane_combination():
     rng = np.random.default_rng(0)
     for n in (4096 * 64, 4096 * 64 + 13, 700001):                # the multi-lane path and its tail
         b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
-        assert T.crc32c(b) == crc_serial(b)
+        assert T.crc32c(b) == T.crc32c_numpy(b) == crc_serial(b)        # C (SSE4.2), NumPy lanes, table-driven Python
     # TensorFlow / LevelDB masking: rotate right by 15, add the delta
     assert T.mask_crc(0) == 0xA282EAD8 and T.mask_crc(0xE3069283) == ((0xE3069283 >> 15 | 0xE3069283 << 17) + 0xA282EAD8) & 0xFFFFFFFF
 
@@ -108,3 +108,30 @@ def test_model_sizes_are_recovered_from_a_tf_checkpoint(tmp_path):
     assert ls['decoder_embedding'] == [150] and ls['encoder_1_projection'] == [225] and ls['decoder_projection'] == []
     assert ds['401']['encoder_inputs'] == 256 and ds[None]['decoder_targets'] == 1806 and ds[None]['encoder_1_targets'] == 13
     assert strides['401'] == [12] and ema
+
+
+def test_backend_checkpoints_store_float32_variables(tmp_path):
+    """the reference's TF1 Saver restores into float32 variables and rejects a dtype mismatch, so every
+    variable SequenceNetwork._save writes must be DT_FLOAT (1), in the .index as well as in the .npz."""
+    import types
+    import torch
+    from oracle import seq2seq as O
+    from helpers import tiny_spec
+    from ecog2txt_amd.engine import ParamStore, NetSpec
+    from ecog2txt_amd.sequence_network import SequenceNetwork
+    ospec = tiny_spec()
+    spec = NetSpec(**{k: getattr(ospec, k) for k in NetSpec.__dataclass_fields__})
+    store = ParamStore(spec, 'cpu')
+    store.import_tf(O.init_params(ospec, seed=2))
+    eng = types.SimpleNamespace(store=store, step_t=torch.zeros(1, dtype=torch.int32))
+    net = SequenceNetwork.__new__(SequenceNetwork)
+    net.checkpoint_path = str(tmp_path / 'model.ckpt')
+    net._save(eng, 3)
+    prefix = str(tmp_path / 'model.ckpt-3')
+    listed = T.list_variables(prefix, with_dtype=True)
+    assert listed and all(dtype == 1 for _, dtype, _ in listed), [x for x in listed if x[1] != 1][:3]
+    z = np.load(prefix + '.npz')
+    assert all(z[k].dtype == np.float32 for k in z.files if not k.startswith('__'))
+    back = T.read_checkpoint(prefix)
+    k = 'seq2seq/decoder_rnn/cell_0/kernel'
+    assert back[k].dtype == np.float32 and np.array_equal(back[k], store.export_tf('p')[k].astype(np.float32))
