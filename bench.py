@@ -28,6 +28,11 @@ CONFIGS = {
     # name: (spec kwargs, B, T, L)
     'cfg2': (dict(channels={401: 256}, decimation=12, enc_embed=100, enc_rnn=[400, 400, 400], dec_embed=150, dec_rnn=800,
                   vocab=1806, aux_layer=1, aux_hidden=[225], aux_dim=13, ff_dropout=0.1, rnn_dropout=0.5), 256, 400, 10),
+    # cfg3 (BASELINE.json configs[2]): 4 participants with their own conv front-ends (grids 16x16, 16x16, 8x16, 16x16:
+    # mochastar_word_sequence.yaml:57-59, 150-152, 243-245, 336-338), one participant per step in turn
+    'cfg3': (dict(channels={400: 256, 401: 256, 402: 128, 403: 256}, decimation=12, enc_embed=100, enc_rnn=[400, 400, 400],
+                  dec_embed=150, dec_rnn=800, vocab=1806, aux_layer=1, aux_hidden=[225], aux_dim=13, ff_dropout=0.1,
+                  rnn_dropout=0.5), 256, 400, 10),
     'cfg4': (dict(channels={401: 256}, decimation=12, enc_embed=100, enc_rnn=[1024] * 4, dec_embed=150, dec_rnn=2048,
                   vocab=1806, aux_layer=1, aux_hidden=[225], aux_dim=13, ff_dropout=0.1, rnn_dropout=0.5), 256, 400, 10),
     'cfg5': (dict(channels={401: 1024}, decimation=12, enc_embed=100, enc_rnn=[400, 400, 400], dec_embed=150, dec_rnn=800,
@@ -70,108 +75,133 @@ def recurrent_flops_fwd(spec_kw, S, L):
     return f + L * 2 * Hd * 4 * Hd
 
 
-def cpu_baseline(spec_kw, T, L, budget_s=20.0):
-    """Oracle (NumPy fp64 restatement, kind 'port') timed on the host cores on a bounded sample."""
+def cpu_baseline(spec_kw, B, T, L, warmup=3, timed=10):
+    """the CPU number timed beside the GPU run.  The reference's own CPU path (TF1.x + un-vendored
+    packages) cannot run here, so this is `oracle/torch_model.py` -- the independent torch-CPU implementation of the
+    same architecture (torch.nn.LSTM oneDNN/MKL kernels, fp32, autograd, Adam + EMA, dropout on) -- on the SAME batch
+    size and shapes as the GPU step, all host cores: 3 warm-up steps, >= 10 timed, median (kind "port")."""
+    import torch
     from oracle import seq2seq as O
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    ospec = O.NetSpec(**spec_kw)
-    P = O.init_params(ospec, seed=0)
-    Bs = 32
-    batch = synth_batch(spec_kw, Bs, T, L, seed=1)
-    state = {}
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        _, cache = O.forward(P, ospec, batch, train=True, seed=n)
-        G = O.backward(P, cache)
-        P, state = O.adam_ema_step(P, G, state)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 3:
+    from oracle.torch_model import train_step_fn
+    sid = list(spec_kw['channels'])[0]
+    kw1 = dict(spec_kw, channels={sid: spec_kw['channels'][sid]})
+    threads = torch.get_num_threads()
+    step, _ = train_step_fn(O.NetSpec(**kw1), synth_batch(kw1, B, T, L, seed=1))
+    t_all = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 60.0 and len(ts) >= 3:        # bounded: a slow host must not stall the bench
             break
-    return dict(value=round(n * Bs / el, 3), unit='utterances/s', cores=int(threads), kind='port',
-                sample='%d train steps of B=%d utterances (T=%d, same architecture) with the NumPy fp64 oracle, %.1f s'
-                       % (n, Bs, T, el))
+    med = float(np.median(ts))
+    cpu = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), '')
+    except OSError:
+        pass
+    return dict(value=round(B / med, 3), unit='utterances/s', cores=int(threads), kind='port',
+                sample='torch-CPU fp32 model of the same architecture (oracle/torch_model.py: nn.LSTM, conv1d, autograd, Adam+EMA), '
+                       'B=%d T=%d, %d warm-up + %d timed train steps, median %.3f s/step (min %.3f, max %.3f); host: %s, nproc=%d'
+                       % (B, T, warmup, len(ts), med, min(ts), max(ts), cpu, os.cpu_count() or 0))
+
+
+GEMM_KERNELS = {'tn128': 'k_gemm_nt<128,128,2,2,true,true> (K-major operands: weight gradients)',
+                'nt128': 'k_gemm_nt<128,128,2,2,true,false> (K-contiguous, full epilogue)',
+                'nt256': 'k_gemm_nt<256,256,2,4,false,false> (K-contiguous, large plain products)'}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='cfg2', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default: the config\'s 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec, ceil_div
-    from ecog2txt_amd.parallel import GradSync, broadcast_flat
+    from ecog2txt_amd import parallel
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     spec_kw, B, T, L = CONFIGS[args.config]
     B = args.batch or B
     spec = NetSpec(**spec_kw)
     eng = Seq2SeqEngine(spec, device='cuda:%d' % local_rank, seed=1234 + rank)
     eng.init_params(seed=0)
-    broadcast_flat([eng.store.p, eng.store.ema])
+    # data parallel: RCCL through the C ABI (e2t_comm_*); E2T_COMM=torch selects torch.distributed's "nccl" instead
+    sync = None
+    if world > 1:
+        if os.environ.get('E2T_COMM', 'rccl') != 'rccl':
+            import torch.distributed as dist
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        sync = parallel.make_sync(eng.store.g)
+        sync.broadcast_([eng.store.p, eng.store.ema])
     eng.pack('p')
-    sid = list(spec.channels)[0]
-    ws = eng.workspace(sid, B, T, L)
-    eng.set_batch(ws, synth_batch(spec_kw, B, T, L, seed=100 + rank))
-    sync = GradSync(eng.store.g) if world > 1 else None
+    # one workspace per participant (cfg3: four, stepped in turn -- SURVEY.md 8 d2); synthetic batches resident in HBM
+    sids = list(spec.channels)
+    wss = []
+    for i, sid in enumerate(sids):
+        ws = eng.workspace(sid, B, T, L)
+        batch = synth_batch(dict(spec_kw, channels={sid: spec.channels[sid]}), B, T, L, seed=100 + rank + 17 * i)
+        eng.set_batch(ws, batch)
+        if sync is not None:
+            # losses are normalised by the GLOBAL token counts, so the exchange is a plain sum (parallel.py)
+            cnt = sync.allreduce_numpy(np.array(eng.local_counts(batch['decoder_targets'], batch['encoder_targets']), np.int64))
+            eng.set_global_counts(ws, int(cnt[0]), int(cnt[1]))
+        wss.append(ws)
     torch.cuda.synchronize()
+    it = [0]
 
     def step():
-        eng.train_step(ws, use_graph=not args.no_graph, sync=sync)
+        eng.train_step(wss[it[0] % len(wss)], use_graph=not args.no_graph, sync=sync)
+        it[0] += 1
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(wss))):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if sync is not None:
+        sync.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if sync is not None:
+        sync.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    losses = eng.losses(ws)
+    if sync is not None:
+        els = np.zeros(world, np.float32)
+        els[rank] = el
+        el = float(sync.allreduce_numpy(els).max())           # max over ranks
+    ws = wss[0]
+    losses = eng.losses(wss[(it[0] - 1) % len(wss)])
     assert np.isfinite(losses['total']), losses
 
-    # ---- roofline of the dominant kernel (rocprofv3: k_gemm_nt, 49% of the step's kernel time; its largest instance is
-    #      the input projection of an encoder layer, Gx[S*B][8H] = Ydrop[S*B][2H] . Wx^T + b, 256x256 tiles) ----
-    # Measured live: `reps` launches captured in a hipGraph on the bench stream, bracketed by HIP events on THAT
-    # stream.  Algorithmic flops per launch = 2*M*N*K; algorithmic HBM bytes = A + B (bf16) + C (fp32).
-    roof = None
-    extra = {}
-    if rank == 0:
-        import ctypes as C
-        from ecog2txt_amd.hip_lib import lib
+    # ---- per-kernel rooflines, measured live.  The dominant kernel of the step (rocprofv3 summary under profiles/) is the
+    #      MFMA GEMM, in three instances.  Every product of one eager step is logged with the instance the library picks
+    #      for it and its ALGORITHMIC flops (2*M*N*K on the unpadded dimensions, DESIGN.md section 6); each instance's
+    #      launches are then replayed back to back from a hipGraph on the bench stream, bracketed by HIP events on THAT
+    #      stream: achieved = sum of flops / sum of launch durations = flops per launch / average launch duration.
+    #      (In the step the same launches share the chip with the side stream; the in-step averages are in profiles/.)
+    roof, groups, extra = None, {}, {}
+    if rank == 0 and not args.no_roofline:
         S = ceil_div(T, spec.decimation)
-        lay, lw = eng.enc[1], ws['enc'][1]
-        x = ws['enc'][0]['Ydrop'].data_ptr()
 
         def time_graph(fn, reps):
             fn(); torch.cuda.synchronize()
@@ -189,56 +219,73 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / (5 * reps)
 
-        M, N, K = S * B, lay.N4, lay.D                    # K is zero-padded to lay.in_ld (a multiple of the 64-wide K tile)
-        us = time_graph(lambda: eng.gemm(x, lay.in_ld, lay.WxT.data_ptr(), lay.in_ld, lw['Gx'].data_ptr(), lay.N4, M, lay.N4,
-                                         lay.in_ld, bias=lay.bias_ptr(eng.store.p)), 20)
-        flops = 2 * M * N * K
-        ach = flops / (us * 1e-6) / 1e12
-        alg_bytes = 2 * M * K + 2 * N * K + 4 * M * N
-        # HBM-side bytes per launch of THIS instance from the committed PMC run (profiles/r01f_pmc_gemm_gx.json:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/roofline_gemm.py, FETCH_SIZE x2 as
-        # MI355X_MICROARCH.md prescribes); a measured constant of this round, not live
-        traffic = None
+        eng._gemm_log = []
+        eng.forward(ws, train=True)
+        eng.backward(ws, train=True)
+        torch.cuda.synchronize()
+        log, eng._gemm_log = eng._gemm_log, None
+        traffic = {}
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01f_pmc_gemm_gx.json')) as f:
-                t = json.load(f)['k_gemm_nt']
-            if args.config == 'cfg2' and B == 256:
-                traffic = t['hbm_read_bytes'] + t['hbm_write_bytes']
+            with open(os.path.join(ROOT, 'profiles', 'r02_pmc_gemm.json')) as f:
+                traffic = json.load(f)
         except Exception:
             pass
-        roof = dict(bound='mfma', kernel='k_gemm_nt', instance='encoder input projection M=%d N=%d K=%d (bias epilogue, fp32 out)' % (M, N, K),
-                    achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    traffic=traffic, us_per_launch=round(us, 2), flops_per_launch=flops, algorithmic_hbm_bytes_per_launch=alg_bytes)
+        for inst in ('tn128', 'nt128', 'nt256'):
+            recs = [r for r in log if r['inst'] == inst]
+            if not recs:
+                continue
+            us = time_graph(lambda: [eng.gemm_replay(r) for r in recs], 3)       # one pass over all launches of the instance
+            flops = sum(r['flops'] for r in recs)
+            big = max(recs, key=lambda r: r['flops'])
+            tf = flops / (us * 1e-6) / 1e12
+            t = traffic.get(inst) if (args.config == 'cfg2' and B == 256) else None
+            groups[inst] = dict(bound='mfma', kernel=GEMM_KERNELS[inst], launches_per_step=len(recs),
+                                achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                                traffic=(t['hbm_bytes_per_launch'] if t else None),
+                                us_per_launch=round(us / len(recs), 2), flops_per_launch=int(flops / len(recs)),
+                                algorithmic_hbm_bytes_per_launch=int(sum(r['in_bytes'] + r['out_bytes'] for r in recs) / len(recs)),
+                                us_per_step=round(us, 1), includes_splitk_reduce=any(r['splits'] > 1 for r in recs),
+                                largest='M=%d N=%d K=%d x%d (splits %d)' % (big['M'], big['N'], big['K'], big['batch'], big['splits']))
+        if groups:
+            dom = max(groups, key=lambda k: groups[k]['us_per_step'])          # the instance with the largest share of the step
+            roof = dict(groups[dom], instance=dom)
         # the recurrences (second largest share): one persistent launch per layer and direction pair, time per step
-        d = lay.desc(lw, True)
-        if eng.persistent_fwd and lay.persistent_ok(B, eng.num_cus):
-            us_f = time_graph(lambda: lay.fwd(lw, x, ws['lens_d'], eng.store.p, True, steps=(0, S)), 3) / S
-            extra['lstm_fwd_us_per_step'] = round(us_f, 3)
-        if eng.persistent_bwd and lay.persistent_bwd_ok(B, eng.num_cus):
-            us_b = time_graph(lambda: lay.bwd_rec(lw, x, ws['lens_d'], ws['dY'][1].data_ptr(), lay.ldy, True, None, 0,
-                                                  dy_masked=lay.out_drop(True) is not None), 3) / S
-            extra['lstm_bwd_us_per_step'] = round(us_b, 3)
-        extra['lstm_step_flops'] = 2 * B * lay.H * 4 * lay.H * 2      # both directions, one time step of one layer
-        assert int(eng.sync_err[0].item()) == 0
+        lay, lw = eng.enc[1 if len(eng.enc) > 1 else 0], ws['enc'][1 if len(eng.enc) > 1 else 0]
+        li = 1 if len(eng.enc) > 1 else 0
+        x = ws['enc'][li - 1]['Ydrop'].data_ptr() if li > 0 else ws['E'].data_ptr()
+        fwd_persist = eng.persistent_fwd and lay.persistent_ok(B, eng.num_cus)
+        bwd_persist = eng.persistent_bwd and lay.persistent_bwd_ok(B, eng.num_cus)
+        us_f = time_graph(lambda: lay.fwd(lw, x, ws['lens_d'], eng.store.p, True, steps=(0, S)), 3) / S
+        us_b = time_graph(lambda: lay.bwd_rec(lw, x, ws['lens_d'], ws['dY'][li].data_ptr(), lay.ldy, True, None, 0,
+                                              dy_masked=lay.out_drop(True) is not None), 3) / S
+        fl = 2 * B * lay.H * 4 * lay.H * 2           # both directions, one time step of one layer
+        extra = dict(lstm_fwd_us_per_step=round(us_f, 3), lstm_bwd_us_per_step=round(us_b, 3), lstm_step_flops=fl,
+                     lstm_fwd_persistent=bool(fwd_persist), lstm_bwd_persistent=bool(bwd_persist),
+                     lstm_fwd_frac_of_mfma_peak=round(fl / (us_f * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     lstm_bwd_frac_of_mfma_peak=round(fl / (us_b * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
+        eng.check_sync()
 
     if rank == 0:
         utt = B * world * args.steps / el
         S = ceil_div(T, spec.decimation)
         rec = 3 * recurrent_flops_fwd(spec_kw, S, L) * utt / 1e12
+        chans = '/'.join(str(c) for c in spec.channels.values())
         out = dict(metric='train utterances/sec', value=round(utt, 2), unit='utterances/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(1e3 * el / args.steps, 4), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload='%s: 1 subject, %d electrodes x %d samples, B=%d/GPU, conv%d -> %dx biLSTM(%d) -> LSTM(%d) -> %d words, L=%d, Adam+EMA'
-                               % (args.config, spec_kw['channels'][sid], T, B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
+                   config=dict(workload='%s: %d subject(s), %s electrodes x %d samples, B=%d/GPU, conv%d -> %dx biLSTM(%d) -> LSTM(%d) -> %d words, L=%d, Adam+EMA'
+                               % (args.config, len(sids), chans, T, B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
                                   spec.dec_rnn, spec.vocab, L), global_batch=B * world, parallelism='dp%d' % world,
-                               hipgraph=not args.no_graph),
+                               hipgraph=not args.no_graph, exchange=(type(sync).__name__ if sync is not None else None)),
                    recurrent_gemm_tflops=round(rec, 3), recurrent_gemm_frac_of_peak=round(rec / MFMA_BF16_PEAK_TFLOPS / world, 5),
-                   final_loss=round(losses['total'], 4), recurrence=extra, roofline=roof)
+                   final_loss=round(losses['total'], 4), recurrence=extra, roofline=roof,
+                   roofline_all_gemm_instances=groups)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(spec_kw, T, L)
+            out['cpu_baseline'] = cpu_baseline(spec_kw, B, T, L)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if sync is not None and hasattr(sync, 'close'):
+        sync.barrier()
+        sync.close()
 
 
 if __name__ == '__main__':

@@ -412,6 +412,44 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
 }
 
 
+struct GemmPlan { int tile, splits, batch; bool want_split; };
+// Which instance a product runs on, and its split count (shared by the launcher and e2t_gemm_plan).
+static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue* ep) {
+    // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
+    static const int forced = [] { const char* e = getenv("E2T_GEMM_TILE"); return e ? atoi(e) : 0; }();      // (thread-safe init)
+    // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
+    // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
+    // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
+    const int nfull = tn ? (K + BK - 1) / BK : K / BK;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const bool have_ws = ep && ep->splitk_ws && ep->splitk_ws_bytes > 0;
+    const bool want_split = have_ws && ((ep->flags & E2T_GEMM_SPLITK) || (t128 <= 160 && nfull >= 16));
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
+    bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 64;
+    if (forced == 128) big = false;
+    if (forced == 256 && !tn && !want_split && !rich) big = true;
+    GemmPlan pl;
+    pl.tile = big ? 256 : 128;
+    pl.batch = (ep && ep->batch > 1) ? ep->batch : 1;
+    pl.want_split = want_split;
+    pl.splits = 1;
+    if (want_split) {
+        const int ntm = (M + pl.tile - 1) / pl.tile, ntn = (N + pl.tile - 1) / pl.tile;
+        const int tiles = ntm * ntn * pl.batch;
+        int s = 512 / tiles;                           // fill, but never exceed, the 2 x 256 resident workgroups: one block
+                                                       // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
+        if (s > nfull / 16) s = nfull / 16;            // keep >= 16 K tiles per split: a workgroup's fixed cost (DMA fill, slab
+                                                       // store, its share of the reduction) is worth ~8 of them (measured on the
+                                                       // train step: 6 -> 16 tiles per split -1.2 %, 24 and more slower again)
+        const size_t per = (size_t)M * N * sizeof(float) * pl.batch;
+        if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
+        if (s < 1) s = 1;
+        pl.splits = s;
+    }
+    return pl;
+}
+
 static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
     E2T_CHECK_ARG(A && B && C);
@@ -438,37 +476,13 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         E2T_CHECK_ARG(!((p.flags & E2T_GEMM_OUT_BF16) && (p.flags & E2T_GEMM_ACCUMULATE)));
     }
     E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
-    // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
-    static const int forced = [] { const char* e = getenv("E2T_GEMM_TILE"); return e ? atoi(e) : 0; }();      // (thread-safe init)
-    // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
-    // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
-    // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
-    const int nfull = tn ? (K + BK - 1) / BK : K / BK;
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    const bool have_ws = ep && ep->splitk_ws && ep->splitk_ws_bytes > 0;
-    const bool want_split = have_ws && ((ep->flags & E2T_GEMM_SPLITK) || (t128 <= 160 && nfull >= 16));
-    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
-    bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 64;
-    if (forced == 128) big = false;
-    if (forced == 256 && !tn && !want_split && !rich) big = true;
-    const int BM = big ? 256 : 128, BN = BM;
+    const GemmPlan pl = gemm_plan(tn, M, N, K, ep);
+    const bool big = pl.tile == 256;
+    const int BM = pl.tile, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    const int batch = (ep && ep->batch > 1) ? ep->batch : 1;
+    const int batch = pl.batch;
     if (batch > 1) { p.a_bs = ep->a_batch_stride; p.b_bs = ep->b_batch_stride; p.c_bs = ep->c_batch_stride; }
-    if (want_split) {
-        const int tiles = ntm * ntn * batch;
-        int s = 512 / tiles;                           // fill, but never exceed, the 2 x 256 resident workgroups: one block
-                                                       // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
-        if (s > nfull / 16) s = nfull / 16;            // keep >= 16 K tiles per split: a workgroup's fixed cost (DMA fill, slab
-                                                       // store, its share of the reduction) is worth ~8 of them (measured on the
-                                                       // train step: 6 -> 16 tiles per split -1.2 %, 24 and more slower again)
-        const size_t per = (size_t)M * N * sizeof(float) * batch;
-        if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
-        if (s < 1) s = 1;
-        p.splits = s;
-        p.slab = (float*)ep->splitk_ws;
-    }
+    if (pl.splits > 1 || pl.want_split) { p.splits = pl.splits; p.slab = (float*)ep->splitk_ws; }
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
     if (attr_rc != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); return E2T_ERR_HIP; }
@@ -491,4 +505,12 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
 extern "C" int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                                 int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
     return gemm_launch(true, A, lda, B, ldb, C, ldc, M, N, K, ep, stream);
+}
+
+extern "C" int e2t_gemm_plan(int tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int* tile, int* splits) {
+    E2T_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
+    const GemmPlan pl = gemm_plan(tn != 0, M, N, K, ep);
+    if (tile) *tile = pl.tile;
+    if (splits) *splits = pl.splits;
+    return E2T_OK;
 }

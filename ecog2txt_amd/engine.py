@@ -490,7 +490,7 @@ class _Lstm:
     def fwd_gx(self, ws, x_ptr, src):
         """Input projection of all time steps (no recurrence in it: may run ahead on another stream)."""
         self.eng.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, ws['M'], self.N4,
-                      self.in_ld, bias=self.bias_ptr(src))
+                      self.in_ld, bias=self.bias_ptr(src), alg=(ws['M'], self.N4, self.D))
 
     def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None, gx_done=False, after_gx=None):
         e = self.eng
@@ -563,10 +563,10 @@ class _Lstm:
         M = ws['M']
         if d_in_bf16_mask is not None:
             e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
-                   rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask)
+                   rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask, alg=(M, self.D, self.N4))
         else:
             e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                   rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop)
+                   rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop, alg=(M, self.D, self.N4))
 
     def bwd_weights(self, ws, x_ptr):
         """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the
@@ -656,6 +656,7 @@ class Seq2SeqEngine:
             k = s.aux_layer
             self.aux.ones_col_set = self.enc[k].ldy > 2 * self.enc[k].H8
         self._pack_table = None
+        self._gemm_log = None         # a list while bench.py records the step's products (instance, shape, flops)
         mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
         self.persistent = mode != '0'
         self.persistent_fwd, self.persistent_bwd = mode in ('1', 'fwd'), mode in ('1', 'bwd')
@@ -704,8 +705,9 @@ class Seq2SeqEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
-             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False, batch=None):
-        """batch = (n, a_stride, b_stride, c_stride): n products of the same shape in one launch (element strides)."""
+             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False, batch=None, alg=None):
+        """batch = (n, a_stride, b_stride, c_stride): n products of the same shape in one launch (element strides).
+        alg = (M, N, K) of the product WITHOUT layout padding, for flop accounting in the launch log (bench.py)."""
         ep = H.GemmEpilogue()
         if batch is not None:
             ep.batch, ep.a_batch_stride, ep.b_batch_stride, ep.c_batch_stride = batch
@@ -727,7 +729,20 @@ class Seq2SeqEngine:
         if row_lens is not None:
             ep.row_lens, ep.rows_per_step = row_lens
         ep.flags = flags
+        if self._gemm_log is not None:
+            tile, splits = C.c_int(0), C.c_int(0)
+            lib.e2t_gemm_plan(int(tn), M, N, K, C.byref(ep), C.byref(tile), C.byref(splits))
+            am, an, ak = alg or (M, N, K)
+            nb = batch[0] if batch is not None else 1
+            self._gemm_log.append(dict(inst=('tn128' if tn else 'nt%d' % tile.value), M=M, N=N, K=K, batch=nb, splits=splits.value,
+                                       flops=2 * am * an * ak * nb, out_bytes=(2 if out_bf16 else 4) * am * an * nb,
+                                       in_bytes=2 * (am * ak + an * ak) * nb, side=self._on_side,
+                                       call=(A, lda, B, ldb, Cp, ldc, M, N, K), ep=ep, tn=tn))
         (lib.e2t_gemm_tn_bf16 if tn else lib.e2t_gemm_nt_bf16)(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
+
+    def gemm_replay(self, rec):
+        """Re-issue a logged product (same operands, same epilogue) on the current stream."""
+        (lib.e2t_gemm_tn_bf16 if rec['tn'] else lib.e2t_gemm_nt_bf16)(*rec['call'], C.byref(rec['ep']), self.stream)
 
     def _dropout(self, rate, stream):
         d = H.Dropout()
@@ -932,7 +947,8 @@ class Seq2SeqEngine:
         self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
                   M, s.enc_embed, ws['Kc8'],
                   bias=self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed), relu=s.conv_relu, out_bf16=True,
-                  drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B))
+                  drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B),
+                  alg=(M, s.enc_embed, ws['Kc']))
         x = ws['E'].data_ptr()
         for l, (lay, lw) in enumerate(zip(self.enc, ws['enc'])):
             lay.fwd(lw, x, ws['lens_d'], src, train, after_gx=(lambda l=l: after_gx(l)) if after_gx is not None else None)

@@ -59,6 +59,7 @@ SIGNATURES = {
     'e2t_decoder_tokens': [_p, _i, _i, _i, _p, _p, _p],
     'e2t_gemm_nt_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     'e2t_gemm_tn_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    'e2t_gemm_plan': [_i, _i, _i, _i, C.POINTER(GemmEpilogue), C.POINTER(_i), C.POINTER(_i)],
     'e2t_transpose_bf16': [_p, _i, _i, _i, _p, _i, _p],
     'e2t_cast_pack': [_p, _l, _l, _i, _i, _p, _i, _p],
     'e2t_pack_frag': [_p, _l, _l, _i, _i, _p, _p],

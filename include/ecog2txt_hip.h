@@ -111,6 +111,9 @@ int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
  * gathered from the K-major LDS tile with the transposing read ds_read_b64_tr_b16. */
 int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep, void* stream);
+/* which instance e2t_gemm_{nt,tn}_bf16 would run this product on: *tile = 128 or 256 (square tiles), *splits = K splits
+ * (1: none).  For profiling tools that attribute time to kernel instances (bench.py). */
+int e2t_gemm_plan(int tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int* tile, int* splits);
 int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
 
 /* ---- weight packing: fp32 masters -> bf16 operand images (after every optimiser step) ---- */

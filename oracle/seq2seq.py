@@ -504,14 +504,30 @@ def backward(P, cache):
     d2 = dEpre.reshape(S * B, -1)
     G[nm + '/weights'] = (A2.T @ d2).reshape(P[nm + '/weights'].shape)
     G[nm + '/biases'] = d2.sum(0)
-    cache['dA'] = None
+    cache['dEpre'] = dEpre                 # what input_gradient() back-projects
     return G
 
 
-def input_gradient(P, cache, G_unused=None):
-    """a12 saliency support: d loss / d encoder_inputs, batch-major [B,T,C]
-    (trainers.py:703-732).  Recomputes the conv back-projection from cache."""
-    raise NotImplementedError
+def input_gradient(P, cache):
+    """a12 saliency support: d loss / d encoder_inputs, batch-major [B,T,C], after backward()
+    (restore_and_get_saliencies, trainers.py:703-732: the penalty-weighted loss is back-propagated
+    into the `encoder_inputs` placeholder; plotters.py:534-560 then takes norms over it).
+    Chain: dEpre (what backward() left at the conv pre-activation) -> dA = dEpre . K^T through the
+    strided convolution (kernel width == stride, trainers.py:535-541) -> un-im2row -> undo
+    tf.reverse_sequence over each utterance's valid length (trainers.py:808-810).
+    [BUILD-DEFINES] padding samples (t >= len) are not inputs: their gradient is defined as 0."""
+    spec = cache['spec']
+    N = spec.decimation
+    S, B = cache['S'], cache['B']
+    X = np.asarray(cache['batch']['encoder_inputs'])
+    T, C = X.shape[1], X.shape[2]
+    dA = cache['dEpre'] @ cache['Kc'].T                                  # [S,B,N*C], K as the forward pass rounded it
+    dXr = dA.reshape(S, B, N, C).transpose(0, 2, 1, 3).reshape(S * N, B, C)     # reversed-time, time-major
+    dX = np.zeros((B, T, C))
+    for b in range(B):
+        n = int(cache['lens'][b])
+        dX[b, :n] = dXr[:n, b][::-1]
+    return dX
 
 
 # --------------------------------------------------------------------------

@@ -68,7 +68,8 @@ MANIFEST_TEMPLATE = """
 """
 
 
-def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20):
+def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None):
+    """grids: {subject id: (rows, cols)} for participants whose electrode grids differ from `grid`."""
     root = str(root)
     os.makedirs(root, exist_ok=True)
     blocks = {}
@@ -91,5 +92,6 @@ def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4),
     path = os.path.join(root, 'experiment.yaml')
     with open(path, 'w') as f:
         for sid in subject_ids:
-            f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=grid[0], g1=grid[1], rate=rate))
+            g = (grids or {}).get(sid, grid)
+            f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=g[0], g1=g[1], rate=rate))
     return path

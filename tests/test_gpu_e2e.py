@@ -111,6 +111,39 @@ def test_sequential_transfer_and_resume(small):
     assert len(a['training'].decoder_accuracies) == tr.net.N_epochs
 
 
+def test_parallel_fit_three_subjects_with_different_grids(small):
+    """The README's multi-subject call (README.md:72-102 uses [400, 401]): ONE fit over three participants whose grids
+    differ (4x4, 2x4, 4x4 electrodes -> per-subject conv front-ends of different widths), batches drawn round-robin.
+    Every participant's front-end is trained and checkpointed, the shared body learns the (shared) sentences, and a
+    resumed fit continues from the checkpoint with all three."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    path = make_experiment(small, subject_ids=(400, 401, 402), epochs=30, interval=15, grids={401: (2, 4)})
+    ck = str(small / 'ck'); os.makedirs(ck)
+    tr = MultiSubjectTrainer(path, [400, 401, 402], checkpoint_dir=ck, VERBOSE=False,
+                             SN_kwargs={'N_cases': 32, 'learning_rate': 3e-3, 'FF_dropout': 0.0, 'RNN_dropout': 0.1, 'EMA_decay': 0.9},
+                             DG_kwargs={'max_samples': 420})
+    for s in tr.ecog_subjects:
+        s.write_tf_records_maybe()
+    a = tr.parallel_transfer_learn()
+    assert a['training'].losses[-1]['decoder'] < 0.6 * a['training'].losses[0]['decoder']
+    assert a['validation'].decoder_word_error_rates[-1] < a['validation'].decoder_word_error_rates[0]
+    z0 = np.load(os.path.join(ck, 'model.ckpt-30.npz'))
+    names = {400: 'seq2seq/subnet_400/encoder_embedding_16_24_0/weights', 401: 'seq2seq/subnet_401/encoder_embedding_8_24_0/weights',
+             402: 'seq2seq/subnet_402/encoder_embedding_16_24_0/weights'}
+    for sid, nm in names.items():
+        assert nm in z0.files and z0[nm].dtype == np.float32
+        assert z0[nm].shape == (1, 12, 8 if sid == 401 else 16, 24)
+    ls, ds, strides, ema = tr.recover_model_sizes()
+    assert ds['401']['encoder_inputs'] == 8 and ds['400']['encoder_inputs'] == 16 and ds['402']['encoder_inputs'] == 16
+    # all three front-ends moved away from their initialisation (each participant was stepped)
+    eng = tr.net._engine
+    init = type(eng)(eng.spec, device='cuda:0', seed=tr.net.seed)
+    init.init_params(tr.net.seed)
+    P0 = init.store.export_tf('p')
+    for nm in names.values():
+        assert np.abs(z0[nm] - P0[nm]).max() > 1e-3, nm
+
+
 def test_staged_backward_graphs_match_single_graph():
     """The data-parallel step replays one hipGraph per backward stage; with a no-op exchange it must
     reproduce the single-graph step."""
@@ -177,6 +210,65 @@ def test_staged_step_with_a_real_rccl_group():
         assert eng.losses(ws)['total'] == pytest.approx(eng2.losses(ws2)['total'], rel=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_staged_step_with_direct_rccl_through_the_c_abi():
+    """The product's exchange: librccl called directly through e2t_comm_* (no torch.distributed anywhere in the step) on a
+    one-rank communicator -- collectives on the communicator's own stream, ordered by events behind the side stream's
+    graphs, the optimiser following the exchange ticket by ticket.  One real rank reported as two takes the engine down
+    the data-parallel path; the sum over one rank leaves the gradients unchanged, so the result must equal the
+    single-graph step.  Also: global-count loss normalisation equals local normalisation when the counts agree."""
+    from test_gpu_parity import build, SPECS
+    from ecog2txt_amd.parallel import RcclSync
+    eng, ws, _, _, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+    eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+    try:
+        sync = RcclSync(eng2.store.g, 0, 1, RcclSync.unique_id(), 0, sum_of_global_means=True)
+    except RuntimeError as e:
+        pytest.skip('cannot create an RCCL communicator here: %r' % (e,))
+    try:
+        sync.world = 2                                       # (the communicator itself has one rank)
+        ntok, nval = eng2.local_counts(batch['decoder_targets'], batch['encoder_targets'])
+        eng2.set_global_counts(ws2, ntok, nval)
+        for _ in range(4):
+            eng.train_step(ws, use_graph=True)
+            eng2.train_step(ws2, use_graph=True, sync=sync)
+        torch.cuda.synchronize()
+        assert int(eng2.sync_err[0].item()) == 0
+        np.testing.assert_allclose(eng.store.p.cpu().numpy(), eng2.store.p.cpu().numpy(), atol=1e-5)
+        assert eng.losses(ws)['total'] == pytest.approx(eng2.losses(ws2)['total'], rel=1e-5)
+        # the small host-side exchanges of the sharded assessment, and the parameter broadcast
+        a = np.arange(12, dtype=np.int32).reshape(3, 4)
+        assert np.array_equal(sync.allreduce_numpy(a), a)
+        f = np.linspace(0, 1, 7).astype(np.float32)
+        assert np.array_equal(sync.allreduce_numpy(f), f)
+        before = eng2.store.p.clone()
+        sync.broadcast_([eng2.store.p])
+        torch.cuda.synchronize()
+        assert torch.equal(before, eng2.store.p)
+    finally:
+        sync.close()
+
+
+def test_optimiser_skips_the_update_after_an_in_kernel_timeout():
+    """a step whose persistent recurrence raised the error word must not reach the weights -- Adam, EMA and the
+    step counter are no-ops on the device while the word is set -- and losses() / check_sync() raise and clear it."""
+    from test_gpu_parity import build, SPECS
+    eng, ws, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+    eng.train_step(ws, use_graph=True)
+    torch.cuda.synchronize()
+    p1, e1, t1 = eng.store.p.clone(), eng.store.ema.clone(), int(eng.step_t.item())
+    eng.sync_err[0] = 1                                      # as the bounded wait of a persistent kernel would
+    eng.train_step(ws, use_graph=True)
+    eng.train_step(ws, use_graph=False)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.store.p, p1) and torch.equal(eng.store.ema, e1) and int(eng.step_t.item()) == t1
+    with pytest.raises(RuntimeError, match='timed out'):
+        eng.losses(ws)
+    assert int(eng.sync_err[0].item()) == 0
+    eng.train_step(ws, use_graph=True)                       # and training goes on
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.store.p, p1) and int(eng.step_t.item()) == t1 + 1
 
 
 def test_forward_after_a_captured_step_sees_the_updated_weights():

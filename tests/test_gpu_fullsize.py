@@ -115,11 +115,11 @@ def test_greedy_matches_teacher_forcing_on_its_own_output(cfg2):
 
 @pytest.mark.parametrize('name', ['cfg4', 'cfg5'])
 def test_other_baseline_configs_step(name):
-    """cfg4 (H=1024, 4 layers, decoder 2048) and cfg5 (1024 electrodes x 2000 samples) at reduced batch: a few
-    optimisation steps run, stay finite and reduce the loss on a repeated batch."""
+    """cfg4 (H=1024, 4 layers, decoder 2048) and cfg5 (1024 electrodes x 2000 samples) at their own B = 256: a few
+    optimisation steps run, stay finite, raise no in-kernel timeout and reduce the loss on a repeated batch."""
     from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
     kw, B, T, L = bench.CONFIGS[name]
-    B = 64
+    assert B == 256
     eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=2, lr=2e-3)
     eng.init_params(seed=0)
     ws = eng.workspace(401, B, T, L)
@@ -131,6 +131,35 @@ def test_other_baseline_configs_step(name):
             first = eng.losses(ws)
     last = eng.losses(ws)
     assert np.isfinite(last['total']) and last['decoder'] < first['decoder']
+
+
+def test_cfg3_four_subjects_round_robin_at_full_size():
+    """cfg3's per-GPU work (BASELINE.json configs[2]): four participants (256 / 256 / 128 / 256 electrodes), B = 256,
+    one step per participant in turn, each from its own captured graph (the graph key carries the subject's parameter
+    ranges).  Losses fall for every participant; only the stepped participant's front-end moves."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    kw, B, T, L = bench.CONFIGS['cfg3']
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=2, lr=2e-3)
+    eng.init_params(seed=0)
+    sids = list(kw['channels'])
+    wss = {}
+    for i, sid in enumerate(sids):
+        wss[sid] = eng.workspace(sid, B, T, L)
+        eng.set_batch(wss[sid], bench.synth_batch(dict(kw, channels={sid: kw['channels'][sid]}), B, T, L, seed=10 + i))
+    first, last = {}, {}
+    conv0 = {sid: eng.store.view('conv%s.W' % sid).clone() for sid in sids}
+    for rnd in range(5):
+        for sid in sids:
+            before = {o: eng.store.view('conv%s.W' % o).clone() for o in sids if o != sid}
+            eng.train_step(wss[sid])
+            lo = eng.losses(wss[sid])
+            first.setdefault(sid, lo)
+            last[sid] = lo
+            for o, w in before.items():
+                assert torch.equal(eng.store.view('conv%s.W' % o), w), (sid, o)
+    for sid in sids:
+        assert np.isfinite(last[sid]['total']) and last[sid]['decoder'] < first[sid]['decoder'], (sid, first[sid], last[sid])
+        assert not torch.equal(eng.store.view('conv%s.W' % sid), conv0[sid])
 
 
 def test_long_run_at_full_size_has_no_in_kernel_timeouts():

@@ -374,3 +374,23 @@ def test_pack_batch_all_kinds(hl):
     for g in range(4):
         Bn = np.array([[base[off6 + (n * 4 + g) + k * s1] for k in range(Kk)] for n in range(Hh)])
         np.testing.assert_array_equal(got6[g], frag_image(Bn, Hh, Kk), err_msg='kind 6 gate %d' % g)
+
+
+@pytest.mark.parametrize('row_words', [400 * 256, 10, 7, 1030])
+def test_gather_rows_assembles_a_batch_with_padding_rows(hl, row_words):
+    """e2t_gather_rows_u32: dst row r = src row idx[r]; idx < 0 and rows beyond n are zero (padding utterances).
+    Bit-exact (a copy); vector (16-B) and scalar row sizes."""
+    rng = np.random.default_rng(row_words)
+    n_src, n, rows_out = 37, 19, 24
+    src = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(n_src, row_words), dtype=np.int64).astype(np.int32)
+    idx = rng.integers(0, n_src, size=n).astype(np.int32)
+    idx[3] = -1
+    d_src, d_idx = torch.from_numpy(src).cuda(), torch.from_numpy(idx).cuda()
+    dst = torch.full((rows_out, row_words), 123, dtype=torch.int32, device='cuda')
+    hl.lib.e2t_gather_rows_u32(d_src.data_ptr(), d_idx.data_ptr(), n, rows_out, row_words, dst.data_ptr(), st())
+    torch.cuda.synchronize()
+    want = np.zeros((rows_out, row_words), np.int32)
+    for r in range(n):
+        if idx[r] >= 0:
+            want[r] = src[idx[r]]
+    np.testing.assert_array_equal(dst.cpu().numpy(), want)

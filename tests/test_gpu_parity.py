@@ -70,6 +70,9 @@ SPECS = {
     # (cfg2: H = 400 / decoder 800; cfg4: H = 1024 / decoder 2048)
     'cfg2_widths': dict(channels={401: 16}, decimation=4, enc_embed=100, enc_rnn=[400], dec_embed=150, dec_rnn=800,
                         vocab=120, aux_layer=0, aux_hidden=[225], aux_dim=13, ff_dropout=0.1, rnn_dropout=0.5),
+    # cfg5's front-end width (1024 electrodes x decimation 12 -> K = 12288 conv GEMM) on a short sequence
+    'cfg5_frontend': dict(channels={401: 1024}, decimation=12, enc_embed=100, enc_rnn=[16], dec_embed=8, dec_rnn=32,
+                          vocab=20, aux_layer=0, aux_hidden=[12], aux_dim=13, ff_dropout=0.1, rnn_dropout=0.0),
     'cfg4_widths': dict(channels={401: 16}, decimation=4, enc_embed=40, enc_rnn=[1024], dec_embed=30, dec_rnn=2048,
                         vocab=90, aux_layer=None, ff_dropout=0.0, rnn_dropout=0.2),
 }
@@ -79,7 +82,7 @@ SPECS = {
 @pytest.mark.parametrize('ragged', [False, True])
 def test_forward_backward_parity(name, ragged):
     kw = SPECS[name]
-    B, T, L = (40, 100, 8) if name == 'mid' else ((70, 26, 5) if name.endswith('_widths') else (19, 26, 6))
+    B, T, L = (40, 100, 8) if name == 'mid' else ((70, 26, 5) if name.endswith('_widths') else ((24, 100, 5) if name == 'cfg5_frontend' else (19, 26, 6)))
     if name == 'cfg4_widths' and not ragged:
         pytest.skip('one variant of the largest case is enough')
     eng, ws, ospec, P, batch = build(kw, B, T, L, seed=4, ragged=ragged)
@@ -103,6 +106,75 @@ def test_forward_backward_parity(name, ragged):
     Gd = eng.store.export_tf('g')
     for k in sorted(G):
         check_grad(k, Gd[k], G[k])
+
+
+@pytest.mark.parametrize('name', ['small_dropout', 'mid', 'no_aux_linear_conv', 'cfg5_frontend'])
+def test_input_gradient_matches_oracle(name):
+    """Row a12 (restore_and_get_saliencies, trainers.py:703-732): d loss / d encoder_inputs, per sample ('sequences') and
+    as the per-electrode RMS ('norms'), against oracle.input_gradient (itself pinned by torch autograd and finite
+    differences on the CPU).  Dropout off, as the saliency path runs it."""
+    kw = SPECS[name]
+    B, T, L = (40, 100, 8) if name == 'mid' else ((24, 100, 5) if name == 'cfg5_frontend' else (19, 26, 6))
+    eng, ws, ospec, P, batch = build(kw, B, T, L, seed=6, ragged=True)
+    eng.forward(ws, train=False)
+    eng.backward(ws, train=False)
+    got = eng.input_gradient(ws).cpu().numpy()
+    torch.cuda.synchronize()
+    _, cache = O.forward(P, ospec, batch, train=False, emulate_bf16=True)
+    O.backward(P, cache)
+    want = O.input_gradient(P, cache)
+    assert got.shape == want.shape == (B, T, kw['channels'][401])
+    lens = cache['lens']
+    for b in range(B):
+        assert not got[b, lens[b]:].any()                     # padding samples: zero by definition
+    check_grad('d loss / d encoder_inputs', got, want)
+    norms_got, norms_want = np.sqrt((got ** 2).mean(axis=(0, 1))), np.sqrt((want ** 2).mean(axis=(0, 1)))
+    np.testing.assert_allclose(norms_got, norms_want, rtol=2e-2, atol=1e-3 * norms_want.max())
+
+
+def test_multi_subject_round_robin_follows_oracle():
+    """cfg3's single-GPU half at small sizes: three participants with different electrode counts (16 / 8 / 16, as the
+    reference's 16x16 / 8x16 / 16x16 grids differ), one shared body, per-subject conv front-ends (`subnet_{id}`,
+    trainers.py:801-818); steps go round-robin over the subjects.  After two rounds with dropout the
+    shared parameters AND each participant's own front-end follow the oracle's trajectory; a front-end only moves on
+    its participant's steps."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    kw = dict(SPECS['small_dropout'], channels={400: 16, 401: 8, 402: 16})
+    spec = NetSpec(**kw)
+    ospec = O.NetSpec(**spec.as_dict())
+    P = O.init_params(ospec, seed=8)
+    eng = Seq2SeqEngine(spec, device='cuda:0', seed=11)
+    eng.load_params(P)
+    B, T, L = 19, 26, 6
+    batches = {sid: make_batch(ospec, B=B, T=T, L=L, seed=20 + i, ragged=True, sid=sid) for i, sid in enumerate(kw['channels'])}
+    wss = {}
+    for sid in kw['channels']:
+        wss[sid] = eng.workspace(sid, B, T, L)
+        eng.set_batch(wss[sid], batches[sid])
+    Po = {k: v.copy() for k, v in P.items()}
+    state = {}
+    step = 0
+    snap = {}
+    for rnd in range(2):
+        for sid in kw['channels']:
+            eng.train_step(wss[sid], use_graph=(rnd == 1))         # eager round, then captured graphs (one per subject)
+            _, cache = O.forward(Po, ospec, batches[sid], train=True, seed=11 + step, emulate_bf16=True)
+            G = O.backward(Po, cache)
+            Po, state = O.adam_ema_step(Po, G, state, lr=5e-4)
+            step += 1
+            if rnd == 0 and sid == 400:
+                torch.cuda.synchronize()
+                snap = eng.store.export_tf('p')
+    torch.cuda.synchronize()
+    assert int(eng.sync_err[0].item()) == 0
+    Pd, Ed = eng.store.export_tf('p'), eng.store.export_tf('ema')
+    for k in Po:
+        assert np.abs(Pd[k] - Po[k]).max() < 6 * 5e-4 * 0.35, k          # six Adam steps of ~lr each
+        assert np.abs(Ed[k] - state['ema'][k]).max() < 2e-4, k
+    # after subject 400's first step only ITS front-end (and the shared body) had moved
+    c401 = O.conv_name(ospec, 401) + '/weights'
+    c400 = O.conv_name(ospec, 400) + '/weights'
+    assert np.array_equal(snap[c401], P[c401].astype(np.float32)) and not np.array_equal(snap[c400], P[c400].astype(np.float32))
 
 
 def test_train_steps_follow_oracle():
