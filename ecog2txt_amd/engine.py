@@ -16,7 +16,9 @@ MultiSubjectTrainer.recover_model_sizes (trainers.py:444-554).
 """
 from dataclasses import dataclass, field, asdict
 from typing import Dict, List, Optional
+import contextlib
 import ctypes as C
+import gc
 import os
 
 import numpy as np
@@ -28,6 +30,23 @@ from .hip_lib import lib
 PAD_ID, EOS_ID, OOV_ID = 0, 1, 2          # trainers.py:191-196
 
 STREAM_CONV, STREAM_ENC, STREAM_DEC_EMB, STREAM_DEC_OUT, STREAM_AUX = 1, 10, 20, 21, 30
+
+
+@contextlib.contextmanager
+def capture(graph):
+    """torch.cuda.graph(graph) with the cyclic garbage collector out of the way: a collection that runs DURING a stream
+    capture may destroy device objects of unrelated, dead Python objects (another engine's CUDAGraphs, events) -- HIP
+    refuses that while capturing and the destructor aborts the process.  (Seen: an exception's traceback kept a dead
+    engine alive in a reference cycle until the next capture.)"""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def rk(x):
@@ -1404,7 +1423,7 @@ class Seq2SeqEngine:
                 graphs = []
                 for i, (main, side, ranges) in enumerate(stages):
                     gm = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gm):
+                    with capture(gm):
                         if i == 0:
                             self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
                             ws['have_dy'] = [False] * len(self.enc)
@@ -1416,13 +1435,13 @@ class Seq2SeqEngine:
                         gs = torch.cuda.CUDAGraph()
                         self._on_side = True
                         try:
-                            with torch.cuda.graph(gs):
+                            with capture(gs):
                                 side(True)
                         finally:
                             self._on_side = False
                     graphs.append((gm, gs, ranges))
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with capture(ga):
                     self.adam_step(ws['sid'], repack=not lazy)
                 g = (graphs, ga)
             else:
@@ -1445,7 +1464,7 @@ class Seq2SeqEngine:
                     if not early:
                         early, early_end = None, 0
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with capture(g1):
                     self.forward(ws, train=True, pack_first=True)
                     self.backward(ws, train=True, early=early)
                     self.adam_step(ws['sid'], repack=False, skip_below=early_end)

@@ -187,5 +187,5 @@ def train_step_fn(spec, batch, lr=5e-4, ema_decay=0.99, dtype=torch.float32, see
         with torch.no_grad():
             for k, v in Pt.items():
                 ema[k].mul_(ema_decay).add_(v, alpha=1.0 - ema_decay)
-        return float(out['total'])
+        return float(out["total"].detach())
     return step, Pt
