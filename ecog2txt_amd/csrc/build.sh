@@ -7,12 +7,12 @@ inc="$here/../../include"
 out="$here/../libecog2txt_hip.so"
 obj="$here/build"
 mkdir -p "$obj"
-srcs=(runtime gemm lstm elementwise comm)
+srcs=(runtime gemm lstm lstm_big elementwise comm)
 pids=()
 for s in "${srcs[@]}"; do
     o="$obj/$s.o"
     if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$inc/ecog2txt_hip.h" -nt "$o" ]; then
-        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$inc" -I"$here" -c "$here/$s.hip" -o "$o" "$@" &
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$inc" -I"$here" -c "$here/$s.hip" -o "$o" -Rpass-analysis=kernel-resource-usage "$@" > "$obj/$s.log" 2>&1 || { cat "$obj/$s.log" | grep -v "remark:" | head -40; exit 1; } &
         pids+=($!)
     fi
 done

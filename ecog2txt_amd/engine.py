@@ -421,6 +421,10 @@ class _Lstm:
         self.WxB = _bf(in_ld, rk(self.N4), device=dev)
         self.WhF = _bf(ndir, 4, self.UT, self.KB, 64, 8, device=dev)
         self.WhB = _bf(ndir, self.UT, self.KB4, 64, 8, device=dev)
+        # large hidden sizes (cfg4: H = 1024): the waves of a workgroup hold different weights and share the state through
+        # LDS (csrc/lstm_big.hip); operand = fragment image over ALL gate columns of the gate-interleaved master
+        self.big = bool(H.load().e2t_lstm_big_ok(Hh)) and self.KB > 26
+        self.WhG = _bf(ndir, 4 * Hh // 16, Hh // 32, 64, 8, device=dev) if self.big else None
 
     def pack_ops(self, ops, src):
         st = self.eng.store
@@ -436,6 +440,8 @@ class _Lstm:
                 for g in range(4):
                     ops.append(('frag', st.ptr(self.name + '.Wh', src, base + g), 4, 4 * Hh, Hh, Hh, self.WhF[d, g]))
             ops.append(('frag', st.ptr(self.name + '.Wh', src, base), 4 * Hh, 1, Hh, 4 * Hh, self.WhB[d]))
+            if self.big:
+                ops.append(('frag', st.ptr(self.name + '.Wh', src, base), 1, 4 * Hh, 4 * Hh, Hh, self.WhG[d]))
 
     def bias_ptr(self, src):
         return self.eng.store.ptr(self.name + '.Wx', src, self.D * self.N4)
@@ -445,6 +451,8 @@ class _Lstm:
         in e2t_lstm_seq_fwd_persistent): 64-utterance x 16-unit workgroups up to H = 416, 32 x 32 up to H = 832."""
         if self.H % 8 != 0:
             return False
+        if self.big:
+            return ceil_div(B, 64) * self.ndir * (self.H // 32) <= num_cus
         if self.KB <= 13:
             return ceil_div(B, 64) * self.ndir * self.UT <= num_cus
         return self.KB <= 26 and ceil_div(B, 32) * self.ndir * ceil_div(self.UT, 2) <= num_cus
@@ -452,6 +460,8 @@ class _Lstm:
     def persistent_bwd_ok(self, B, num_cus):
         """Mirrors the checks in e2t_lstm_seq_bwd_persistent: 16-utterance x 64-unit workgroups up to H = 416,
         32 x 32 up to H = 800, one per CU."""
+        if self.big:
+            return self.H % 128 == 0 and ceil_div(B, 64) * self.ndir * (self.H // 32) <= num_cus
         kq = H.load().e2t_bwd_persist_kq(self.H)
         if kq == 0 or self.H % 8 != 0:
             return False
@@ -485,6 +495,10 @@ class _Lstm:
             ws['counters'] = torch.zeros(nflag + 1, dtype=torch.int32, device=dev)
             ws['dgx'] = _bf(2, nd, RT if kq <= 13 else 2 * ceil_div(RT, 2), 4 * kq, 64, 8, device=dev)
         ws['hx'] = _bf(2 * nd * 4 * ceil_div(B, 64) * self.KB * 64 * 8 + 512, device=dev)     # in-launch h exchange (persistent recurrence)
+        if self.big:
+            ws['flagsb'] = torch.zeros(ceil_div(B, 64) * nd * 128, dtype=torch.int32, device=dev)
+            ws['flagsbb'] = torch.zeros(ceil_div(B, 64) * nd * 128, dtype=torch.int32, device=dev)
+            ws['dgxb'] = _bf(2 * nd * 4 * ceil_div(B, 64) * (Hh // 8) * 512, device=dev)       # in-launch dG exchange (big BPTT)
         return ws
 
     def desc(self, ws, train):
@@ -523,6 +537,12 @@ class _Lstm:
         if e.persistent_fwd and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
             # whole sequence in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_fwd_persist)
             d = self.desc(ws, train)
+            if self.big:        # csrc/lstm_big.hip: k_lstm_seq_fwd_big
+                lib.e2t_lstm_seq_fwd_big(C.byref(d), ws['Gx'].data_ptr(), self.WhG.data_ptr(), ws['Yext'].data_ptr(),
+                                         ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
+                                         c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(),
+                                         ws['flagsb'].data_ptr(), e.sync_err.data_ptr(), e.num_cus, e.stream)
+                return
             lib.e2t_lstm_seq_fwd_persistent(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
                                             ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
                                             c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(),
@@ -560,7 +580,14 @@ class _Lstm:
             lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
                                  ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
                                  ws['dc_carry'].data_ptr(), p(dh0), p(dc0), stream)
-        if e.persistent_bwd and self.persistent_bwd_ok(B, e.num_cus):
+        if e.persistent_bwd and self.big and dh0 is None and self.persistent_bwd_ok(B, e.num_cus):
+            d = self.desc(ws, train)            # csrc/lstm_big.hip: k_lstm_seq_bwd_big
+            if dy_masked:
+                d.drop_rate = 0.0
+            lib.e2t_lstm_seq_bwd_big(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
+                                     ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
+                                     ws['dgxb'].data_ptr(), ws['flagsbb'].data_ptr(), e.sync_err.data_ptr(), e.num_cus, e.stream)
+        elif e.persistent_bwd and not self.big and self.persistent_bwd_ok(B, e.num_cus):
             # whole BPTT sweep in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_bwd_persist)
             d = self.desc(ws, train)
             if dy_masked:
@@ -1543,7 +1570,7 @@ class Seq2SeqEngine:
         self.sync_err.zero_()
         for w in ([ws] if ws is not None else list(self._ws.values())):
             for lw in list(w['enc']) + [w['dec']]:
-                for k in ('hx', 'dgx', 'counters'):
+                for k in ('hx', 'dgx', 'counters', 'flagsb', 'flagsbb', 'dgxb'):
                     if k in lw:
                         lw[k].zero_()
         raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid, the '

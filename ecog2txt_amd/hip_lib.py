@@ -68,6 +68,8 @@ SIGNATURES = {
     'e2t_lstm_seq_fwd_persistent': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_lstm_seq_bwd': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'e2t_lstm_seq_bwd_persistent': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    'e2t_lstm_seq_fwd_big': [C.POINTER(LstmDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    'e2t_lstm_seq_bwd_big': [C.POINTER(LstmDesc), _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'e2t_final_state': [_p, _i, _p, _p, _i, _i, _p, _i, _p, _p],
     'e2t_embed_fwd': [_p, _i, _p, _i, _i, _i, _p, _i, C.POINTER(Dropout), _p],
     'e2t_embed_bwd': [_p, _i, _p, _i, _i, _p, _i, C.POINTER(Dropout), _p],
@@ -86,7 +88,7 @@ SIGNATURES = {
 }
 COMM_ID_BYTES = 128
 PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_sizeof': ([_i], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int),
-         'e2t_bwd_persist_kq': ([_i], C.c_int), 'e2t_comm_rank': ([_p], C.c_int), 'e2t_comm_size': ([_p], C.c_int),
+         'e2t_bwd_persist_kq': ([_i], C.c_int), 'e2t_lstm_big_ok': ([_i], C.c_int), 'e2t_comm_rank': ([_p], C.c_int), 'e2t_comm_size': ([_p], C.c_int),
          'e2t_crc32c': ([_p, _z, C.c_uint32], C.c_uint32)}
 
 _lib = None

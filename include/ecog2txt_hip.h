@@ -190,6 +190,22 @@ int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* d
                                 const float* Gs, const float* Cs, const int32_t* lens, const float* c0,
                                 const float* dh_final, const float* dc_final, float* dh0, float* dc0, void* dgx,
                                 uint32_t* flags, int32_t* err, int num_cus, void* stream);
+/* Large hidden sizes (config 4: H = 1024): weight-stationary persistent recurrences in which the four waves of a workgroup
+ * hold DIFFERENT weights and share the state through LDS (csrc/lstm_big.hip).  e2t_lstm_big_ok(H): 1 if H is supported
+ * (H % 64 == 0, 448 <= H <= 1024).  Forward: same result, bit for bit, as e2t_lstm_seq_fwd over steps [0,S); needs
+ * ceil(B/64) * ndir * (H/32) workgroups co-resident (<= num_cus), else returns non-zero.
+ * WhG: e2t_pack_frag image of Bn[n][k] = W_h[k][n] over ALL gate columns n < 4H (gate-interleaved master), per direction:
+ * [ndir][4H/16][H/32][64][8].  hx: bf16 [2][ndir][4*ceil(B/64)][H/32][64][8]; flags: uint32 [ceil(B/64)*ndir][128]; both
+ * zero-filled once by the caller and afterwards only touched by these entry points (zero them again after an error). */
+int e2t_lstm_big_ok(int H);
+int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const float* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs, float* Gs,
+                         const int32_t* lens, const float* c0, void* hx, uint32_t* flags, int32_t* err, int num_cus, void* stream);
+/* BPTT counterpart (same gradients as e2t_lstm_seq_bwd to fp32 round-off: the K = 4H sum is split in 4 quarters); H in
+ * {512, 768, 1024}; no gradient into an initial state (dh0/dc0: use the other entry points).
+ * dgx: bf16 [2][ndir][4*ceil(B/64)][4H/32][64][8]; flags as for the forward, a separate array. */
+int e2t_lstm_seq_bwd_big(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy, const float* Gs,
+                         const float* Cs, const int32_t* lens, const float* c0, const float* dh_final, const float* dc_final,
+                         void* dgx, uint32_t* flags, int32_t* err, int num_cus, void* stream);
 /* encoder final state -> decoder initial state (App. D2) */
 int e2t_final_state(const void* Yext, int ldy, const float* Cs, const int32_t* lens, int B, int H, void* h0, int ldh0,
                     float* c0, void* stream);

@@ -227,7 +227,10 @@ def test_greedy_sequences_identical(name):
 
 @pytest.mark.parametrize('name,B,T,L', [('small_dropout', 70, 50, 6), ('cfg2_widths', 130, 40, 5), ('mid', 256, 100, 8),
                                         # 32-row blocks whose second row tile lies wholly beyond B (stamp state per cluster)
-                                        ('cfg2_widths', 200, 36, 9), ('cfg2_widths', 40, 24, 9)])
+                                        ('cfg2_widths', 200, 36, 9), ('cfg2_widths', 40, 24, 9),
+                                        # H = 1024: the kernels of csrc/lstm_big.hip (waves hold different weights, state shared through
+                                        # LDS, flag hand-off); the decoder (H = 2048) stays on the launch-per-step kernels
+                                        ('cfg4_widths', 70, 26, 5), ('cfg4_widths', 256, 40, 4), ('cfg4_widths', 130, 80, 4)])
 def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypatch):
     """The one-launch weight-stationary recurrences (in-launch exchange between CUs) against the launch-per-step
     kernels.  Forward: bit for bit (outputs, dropped outputs, saved cell states, losses).  Backward: the K = 4H sum
@@ -240,6 +243,8 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
             assert all(lay.persistent_ok(B, eng.num_cus) for lay in eng.enc), 'case must exercise the persistent path'
             if name == 'cfg2_widths':
                 assert eng.dec.persistent_ok(B, eng.num_cus), 'the decoder (H=800) must take the wide persistent kernel'
+            if name == 'cfg4_widths':
+                assert all(lay.big for lay in eng.enc), 'H = 1024 must take the kernels of lstm_big.hip'
         if flag == '1':
             assert all(lay.persistent_bwd_ok(B, eng.num_cus) for lay in eng.enc)
             if name == 'cfg2_widths':
