@@ -67,6 +67,43 @@ __global__ __launch_bounds__(1024) void k_seq_lengths_f32(const float* x, int T,
     }
 }
 
+// Same result for END-padded data (the only padding the reference produces: subjects.py:386-390) without reading the
+// whole batch: the last non-zero row is searched from the tail, 32 rows per pass (16 waves x 2 rows, 16-B loads), so an
+// utterance costs (padding + <= 32 rows) instead of T rows -- 105 MB -> ~9 MB at cfg2, 2.1 GB -> ~35 MB at cfg5.
+// length = index of the last non-zero row + 1; interior all-zero rows (not padding) would make this differ from the
+// non-zero-row COUNT of k_seq_lengths_f32: the host rejects such utterances when it stages them.
+__global__ __launch_bounds__(1024) void k_seq_lengths_tail_f32(const float* x, int T, int C, int div, int* lens, int* lens_div) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (size_t)b * T * C;
+    __shared__ int best;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    for (int hi = T; hi > 0; hi -= 32) {
+        int found = 0;                                   // (1 + row index) of a non-zero row of this pass, wave-uniform
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = hi - 1 - (wave * 2 + i);
+            bool nz = false;
+            if (t >= 0)
+                for (int c = lane * 4; c < C; c += 256) {
+                    const float4 v = *(const float4*)(xb + (size_t)t * C + c);
+                    nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+                }
+            if (__any(nz)) found = max(found, t + 1);
+        }
+        if (lane == 0 && found) atomicMax(&best, found);
+        __syncthreads();
+        const int n = best;
+        if (n > 0) break;                                // uniform: every thread reads the same word after the barrier
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int n = best;
+        lens[b] = n;
+        if (lens_div) lens_div[b] = (n + div - 1) / div;
+    }
+}
+
 __global__ void k_seq_lengths_i32(const int* x, int B, int L, int pad, int div, int* lens, int* lens_div) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -659,6 +696,14 @@ extern "C" int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, i
 extern "C" int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream) {
     E2T_CHECK_ARG(x && lens && B > 0 && T > 0 && C > 0 && div > 0);
     hipLaunchKernelGGL(k_seq_lengths_f32, dim3(B), dim3(1024), 0, ST, x, T, C, div, lens, lens_div);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_seq_lengths_tail_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream) {
+    E2T_CHECK_ARG(x && lens && B > 0 && T > 0 && C > 0 && div > 0);
+    if ((C & 3) == 0 && C >= 32 && (((uintptr_t)x) & 15) == 0)
+        hipLaunchKernelGGL(k_seq_lengths_tail_f32, dim3(B), dim3(1024), 0, ST, x, T, C, div, lens, lens_div);
+    else
+        hipLaunchKernelGGL(k_seq_lengths_f32, dim3(B), dim3(1024), 0, ST, x, T, C, div, lens, lens_div);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int div, int32_t* lens, int32_t* lens_div, void* stream) {

@@ -4,8 +4,8 @@
 (reference ecog2txt/data_generators.py:45-245: electrode layout, good channels, bipolar map,
 max_samples, MFCC width, vocab lookup, record path) and the record writer; the three
 user-supplied hooks (`_ecog_token_generator`, `_get_wav_data`, `_query`, reference :502-530)
-stay abstract.  MFCC extraction / word-piece encoding are offline preprocessing outside the
-hot path and are not restated."""
+stay abstract.  MFCC / log-mel extraction and word-piece encoding are restated in
+speech_features.py and reached through `_get_MFCC_features` / `_sentence_tokenize` / `TokenEncoder`."""
 import os
 
 import zlib
@@ -140,14 +140,38 @@ class ECoGDataGenerator:
 
     def get_class_list(self, sequence_type=None, block_set=None):
         if sequence_type is not None:
-            with open(self.sequence_type_to_vocab_file_path(sequence_type)) as f:
+            path = self.sequence_type_to_vocab_file_path(sequence_type)
+            if self.token_type == 'word_piece_sequence':          # data_generators.py:431-433
+                return self.TokenEncoder(path)._all_subtoken_strings
+            with open(path) as f:
                 return f.read().split()
         if block_set is not None:
             return self.write_to_Protobuf_maybe(sequence_type, block_set)
         raise ValueError('get_class_list needs a sequence_type or a block_set')
 
+    def TokenEncoder(self, vocab_file_path):
+        """tensor2tensor's SubwordTextEncoder, restated (data_generators.py:475-485)."""
+        from .speech_features import SubwordTextEncoder
+        return SubwordTextEncoder(vocab_file_path)
+
+    def _get_MFCC_features(self, index, winstep, nfft=512):
+        """MFCCs (or log-mels + log energy, optionally with deltas) of trial `index`'s audio at frame step `winstep`
+        seconds: data_generators.py:328-380, parameters as fixed there; `_get_wav_data` is the subclass hook."""
+        from .speech_features import mfcc_features
+        audio_sampling_rate, audio_signal = self._get_wav_data(index)
+        if audio_signal is None:
+            return np.zeros((0, self.num_MFCC_features))
+        if self.num_MFCC_features == 0:
+            return np.zeros((int(audio_signal.shape[0] / audio_sampling_rate / winstep), 0))
+        return mfcc_features(audio_signal, audio_sampling_rate, self.mfcc_winlen, winstep, self.num_mel_features,
+                             self.num_cepstral_coeffs, bool(self.USE_LOG_MELS), bool(self.USE_MFCC_DELTAS), nfft)
+
     def _sentence_tokenize(self, token_list, sequence_type=None):
-        """lower-cased word + '_' as UTF-8 bytes (data_generators.py:462-473)."""
+        """lower-cased word + '_' as UTF-8 bytes; word pieces through the subword encoder (data_generators.py:446-473)."""
+        if self.token_type == 'word_piece_sequence':
+            enc = self.TokenEncoder(self.sequence_type_to_vocab_file_path(sequence_type))
+            pieces = enc._all_subtoken_strings
+            return [pieces[i].encode('utf-8') for i in enc.encode(' '.join(t.lower() for t in token_list))]
         if self.token_type == 'trial':
             return [' '.join(t.lower() + '_' for t in token_list).encode('utf-8')]
         return [(t.lower() + '_').encode('utf-8') for t in token_list]

@@ -414,7 +414,7 @@ class _Lstm:
             eng, name, ndir, D, in_blocks, in_ld, Hh, stream
         dev = eng.device
         self.H8 = r8(Hh)
-        self.ldy = rk(ndir * self.H8)
+        self.ldy = rk(ndir * self.H8 + 1)      # (+1: always room for the ones column of the consumers' TN weight-gradient GEMMs)
         self.N4 = ndir * 4 * Hh
         self.UT, self.KB, self.KB4 = ceil_div(Hh, 16), ceil_div(self.H8, 32), ceil_div(4 * Hh, 32)
         self.WxT = _bf(self.N4, in_ld, device=dev)
@@ -680,18 +680,18 @@ class Seq2SeqEngine:
                 D, blocks, ld = s.enc_embed, [(0, s.enc_embed, 0)], self.F8
             else:
                 Hp = s.enc_rnn[l - 1]
-                D, blocks, ld = 2 * Hp, [(0, Hp, 0), (Hp, Hp, r8(Hp))], rk(2 * r8(Hp))
+                D, blocks, ld = 2 * Hp, [(0, Hp, 0), (Hp, Hp, r8(Hp))], rk(2 * r8(Hp) + 1)
             self.enc.append(_Lstm(self, 'enc%d' % l, 2, D, blocks, ld, Hh, STREAM_ENC + l))
         self.aux = None
         if s.aux_layer is not None:
             Hk = s.enc_rnn[s.aux_layer]
             self.aux = _FFStack(self, 'aux', [2 * Hk] + list(s.aux_hidden) + [s.aux_dim],
-                                [(0, Hk, 0), (Hk, Hk, r8(Hk))], rk(2 * r8(Hk)), STREAM_AUX)
+                                [(0, Hk, 0), (Hk, Hk, r8(Hk))], rk(2 * r8(Hk) + 1), STREAM_AUX)
         self.E8 = rk(s.dec_embed)
         self.emb = _bf(s.vocab, self.E8, device=dev)
         self.dec = _Lstm(self, 'dec', 1, s.dec_embed, [(0, s.dec_embed, 0)], self.E8, s.dec_rnn, STREAM_DEC_OUT)
         self.proj = _FFStack(self, 'proj', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab],
-                             [(0, s.dec_rnn, 0)], rk(s.dec_rnn), STREAM_DEC_OUT + 1)
+                             [(0, s.dec_rnn, 0)], rk(r8(s.dec_rnn) + 1), STREAM_DEC_OUT + 1)
         # does the buffer a layer reads as x carry the ones column at x[:, D]?  (set where the buffers are allocated)
         self.enc[0].ones_col_set = self.F8 > s.enc_embed
         for l in range(1, len(self.enc)):
@@ -825,17 +825,20 @@ class Seq2SeqEngine:
             lo += cnt
 
     # ------------------------------------------------------------------ packing
-    def pack(self, which='p'):
-        """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema'):
-        ONE launch driven by a device-resident descriptor table (built once)."""
+    def pack(self, which='p', after_head=None):
+        """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema'): two launches driven
+        by device-resident descriptor tables (built once) -- first the (small) images the front-end needs, the conv
+        kernels of all subjects, then everything else; after_head() runs between the two (an event record: the conv GEMM
+        of a captured step waits for the first launch only, not for the 80 us of the second)."""
         src = getattr(self.store, which)
         if self._pack_table is None:
-            ops = []
             st, s = self.store, self.spec
             base = st.p          # offsets are relative, identical for p and ema
+            head = []
             for sid, Cc in s.channels.items():
                 Kc = s.decimation * Cc
-                ops.append(('cast', st.ptr('conv%s.W' % sid, base), 1, s.enc_embed, s.enc_embed, Kc, self.convT[sid], 0, 0))
+                head.append(('cast', st.ptr('conv%s.W' % sid, base), 1, s.enc_embed, s.enc_embed, Kc, self.convT[sid], 0, 0))
+            ops = []
             for lay in self.enc:
                 lay.pack_ops(ops, base)
             if self.aux:
@@ -850,6 +853,16 @@ class Seq2SeqEngine:
                         return 'frag4' if op[0] == 'frag4' else 'fragK'
                     return 'tr' if (op[2] == 1 and op[3] != 1) else 'cast'
                 ops = [op for op in ops if kind_of(op) == want]
+                head = [op for op in head if kind_of(op) == want]
+            self._pack_table = [self._pack_descs(t, base) for t in (head, ops) if t]
+        for i, (dev, n, nblk) in enumerate(self._pack_table):
+            lib.e2t_pack_batch(dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
+            if i == 0 and after_head is not None:
+                after_head()
+        self._packed = which
+
+    def _pack_descs(self, ops, base):
+        if True:
             descs = (H.PackDesc * len(ops))()
             nblk = 0
             p0 = base.data_ptr()
@@ -888,11 +901,7 @@ class Seq2SeqEngine:
                         units = ceil_div(ceil_div(Nn, 16), 4) * KB if tiled else ceil_div(ceil_div(Nn, 16) * KB, 4)
                     nblk += ceil_div(units, 1 if (tiled or four) else H.PACK_UNITS)
             raw = bytes(descs)
-            self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-            self._pack_table = (len(ops), nblk)
-        n, nblk = self._pack_table
-        lib.e2t_pack_batch(self._pack_dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
-        self._packed = which
+            return (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(ops), nblk)
 
     def load_params(self, P):
         self.store.import_tf(P)
@@ -955,7 +964,20 @@ class Seq2SeqEngine:
         self._ws[key] = ws
         return ws
 
+    @staticmethod
+    def check_end_padded(X):
+        """Raise if an utterance of the padded batch X [n,T,C] has an all-zero row in front of a non-zero one: lengths
+        are read off the zero padding (trainers.py:806-807) and the device searches it from the tail."""
+        nz = np.abs(np.asarray(X)).max(axis=2) > 0
+        lens = nz.shape[1] - np.argmax(nz[:, ::-1], axis=1)
+        lens[~nz.any(axis=1)] = 0
+        if int(nz.sum()) != int(lens.sum()):
+            bad = np.nonzero(nz.sum(1) != lens)[0]
+            raise ValueError('utterances %s contain all-zero sample rows in front of their last valid row; zero rows are '
+                             'reserved for the end padding (subjects.py:386-390)' % bad[:8].tolist())
+
     def set_batch(self, ws, batch):
+        self.check_end_padded(batch['encoder_inputs'])
         ws['X'].copy_(torch.as_tensor(np.asarray(batch['encoder_inputs']), dtype=torch.float32))
         ws['Y'].copy_(torch.as_tensor(np.asarray(batch['decoder_targets']), dtype=torch.int32))
         if self.aux and 'encoder_targets' in batch:
@@ -980,11 +1002,12 @@ class Seq2SeqEngine:
         return ntok, nval
 
     # ------------------------------------------------------------------ forward
-    def encode(self, ws, src, train, after_layer=None, after_first=None, after_gx=None, before_weights=None):
+    def encode(self, ws, src, train, after_layer=None, after_first=None, after_gx=None, before_weights=None, before_enc=None):
         s = self.spec
         B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
         st = self.stream
-        lib.e2t_seq_lengths_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
+        # (searched from the tail: end-padded batches only -- subjects.py:386-390; set_batch / the staging code check that)
+        lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
         if after_first is not None:
             after_first()
         lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
@@ -996,6 +1019,8 @@ class Seq2SeqEngine:
                   drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B),
                   alg=(M, s.enc_embed, ws['Kc']))
         x = ws['E'].data_ptr()
+        if before_enc is not None:
+            before_enc()
         for l, (lay, lw) in enumerate(zip(self.enc, ws['enc'])):
             lay.fwd(lw, x, ws['lens_d'], src, train, after_gx=(lambda l=l: after_gx(l)) if after_gx is not None else None)
             x = lw['Ydrop'].data_ptr()
@@ -1071,10 +1096,18 @@ class Seq2SeqEngine:
                 if pack_first:
                     # the operand re-pack of the optimiser step that came before runs here, next to the weight-free
                     # start of the front-end (lengths, im2row) instead of in front of it
-                    pend['pack'] = self.run_side(ev0, lambda: self.pack(which or 'p'))
+                    def pack_side():
+                        self.pack(which or 'p', after_head=lambda: pend.__setitem__('pack_head', self.fork_point()))
+                    pend['pack'] = self.run_side(ev0, pack_side)
                 pend['dec'] = self.run_side(ev0, dec_prep)
 
         def before_weights():
+            # the conv GEMM needs the conv images only (first pack launch); everything else is joined in front of the
+            # first encoder layer's input projection
+            if 'pack_head' in pend:
+                self.join_side(pend.pop('pack_head'))
+
+        def before_enc():
             if 'pack' in pend:
                 self.join_side(pend.pop('pack'))
 
@@ -1092,7 +1125,7 @@ class Seq2SeqEngine:
                 joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
         if (pack_first and not ahead) or (not pack_first and self._packed != (which or 'p')):
             self.pack(which or 'p')        # (a captured train step leaves the images one update behind: see train_step)
-        self.encode(ws, src, train, after_layer, after_first, after_gx, before_weights)
+        self.encode(ws, src, train, after_layer, after_first, after_gx, before_weights, before_enc)
         if 'aux_ev' in pend:
             joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
         jdec = pend.get('dec')

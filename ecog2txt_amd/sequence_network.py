@@ -159,6 +159,8 @@ class SequenceNetwork:
         # per-utterance loss-normalisation counts (what the kernels count on the device): non-pad target tokens, and
         # ceil(valid auxiliary-target length / decimation) samples -- data parallel: every rank can sum them over a
         # GLOBAL batch without any exchange
+        from .engine import Seq2SeqEngine
+        Seq2SeqEngine.check_end_padded(X)
         tok = (Y != 0).sum(1).astype(np.int64)
         val = np.zeros(n, np.int64)
         if A is not None:

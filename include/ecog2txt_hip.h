@@ -59,6 +59,10 @@ int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, int rows_out
 
 /* ---- a4: nn.sequences_tools (trainers.py:789-790, 806-807) ---- */
 int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream);
+/* the same lengths for END-padded batches (subjects.py:386-390), searched from the tail: reads the padding plus <= 32 rows
+ * per utterance instead of all T rows.  length = index of the last non-zero row + 1 (callers guarantee that no interior
+ * row is all-zero; narrow or unaligned rows fall back to the full count). */
+int e2t_seq_lengths_tail_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream);
 int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int div, int32_t* lens, int32_t* lens_div, void* stream);
 int e2t_sum_i32(const int32_t* x, int n, int32_t* out, void* stream);
 int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float* out, void* stream);

@@ -237,6 +237,34 @@ def test_lengths_and_conv_pack(hl, C_):
     assert (got[:, N * C_:] == 0).all()
 
 
+@pytest.mark.parametrize('C_,T', [(256, 400), (1024, 150), (64, 33), (36, 70), (6, 23)])
+def test_lengths_from_the_tail_equal_the_row_count_for_end_padded_batches(hl, C_, T):
+    """e2t_seq_lengths_tail_f32 (searches the padding from the end, 32 rows per pass) against the full non-zero-row count
+    and NumPy, on lengths that hit the pass boundaries; a row whose only non-zero sits in the last channel counts."""
+    rng = np.random.default_rng(C_ + T)
+    B, N = 13, 12
+    lens = np.array([T, 0, 1, T - 1, T - 31, T - 32, T - 33, max(T - 64, 0), 2, 31, 32, min(33, T), T // 2])
+    lens = np.clip(lens, 0, T)
+    X = np.zeros((B, T, C_), np.float32)
+    for b in range(B):
+        X[b, :lens[b]] = np.abs(rng.standard_normal((lens[b], C_))) + 0.1
+        if lens[b] > 0:
+            X[b, lens[b] - 1] = 0
+            X[b, lens[b] - 1, C_ - 1] = 1e-3
+    xt = torch.tensor(X, device='cuda')
+    out = {}
+    for name in ('e2t_seq_lengths_f32', 'e2t_seq_lengths_tail_f32'):
+        lt = torch.full((B,), -7, dtype=torch.int32, device='cuda')
+        ld = torch.full((B,), -7, dtype=torch.int32, device='cuda')
+        getattr(hl.lib, name)(xt.data_ptr(), B, T, C_, N, lt.data_ptr(), ld.data_ptr(), st())
+        torch.cuda.synchronize()
+        out[name] = (lt.cpu().numpy(), ld.cpu().numpy())
+    for lt, ld in out.values():
+        np.testing.assert_array_equal(lt, lens)
+        np.testing.assert_array_equal(ld, -(-lens // N))
+    np.testing.assert_array_equal(O.sequence_lengths(X), lens)
+
+
 def test_softmax_ce(hl):
     rng = np.random.default_rng(0)
     B, L, V = 6, 5, 1806

@@ -88,3 +88,17 @@ def test_greedy_consistent_with_teacher_forcing():
         ln = int((Y[b] != 0).sum())
         for l in range(min(ln, n)):
             np.testing.assert_allclose(tf_logits[l, b], logits[l, b], atol=1e-9)
+
+
+def test_interior_zero_rows_are_rejected_on_the_host():
+    """Lengths are read off the END padding (trainers.py:806-807, subjects.py:386-390); the device searches it from the tail,
+    so an all-zero sample row in front of valid samples must be refused when a batch is staged."""
+    import pytest
+    from ecog2txt_amd.engine import Seq2SeqEngine
+    X = np.ones((3, 6, 4), np.float32)
+    X[1, 4:] = 0
+    X[2] = 0
+    Seq2SeqEngine.check_end_padded(X)
+    X[0, 2] = 0
+    with pytest.raises(ValueError, match='all-zero sample rows'):
+        Seq2SeqEngine.check_end_padded(X)
