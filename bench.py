@@ -141,6 +141,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--gemm-detail', action='store_true', help='stderr: isolated time of every logged product of the step')
     args = ap.parse_args()
 
     import torch
@@ -262,6 +263,11 @@ def main():
                                 algorithmic_hbm_bytes_per_launch=int(sum(r['in_bytes'] + r['out_bytes'] for r in recs) / len(recs)),
                                 us_per_step=round(us, 1), includes_splitk_reduce=any(r['splits'] > 1 for r in recs),
                                 largest='M=%d N=%d K=%d x%d (splits %d)' % (big['M'], big['N'], big['K'], big['batch'], big['splits']))
+        if args.gemm_detail:
+            for r in log:
+                us1 = time_graph(lambda: eng.gemm_replay(r), 10)
+                print('%-6s M=%5d N=%5d K=%5d x%d splits %d %s  %7.1f us  %6.1f TF' % (r['inst'], r['M'], r['N'], r['K'], r['batch'], r['splits'],
+                      'side' if r['side'] else 'main', us1, r['flops'] / us1 / 1e6), file=sys.stderr)
         if groups:
             dom = max(groups, key=lambda k: groups[k]['us_per_step'])          # the instance with the largest share of the step
             roof = dict(groups[dom], instance=dom)

@@ -442,6 +442,10 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
         if (s > nfull / 16) s = nfull / 16;            // keep >= 16 K tiles per split: a workgroup's fixed cost (DMA fill, slab
                                                        // store, its share of the reduction) is worth ~8 of them (measured on the
                                                        // train step: 6 -> 16 tiles per split -1.2 %, 24 and more slower again)
+        // (measured, E2T_GEMM_SPLITS sweep, dW_x 801 x 3200 x 8704 = 175 tiles: 1 split 114 us, 2: 92, 3: 105, 4: 94; batched
+        //  dW_h 104 tiles: 1: 109, 2: 67, 3: 63, 4: 56 -- a workgroup ALONE on a CU is not faster than one of two: a K tile
+        //  costs ~0.8 us of LDS-DMA issue + wait + barrier either way, so filling both slots of every CU is what counts)
+        { static const int forced_s = [] { const char* e = getenv("E2T_GEMM_SPLITS"); return e ? atoi(e) : 0; }(); if (forced_s > 0) s = forced_s; }
         const size_t per = (size_t)M * N * sizeof(float) * pl.batch;
         if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
         if (s < 1) s = 1;

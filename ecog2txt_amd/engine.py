@@ -614,7 +614,7 @@ class _Lstm:
             e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
                    rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop, alg=(M, self.D, self.N4))
 
-    def bwd_weights(self, ws, x_ptr):
+    def bwd_weights(self, ws, x_ptr, part=None):
         """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the
         engine runs it on a side stream under the next layer's BPTT.  Both products have K = S*B rows of activations
         (x, h_{t-1}) and of their gradients (dG) exactly as the layers wrote them -- K-major -- so they go to the TN
@@ -627,14 +627,18 @@ class _Lstm:
         nd, Hh = self.ndir, self.H
         dense = all(k0 == r0 for (r0, n, k0) in self.in_blocks) and self.in_ld > self.D
         if e.tn and dense and self.ones_col_set:
-            e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
-                   self.D + 1, self.N4, M, splitk=True, tn=True)
+            if part in (None, 0):
+                e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
+                       self.D + 1, self.N4, M, splitk=True, tn=True)
             # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction).  Both directions in ONE
             # batched launch: twice the tiles, so half the K splits (slabs, workgroup start-ups) for the same fill
-            e.gemm(ws['Yext'].data_ptr(), self.ldy, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wh', st.g), 4 * Hh,
-                   Hh, 4 * Hh, M, splitk=True, tn=True,
-                   batch=(nd, 2 * B * self.ldy + self.H8, 4 * Hh, Hh * 4 * Hh) if nd > 1 else None)
+            if part in (None, 1):
+                e.gemm(ws['Yext'].data_ptr(), self.ldy, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wh', st.g), 4 * Hh,
+                       Hh, 4 * Hh, M, splitk=True, tn=True,
+                       batch=(nd, 2 * B * self.ldy + self.H8, 4 * Hh, Hh * 4 * Hh) if nd > 1 else None)
             return
+        if part == 1:
+            return              # (the transposing fallback shares buffers between its products: everything runs as part 0)
         lib.e2t_transpose_bf16(ws['dG'].data_ptr(), rk(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
         for (r0, n, k0) in self.in_blocks:
             lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
@@ -715,6 +719,9 @@ class Seq2SeqEngine:
         self.splitk_ws = _f32(16 * 1024 * 1024, device=dev)          # 64 MiB of split-K partial slabs
         self.splitk_ws_side = _f32(16 * 1024 * 1024, device=dev)     # ... of the side stream (weight-gradient branch)
         self._on_side = False
+        self._ws_override = None      # split-K workspace of the second side lane while it is being enqueued
+        self._wstream2, self.splitk_ws_side2 = None, None
+        self.par_gemms = os.environ.get('E2T_PAR_GEMMS', '0') != '0'     # weight gradients on TWO side streams (dW_x | dW_h): measured slower (2.02 vs 1.87 ms), off
         self._wstream = None
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
         self._ovl = os.environ.get('E2T_OVERLAP', '1')          # diagnostics: 'auxf' / 'stage' / 'defer' subsets
@@ -764,7 +771,7 @@ class Seq2SeqEngine:
         if splitk:
             flags |= H.GEMM_SPLITK
         # the workspace is always offered: the library also splits K on its own when a product has too few tiles
-        wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
+        wsb = self._ws_override if self._ws_override is not None else (self.splitk_ws_side if self._on_side else self.splitk_ws)
         ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
@@ -1178,12 +1185,18 @@ class Seq2SeqEngine:
         for l in range(nl - 1, -1, -1):
             if l < nl - 1:
                 names = enc_names(l + 1)
-                side = (lambda train, l=l: self._bwd_enc_weights(ws, l + 1))
+                side = (lambda train, l=l, part=None: self._bwd_enc_weights(ws, l + 1, part))
             else:       # the head's own weight gradients queue up first, under the top layer's BPTT
                 names = head
-                side = (lambda train: self._bwd_head_weights(ws, train))
+                side = (lambda train, part=None: self._bwd_head_weights(ws, train, part))
             stages.append((lambda train, l=l: self._bwd_enc_rec(ws, l, train), side, rng_of(names)))
-        stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
+        if self.par_gemms:
+            # the bottom layer's dW_h runs next to its dW_x + conv gradient instead of behind them
+            stages.append((lambda train: self._bwd_enc_weights(ws, 0, 0),
+                           lambda train, part=None: (self._bwd_enc_weights(ws, 0, 1) if part in (None, 1) else None),
+                           rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
+        else:
+            stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
         return stages
 
     def fork_side(self, fn):
@@ -1214,19 +1227,28 @@ class Seq2SeqEngine:
         ev.record(torch.cuda.current_stream(self.device))
         return ev
 
-    def run_side(self, ev, fn):
-        """fn() on the side stream, ordered after fork_point() event ev.  Returns the event to pass to join_side()."""
+    def run_side(self, ev, fn, lane=0):
+        """fn() on the side stream, ordered after fork_point() event ev.  Returns the event to pass to join_side().
+        lane 1: a second side stream with its own split-K workspace -- independent weight-gradient products (dW_x | dW_h
+        of a layer) then run side by side and fill each other's ramp-up / ramp-down bubbles instead of queueing in
+        stream order.  (Both lanes fork from the MAIN branch: a fork off a forked stream crashes hipGraphInstantiate.)"""
         if self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
-        self._wstream.wait_event(ev)
-        with torch.cuda.stream(self._wstream):
+        if lane == 1 and self._wstream2 is None:
+            self._wstream2 = torch.cuda.Stream(device=self.device)
+            self.splitk_ws_side2 = _f32(16 * 1024 * 1024, device=self.device)
+        stream = self._wstream2 if lane == 1 else self._wstream
+        stream.wait_event(ev)
+        with torch.cuda.stream(stream):
             self._on_side = True
+            self._ws_override = self.splitk_ws_side2 if lane == 1 else None
             try:
                 fn()
             finally:
                 self._on_side = False
+                self._ws_override = None
             join = torch.cuda.Event()
-            join.record(self._wstream)
+            join.record(stream)
         return join
 
     def join_side(self, join):
@@ -1271,7 +1293,11 @@ class Seq2SeqEngine:
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
                 ev = self.fork_point()
                 main(train)
-                deferred.append(self.run_side(ev, lambda side=side: side(train)))
+                if self.par_gemms and self._ovl == '1':
+                    deferred.append(self.run_side(ev, lambda side=side: side(train, part=0)))
+                    deferred.append(self.run_side(ev, lambda side=side: side(train, part=1), lane=1))
+                else:
+                    deferred.append(self.run_side(ev, lambda side=side: side(train)))
                 if early is not None and i in early:
                     deferred.append(self.run_side(ev, early[i]))
             else:
@@ -1294,16 +1320,19 @@ class Seq2SeqEngine:
         self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
                          None, self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'], dy_masked=dd is not None)
 
-    def _bwd_head_weights(self, ws, train):
-        """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them."""
+    def _bwd_head_weights(self, ws, train, part=None):
+        """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them.
+        part 0 / 1: the two halves that run on the two side lanes (None: everything)."""
         s, store = self.spec, self.store
-        self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
-        # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
-        self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
-        self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
-        dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
-        lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
-                          store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)
+        if part in (None, 0):
+            self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
+            # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
+            self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
+            dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
+            lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
+                              store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)
+        if part in (None, 1):
+            self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
 
     def _bwd_enc_rec(self, ws, l, train):
         """aux head (if it taps layer l), BPTT of layer l, gradient into the layer below."""
@@ -1344,14 +1373,15 @@ class Seq2SeqEngine:
                      d_in_drop=lay.out_drop(train))
         ws['have_dy'][l] = True
 
-    def _bwd_enc_weights(self, ws, l):
-        """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end)."""
+    def _bwd_enc_weights(self, ws, l, part=None):
+        """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end).
+        part 0: dW_x (+ conv), part 1: dW_h -- the halves for the two side lanes; None: everything."""
         s, store = self.spec, self.store
         M, Mk = ws['M'], ws['Mk']
         st = self.stream
         x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
-        self.enc[l].bwd_weights(ws['enc'][l], x)
-        if l > 0:
+        self.enc[l].bwd_weights(ws['enc'][l], x, part)
+        if l > 0 or part == 1:
             return
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
         sid = ws['sid']
