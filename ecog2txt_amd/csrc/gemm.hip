@@ -129,13 +129,17 @@ extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
 
 // RICH = false drops the ReLU / mask / dropout epilogue: with 32 accumulator tiles per wave the full epilogue body is too
 // large for hipcc to unroll, and a rolled loop indexes the accumulators dynamically (= scratch memory, 4x slower kernel).
-template <int BM, int BN, int WM, int WN, bool RICH, bool TN>
-__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void k_gemm_nt(GemmArgs p_in) {
+// KT = K depth of a stage (64; 32 for the K-major instance with 4 workgroups per CU: a K tile costs ~0.8 us of LDS-DMA
+// issue + wait + barrier whether one or two workgroups share the CU, so the K-major products -- whose k-rows are full
+// 256-B lines at any depth -- trade pipeline depth for occupancy: 32 KiB of LDS and <= 128 registers per workgroup)
+template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64>
+__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 4 : 2) : 1) void k_gemm_nt(GemmArgs p_in) {
     const GemmArgs p = gemm_batch_view(p_in, blockIdx.z);
     constexpr int NW = WM * WN, NT = 64 * NW;
-    constexpr int STAGE = (BM + BN) * 8;         // 16-B units per stage: [A: BM rows | B: BN rows][8 chunks]
+    constexpr int STAGE = (BM + BN) * (KT / 8);  // 16-B units per stage: [A: BM rows | B: BN rows][KT/8 chunks]
+    static_assert(KT == 64 || (TN && KT == 32), "a 32-deep stage exists for the K-major form only");
     constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
-    constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;      // DMA instructions per wave and operand (8 rows each)
+    constexpr int IA = BM / 8 / NW * KT / 64, IB = BN / 8 / NW * KT / 64;      // DMA instructions per wave and operand (1 KiB each)
     uint4* smem = gemm_smem;                     // [2 stages][STAGE], ONE object
 
     // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): each XCD walks a
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
 
     // K range of this split (in full 64-wide tiles; the zero-filled tail belongs to the last split)
-    const int nfull = TN ? (p.K + BK - 1) / BK : p.K / BK;
+    const int nfull = TN ? (p.K + KT - 1) / KT : p.K / BK;
     const bool has_tail = !TN && (p.K % BK) != 0;
     const int per = (nfull + p.splits - 1) / p.splits;
     const int t0 = blockIdx.y * per;
@@ -183,9 +187,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     // one DMA instruction (1 KiB) of tile t into stage buf: pieces 0..IA-1 belong to the A tile, IA..IA+IB-1 to the B tile
     constexpr int NP = IA + IB;
     auto issue_piece = [&](int t, int buf, int pc_) {
-        const int k0 = t * BK;
+        const int k0 = t * KT;
         uint4* sa = smem + buf * STAGE;
-        uint4* sb = sa + BM * 8;
+        uint4* sb = sa + BM * (KT / 8);
         const bool isA = pc_ < IA;
         const int i = isA ? pc_ : pc_ - IA;
         if (TN) {
@@ -229,13 +233,13 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? 2 : 1) void 
     // preceding it
     auto compute = [&](int buf, int nt) {
         const uint4* sa = smem + buf * STAGE;
-        const uint4* sb = sa + BM * 8;
+        const uint4* sb = sa + BM * (KT / 8);
         // 128 x 128 instances: the fragments of BOTH K blocks are requested before the first MFMA (registers to spare), so
         // the LDS latency is exposed once per tile instead of once per K block
         constexpr bool BOTH = (BM * BN <= 128 * 128) && !TN;      // (K-major operands: measured 4 % slower this way)
         bf16x8 fa2[2][TI], fb2[2][TJ];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KT / 32; ++kb) {
             bf16x8 (&fa)[TI] = fa2[kb], (&fb)[TJ] = fb2[kb];
             if (TN) {
                 // lane (frow = l&15, fq = l>>4) needs k = kb*32 + fq*8 .. +7 of column (tile offset + frow): two transposing
@@ -413,6 +417,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
 
 
 struct GemmPlan { int tile, splits, batch; bool want_split; };
+// stage depth of the K-major instance: 64; E2T_TN_KT=32 selects the 4-workgroups-per-CU variant (diagnostics -- measured:
+// dW_x 801 x 3200 x 8704 88-92 us vs 93, batched dW_h 63 vs 56, whole step 1.94 vs 1.87 ms: more occupancy does not help, the
+// instance is bound by the bytes a CU can pull into LDS per flop, not by latency)
+static int tn_stage_depth() {
+    static const int kt = [] { const char* e = getenv("E2T_TN_KT"); return (e && atoi(e) == 32) ? 32 : 64; }();
+    return kt;
+}
 // Which instance a product runs on, and its split count (shared by the launcher and e2t_gemm_plan).
 static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue* ep) {
     // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
@@ -420,7 +431,8 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
     // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
     // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
-    const int nfull = tn ? (K + BK - 1) / BK : K / BK;
+    const int kt = tn ? tn_stage_depth() : BK;
+    const int nfull = tn ? (K + kt - 1) / kt : K / BK;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool have_ws = ep && ep->splitk_ws && ep->splitk_ws_bytes > 0;
     const bool want_split = have_ws && ((ep->flags & E2T_GEMM_SPLITK) || (t128 <= 160 && nfull >= 16));
@@ -437,9 +449,10 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     if (want_split) {
         const int ntm = (M + pl.tile - 1) / pl.tile, ntn = (N + pl.tile - 1) / pl.tile;
         const int tiles = ntm * ntn * pl.batch;
-        int s = 512 / tiles;                           // fill, but never exceed, the 2 x 256 resident workgroups: one block
+        const int slots = (tn && kt == 32) ? 1024 : 512;
+        int s = slots / tiles;                         // fill, but never exceed, the 2 (4) x 256 resident workgroups: one block
                                                        // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
-        if (s > nfull / 16) s = nfull / 16;            // keep >= 16 K tiles per split: a workgroup's fixed cost (DMA fill, slab
+        if (s > nfull * kt / 1024) s = nfull * kt / 1024;   // keep >= 16 K tiles (of 64) per split: a workgroup's fixed cost (DMA fill, slab
                                                        // store, its share of the reduction) is worth ~8 of them (measured on the
                                                        // train step: 6 -> 16 tiles per split -1.2 %, 24 and more slower again)
         // (measured, E2T_GEMM_SPLITS sweep, dW_x 801 x 3200 x 8704 = 175 tiles: 1 split 114 us, 2: 92, 3: 105, 4: 94; batched
@@ -490,7 +503,8 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
     if (attr_rc != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); return E2T_ERR_HIP; }
-    if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
+    if (tn && tn_stage_depth() == 32) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 32>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 4 * 16, (hipStream_t)stream, p);
+    else if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     if (p.splits > 1) {
