@@ -453,8 +453,9 @@ class _Lstm:
             return False
         if self.big:
             return ceil_div(B, 64) * self.ndir * (self.H // 32) <= num_cus
-        if self.KB <= 13:
-            return ceil_div(B, 64) * self.ndir * self.UT <= num_cus
+        if self.KB <= 13:        # 16 x 64 tiling with the state shared through LDS, or 64 x 16 (csrc/lstm.hip picks)
+            return (ceil_div(B, 16) * self.ndir * ceil_div(self.UT, 4) <= num_cus
+                    or ceil_div(B, 64) * self.ndir * self.UT <= num_cus)
         return self.KB <= 26 and ceil_div(B, 32) * self.ndir * ceil_div(self.UT, 2) <= num_cus
 
     def persistent_bwd_ok(self, B, num_cus):
