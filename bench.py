@@ -163,10 +163,16 @@ def main():
     # data parallel: RCCL through the C ABI (e2t_comm_*); E2T_COMM=torch selects torch.distributed's "nccl" instead
     sync = None
     if world > 1:
-        if os.environ.get('E2T_COMM', 'rccl') != 'rccl':
+        if os.environ.get('E2T_COMM', 'rccl') == 'rccl':
+            try:
+                sync = parallel.make_sync(eng.store.g)
+            except Exception as e:                          # (symmetric on all ranks of a node: same library, same driver)
+                print('bench: direct RCCL exchange unavailable (%r); falling back to torch.distributed "nccl"' % (e,), file=sys.stderr)
+                os.environ['E2T_COMM'] = 'torch'
+        if sync is None:
             import torch.distributed as dist
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        sync = parallel.make_sync(eng.store.g)
+            sync = parallel.make_sync(eng.store.g)
         sync.broadcast_([eng.store.p, eng.store.ema])
     eng.pack('p')
     # one workspace per participant (cfg3: four, stepped in turn -- SURVEY.md 8 d2); synthetic batches resident in HBM

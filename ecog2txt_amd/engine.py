@@ -1561,6 +1561,8 @@ class Seq2SeqEngine:
                     self.adam_step(ws['sid'], repack=False, skip_below=early_end)
                 g = (g1,)
             ws['graph'][key] = g
+        # (a replay does not run forward(): an assessment in between may have left the flag off)
+        ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
         if not dp:
             g[0].replay()
             self._packed = None          # the images are those of the weights BEFORE this step's update
