@@ -416,6 +416,133 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a5 + a6 fused: tf.reverse_sequence (trainers.py:808-810) + strided temporal convolution (_convolve_sequences,
+// trainers.py:813-818) straight from the fp32 electrode grid x [B][T][C] -- ONE pass over the input, no packed bf16 copy
+// (config 5: 2.1 GB of input; the im2row copy cost a second pass plus 1.05 GB of writes and 1.05 GB of re-reads).
+//   E[m][n] = epilogue( sum_k bf16(x[b][len_b - 1 - (t'*N + w)][c]) * W[n][k] ),  m = t'*B + b,  k = w*C + c
+// A workgroup owns 64 output rows x all F <= 128 columns; per K step it gathers 64 rows x 64 fp32 (256 contiguous bytes
+// per row: C % 64 == 0 keeps a step inside one source row), rounds them to bf16 on the way into LDS (the rounding point of
+// e2t_conv_pack, so the products are the same), and multiplies with the matching 128 x 64 slice of the weight image.
+// HBM-bound by design: 3 workgroups per CU keep ~48 KiB of fp32 loads in flight per CU.  Epilogue = the GEMM's (bias,
+// ReLU, dropout, rows beyond an utterance's decimated length zeroed).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvFwdArgs {
+    const float* x; const int* lens; const bf16_t* WT; int ldw;
+    int B, T, C, N, M, F;
+    GemmArgs epi;               // C = E, ldc, N = F, flags, drop, ld_logical, lens (decimated) / rowsB
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvFwdArgs a) {
+    constexpr int BMc = 64, BNc = 128;
+    __shared__ __attribute__((aligned(16))) uint4 sm[2][(BMc + BNc) * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BMc;
+    const int K = a.N * a.C, nk = K / 64;
+    // gather map: thread -> (row r = tid/4, 16 consecutive k = two 16-B bf16 chunks q*2, q*2+1)
+    const int r = tid >> 2, q = tid & 3;
+    const int m = min(m0 + r, a.M - 1);
+    const int tp = m / a.B, b = m - tp * a.B;
+    const int len = a.lens[b];
+    const float* xb = a.x + (size_t)b * a.T * a.C;
+    // weight map: thread -> rows n = tid/8 + 32*i (i < 4), chunk tid%8
+    const int wn = tid >> 3, wc = tid & 7;
+    float4 av[4];
+    uint4 wv[4];
+    auto gload = [&](int t) {
+        const int k0 = t * 64, w = k0 / a.C, c0 = k0 - w * a.C;
+        const int tt = tp * a.N + w;
+        if (tt < len) {
+            const f32x4* src = (const f32x4*)(xb + (size_t)(len - 1 - tt) * a.C + c0 + q * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const f32x4 v = __builtin_nontemporal_load(src + i); av[i] = make_float4(v[0], v[1], v[2], v[3]); }   // read once
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = *(const uint4*)(a.WT + (size_t)min(wn + 32 * i, a.F - 1) * a.ldw + k0 + wc * 8);
+    };
+    auto lstore = [&](int buf) {
+        uint4* sa = sm[buf];
+        uint4* sb = sa + BMc * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 v0 = av[2 * h], v1 = av[2 * h + 1];
+            uint4 o;
+            o.x = f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16); o.y = f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
+            o.z = f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16); o.w = f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
+            sa[swz(r, q * 2 + h)] = o;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[swz(wn + 32 * i, wc)] = wv[i];
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) gload(t + 1);                           // in flight while tile t is multiplied
+        const uint4* sa = sm[t & 1];
+        const uint4* sb = sa + BMc * 8;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const uint4 fa = sa[swz(wave * 16 + frow, kb * 4 + fq)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 fb = sb[swz(j * 16 + frow, kb * 4 + fq)];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fb, *(const bf16x8*)&fa, acc[j], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nk) lstore((t + 1) & 1);                    // the other stage: nobody reads it before the barrier
+        __syncthreads();
+    }
+    // epilogue: D[i][j]: column j = lane&15 is the output row, rows (lane>>4)*4 + r are four consecutive channels
+    const GemmArgs& p = a.epi;
+    const EpiCtx ec = epi_ctx(p);
+    const int gm = m0 + wave * 16 + frow;
+    if (gm >= a.M) return;
+    const bool rowvalid = p.lens ? (gm / p.rowsB) < p.lens[gm % p.rowsB] : true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gn0 = j * 16 + fq * 4;
+        if (gn0 >= a.F) continue;
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) v[rr] = acc[j][rr] + ((p.bias && gn0 + rr < a.F) ? p.bias[gn0 + rr] : 0.f);
+        epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
+    }
+}
+
+extern "C" int e2t_conv_fwd_fused_ok(int C, int F) { return (C % 64 == 0 && F >= 1 && F <= 128) ? 1 : 0; }
+
+extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, int T, int C, int N, const void* WT, int ldw,
+                                  void* E, int lde, int F, const e2t_gemm_epilogue* ep, void* stream) {
+    E2T_CHECK_ARG(x && lens && WT && E && ep);
+    E2T_CHECK_ARG(B > 0 && T > 0 && N > 0 && e2t_conv_fwd_fused_ok(C, F) && ldw % 8 == 0 && ldw >= N * C && lde >= F);
+    E2T_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)WT) & 15) == 0 && (ep->flags & E2T_GEMM_OUT_BF16));
+    ConvFwdArgs a{};
+    a.x = x; a.lens = lens; a.WT = (const bf16_t*)WT; a.ldw = ldw;
+    a.B = B; a.T = T; a.C = C; a.N = N; a.F = F;
+    const int S = (T + N - 1) / N;
+    a.M = S * B;
+    GemmArgs& p = a.epi;
+    p.C = E; p.ldc = lde; p.M = a.M; p.N = F; p.K = N * C; p.alpha = 1.0f; p.splits = 1;
+    p.bias = ep->bias;
+    p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1;
+    p.flags = ep->flags;
+    p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;
+    p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : F;
+    hipLaunchKernelGGL(k_conv_fwd, dim3((a.M + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+    E2T_LAUNCH_CHECK();
+    return E2T_OK;
+}
+
 struct GemmPlan { int tile, splits, batch; bool want_split; };
 // stage depth of the K-major instance: 64; E2T_TN_KT=32 selects the 4-workgroups-per-CU variant (diagnostics -- measured:
 // dW_x 801 x 3200 x 8704 88-92 us vs 93, batched dW_h 63 vs 56, whole step 1.94 vs 1.87 ms: more occupancy does not help, the

@@ -726,6 +726,7 @@ class Seq2SeqEngine:
         self._wstream = None
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
         self._ovl = os.environ.get('E2T_OVERLAP', '1')          # diagnostics: 'auxf' / 'stage' / 'defer' subsets
+        self.fused_conv = os.environ.get('E2T_FUSED_CONV', '0') != '0'     # front-end in one pass over x (no packed copy in forward): measured SLOWER (cfg5 1296 vs 847 us, cfg2 132 vs 60), off
         self.tn = os.environ.get('E2T_TN', '1') != '0'       # weight gradients straight from the K-major activations (no transposes)
         self.trainable = None         # None = everything; else set of segment names
 
@@ -1018,14 +1019,31 @@ class Seq2SeqEngine:
         lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
         if after_first is not None:
             after_first()
-        lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
+        fused = self.fused_conv and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed))
+        if not fused:
+            lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
+        ws['A_stale'] = fused                 # the im2row copy is made in the backward pass, where the conv gradient needs it
         if before_weights is not None:
             before_weights()
-        self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
-                  M, s.enc_embed, ws['Kc8'],
-                  bias=self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed), relu=s.conv_relu, out_bf16=True,
-                  drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B),
-                  alg=(M, s.enc_embed, ws['Kc']))
+        if fused:
+            # one pass over the fp32 electrode grid: reversal + im2row + bf16 rounding in the GEMM's staging path
+            ep = H.GemmEpilogue()
+            ep.bias = self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed)
+            ep.alpha = 1.0
+            ep.flags = (H.GEMM_RELU if s.conv_relu else 0) | H.GEMM_OUT_BF16
+            ep.row_lens, ep.rows_per_step = ws['lens_d'].data_ptr(), B
+            if train and s.ff_dropout > 0:
+                ep.flags |= H.GEMM_DROPOUT
+                ep.drop_rate, ep.drop_stream, ep.drop_ld = s.ff_dropout, STREAM_CONV, s.enc_embed
+                ep.drop_seed, ep.drop_step = self.seed, self.step_t.data_ptr()
+            lib.e2t_conv_fwd_fused(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, self.convT[ws['sid']].data_ptr(),
+                                   ws['Kc8'], ws['E'].data_ptr(), self.F8, s.enc_embed, C.byref(ep), st)
+        else:
+            self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
+                      M, s.enc_embed, ws['Kc8'],
+                      bias=self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed), relu=s.conv_relu, out_bf16=True,
+                      drop=(s.ff_dropout if train else 0.0, STREAM_CONV, s.enc_embed), row_lens=(ws['lens_d'].data_ptr(), B),
+                      alg=(M, s.enc_embed, ws['Kc']))
         x = ws['E'].data_ptr()
         if before_enc is not None:
             before_enc()
@@ -1386,6 +1404,10 @@ class Seq2SeqEngine:
             return
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
         sid = ws['sid']
+        if ws.get('A_stale'):          # fused forward: the packed bf16 copy is made here, off the forward critical path
+            lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), ws['B'], ws['T'], ws['C'], s.decimation,
+                              ws['A'].data_ptr(), ws['Kc8'], st)
+            ws['A_stale'] = False
         if self.tn:
             self.gemm(ws['A'].data_ptr(), ws['Kc8'], ws['dEpre'].data_ptr(), self.F8, store.ptr('conv%s.W' % sid, store.g),
                       s.enc_embed, ws['Kc'] + 1, s.enc_embed, M, splitk=True, tn=True)

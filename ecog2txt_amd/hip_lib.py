@@ -54,6 +54,7 @@ SIGNATURES = {
     'e2t_sum_i32': [_p, _i, _p, _p],
     'e2t_sum_f32': [_p, _i, _p, _f, _p, _p],
     'e2t_conv_pack': [_p, _p, _i, _i, _i, _i, _p, _i, _p],
+    'e2t_conv_fwd_fused': [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, C.POINTER(GemmEpilogue), _p],
     'e2t_conv_unpack_grad': [_p, _i, _p, _i, _i, _i, _i, _p, _p],
     'e2t_gather_rev_decim_f32': [_p, _p, _i, _i, _i, _i, _p, _p],
     'e2t_gather_rev_decim_i32': [_p, _p, _i, _i, _i, _p, _p],
@@ -89,7 +90,7 @@ SIGNATURES = {
 }
 COMM_ID_BYTES = 128
 PLAIN = {'e2t_abi_version': ([], C.c_int), 'e2t_sizeof': ([_i], C.c_int), 'e2t_last_error': ([], C.c_char_p), 'e2t_device_cus': ([_i], C.c_int),
-         'e2t_bwd_persist_kq': ([_i], C.c_int), 'e2t_lstm_big_ok': ([_i], C.c_int), 'e2t_comm_rank': ([_p], C.c_int), 'e2t_comm_size': ([_p], C.c_int),
+         'e2t_bwd_persist_kq': ([_i], C.c_int), 'e2t_lstm_big_ok': ([_i], C.c_int), 'e2t_conv_fwd_fused_ok': ([_i, _i], C.c_int), 'e2t_comm_rank': ([_p], C.c_int), 'e2t_comm_size': ([_p], C.c_int),
          'e2t_crc32c': ([_p, _z, C.c_uint32], C.c_uint32)}
 
 _lib = None

@@ -422,3 +422,48 @@ def test_gather_rows_assembles_a_batch_with_padding_rows(hl, row_words):
         if idx[r] >= 0:
             want[r] = src[idx[r]]
     np.testing.assert_array_equal(dst.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('C_,F,N,T,B', [(64, 100, 12, 50, 9), (256, 100, 12, 400, 40), (1024, 100, 12, 100, 24), (128, 128, 4, 30, 70), (64, 5, 3, 20, 3)])
+def test_fused_conv_forward_matches_pack_plus_gemm(hl, C_, F, N, T, B):
+    """e2t_conv_fwd_fused (one pass over the fp32 grid: reversal + im2row + bf16 rounding + GEMM + epilogue) against the
+    NumPy restatement: bf16(x) . bf16(W) accumulated in fp64, + bias, ReLU, rows beyond the decimated length zeroed
+    (oracle/seq2seq.py forward(), conv stage; trainers.py:808-818)."""
+    rng = np.random.default_rng(C_ + F)
+    S = -(-T // N)
+    lens = rng.integers(1, T + 1, size=B)
+    lens[0] = T
+    if B > 2:
+        lens[1] = 1
+    X = (np.abs(rng.standard_normal((B, T, C_))) + 0.1).astype(np.float32)
+    for b in range(B):
+        X[b, lens[b]:] = 0
+    K = N * C_
+    ldw = (K + 1 + 63) // 64 * 64
+    W = (rng.standard_normal((F, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32) * 0.1
+    WT = torch.zeros((F, ldw), dtype=torch.bfloat16, device='cuda')
+    WT[:, :K] = dev_bf16(W)
+    lde = (F + 63) // 64 * 64
+    E = torch.full((S * B, lde), 7.0, dtype=torch.bfloat16, device='cuda')
+    xt = torch.tensor(X, device='cuda')
+    lt = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    ld = torch.tensor(-(-lens // N), dtype=torch.int32, device='cuda')
+    bt = torch.tensor(bias, device='cuda')
+    ep = hl.GemmEpilogue()
+    ep.bias, ep.alpha, ep.flags = bt.data_ptr(), 1.0, hl.GEMM_RELU | hl.GEMM_OUT_BF16
+    ep.row_lens, ep.rows_per_step = ld.data_ptr(), B
+    assert hl.load().e2t_conv_fwd_fused_ok(C_, F) == 1
+    hl.lib.e2t_conv_fwd_fused(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, WT.data_ptr(), ldw, E.data_ptr(), lde, F, C.byref(ep), st())
+    torch.cuda.synchronize()
+    Xr = O.reverse_time_major(X.astype(np.float64), lens)
+    Xp = np.zeros((S * N, B, C_))
+    Xp[:T] = Xr
+    A = round_bf16(Xp.reshape(S, N, B, C_).transpose(0, 2, 1, 3).reshape(S * B, K))
+    want = np.maximum(A @ round_bf16(W.astype(np.float64)).T + bias, 0.0)
+    valid = (np.arange(S)[:, None] < (-(-lens // N))[None, :]).reshape(-1)
+    want = round_bf16(want * valid[:, None])
+    got = host(E)
+    np.testing.assert_allclose(got[:, :F], want, rtol=1e-2, atol=1e-2)          # bf16 output: one ulp where fp32 vs fp64 sums straddle
+    assert (got[:, F:] == 7.0).all()                                              # padding columns untouched (the ones column lives there)
+    assert np.abs(got[:, :F] - want).mean() < 2e-4
