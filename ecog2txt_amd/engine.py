@@ -707,6 +707,8 @@ class Seq2SeqEngine:
             k = s.aux_layer
             self.aux.ones_col_set = self.enc[k].ldy > 2 * self.enc[k].H8
         self._pack_table = None
+        self._pack_ops, self._pack_sub = None, {}
+        self._img_early = None        # 'all' after a full pack of the masters, else the ranges the last replay re-packed itself
         self._gemm_log = None         # a list while bench.py records the step's products (instance, shape, flops)
         mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
         self.persistent = mode != '0'
@@ -727,6 +729,7 @@ class Seq2SeqEngine:
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
         self._ovl = os.environ.get('E2T_OVERLAP', '1')          # diagnostics: 'auxf' / 'stage' / 'defer' subsets
         self.fused_conv = os.environ.get('E2T_FUSED_CONV', '0') != '0'     # front-end in one pass over x (no packed copy in forward): measured SLOWER (cfg5 1296 vs 847 us, cfg2 132 vs 60), off
+        self.early_pack = os.environ.get('E2T_EARLY_PACK', '1') != '0'     # images of early-updated ranges re-packed under the backward pass
         self.tn = os.environ.get('E2T_TN', '1') != '0'       # weight gradients straight from the K-major activations (no transposes)
         self.trainable = None         # None = everything; else set of segment names
 
@@ -834,12 +837,50 @@ class Seq2SeqEngine:
             lo += cnt
 
     # ------------------------------------------------------------------ packing
-    def pack(self, which='p', after_head=None):
+    def pack_ranges(self, ranges):
+        """Re-pack (from the masters) exactly the images whose source parameters lie in the element ranges `ranges`: used by
+        the captured train step right behind the optimiser update of those ranges, so that the next step starts with
+        only the bottom layer's images left to build."""
+        tab = self._pack_subtable(tuple(ranges))
+        if tab:
+            lib.e2t_pack_batch(tab[0].data_ptr(), tab[1], tab[2], self.store.p.data_ptr(), self.stream)
+
+    def _pack_subtable(self, key):
+        """Descriptor table of the images sourced from the ranges `key` (built once, OUTSIDE any stream capture: it
+        allocates); key ('skip', ranges...) = [head table, table of everything else]."""
+        tab = self._pack_sub.get(key)
+        if tab is None:
+            if self._pack_table is None:
+                self.pack('p')
+            if key and key[0] == 'skip':
+                rest = [op for op in self._pack_ops[1] if not self._op_in(op, key[1:])]
+                tab = [self._pack_descs(t, self.store.p) for t in (self._pack_ops[0], rest) if t]
+            else:
+                ops = [op for op in self._pack_ops[1] if self._op_in(op, key)]
+                tab = self._pack_descs(ops, self.store.p) if ops else False
+            self._pack_sub[key] = tab
+        return tab
+
+    def _op_in(self, op, ranges):
+        off = (op[1] - self.store.p.data_ptr()) // 4
+        return any(a <= off < b for a, b in ranges)
+
+    def pack(self, which='p', after_head=None, skip_ranges=None):
         """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema'): two launches driven
         by device-resident descriptor tables (built once) -- first the (small) images the front-end needs, the conv
         kernels of all subjects, then everything else; after_head() runs between the two (an event record: the conv GEMM
         of a captured step waits for the first launch only, not for the 80 us of the second)."""
         src = getattr(self.store, which)
+        if skip_ranges:
+            # (a captured train step re-packed these images itself, behind their optimiser update: pack_ranges)
+            tab = self._pack_subtable(('skip',) + tuple(skip_ranges))
+            for i, (dev, n, nblk) in enumerate(tab):
+                lib.e2t_pack_batch(dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
+                if i == 0 and after_head is not None:
+                    after_head()
+            self._packed = None
+            return
+        self._img_early = 'all' if which == 'p' else None      # every image is current (masters): any captured step may follow
         if self._pack_table is None:
             st, s = self.store, self.spec
             base = st.p          # offsets are relative, identical for p and ema
@@ -863,6 +904,7 @@ class Seq2SeqEngine:
                     return 'tr' if (op[2] == 1 and op[3] != 1) else 'cast'
                 ops = [op for op in ops if kind_of(op) == want]
                 head = [op for op in head if kind_of(op) == want]
+            self._pack_ops = (head, ops)
             self._pack_table = [self._pack_descs(t, base) for t in (head, ops) if t]
         for i, (dev, n, nblk) in enumerate(self._pack_table):
             lib.e2t_pack_batch(dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
@@ -1057,7 +1099,7 @@ class Seq2SeqEngine:
         lib.e2t_final_state(lw['Yext'].data_ptr(), last.ldy, lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), B, last.H,
                             ws['dec']['Yext'].data_ptr(), self.dec.ldy, ws['c0'].data_ptr(), st)
 
-    def forward(self, ws, train=True, which=None, with_aux=True, pack_first=False, global_counts=False):
+    def forward(self, ws, train=True, which=None, with_aux=True, pack_first=False, global_counts=False, pack_skip=None):
         """Teacher-forced forward incl. losses and d(logits); leaves everything backward needs in ws.
         global_counts: normalise the losses by the counts in ws['cnt_g'] (set_global_counts: the token / auxiliary-sample
         counts of the batch over ALL ranks) instead of this rank's own, so that the SUM of the ranks' gradients is the
@@ -1123,7 +1165,7 @@ class Seq2SeqEngine:
                     # the operand re-pack of the optimiser step that came before runs here, next to the weight-free
                     # start of the front-end (lengths, im2row) instead of in front of it
                     def pack_side():
-                        self.pack(which or 'p', after_head=lambda: pend.__setitem__('pack_head', self.fork_point()))
+                        self.pack(which or 'p', after_head=lambda: pend.__setitem__('pack_head', self.fork_point()), skip_ranges=pack_skip)
                     pend['pack'] = self.run_side(ev0, pack_side)
                 pend['dec'] = self.run_side(ev0, dec_prep)
 
@@ -1474,6 +1516,7 @@ class Seq2SeqEngine:
             self.pack('p')
         else:
             self._packed = None
+            self._img_early = None
 
     def trainable_ranges(self, sid=None):
         """Contiguous [a,b) element ranges of the flat buffers that receive updates."""
@@ -1562,6 +1605,7 @@ class Seq2SeqEngine:
                 # auxiliary head above the bottom layers) are updated on the side stream under the remaining stages
                 nl = len(self.enc)
                 early_end, early = 0, None
+                packed_early, early_sets = [], []
                 if nl >= 2 and self.overlap and self._ovl == '1' and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
                     # stage i (2 <= i <= nl) queues the weight gradients of layer nl-i+1 on the side stream: behind them,
                     # everything in front of layer nl-i's segment is final
@@ -1571,23 +1615,37 @@ class Seq2SeqEngine:
                         hi = self.store.seg_range('enc%d.Wx' % (nl - i))[0]
                         er = [(max(a, lo), min(b, hi)) for a, b in tr if a < hi and b > lo]
                         if er:
-                            early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
+                            if self.early_pack:
+                                early_sets.append(er)
+                                # ... and their operand images right behind: the layers that read them in THIS step's backward
+                                # pass (BPTT and input gradient of the layers above the one stage i works on) are done
+                                early[i] = (lambda er=er: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))
+                                packed_early += er
+                            else:
+                                early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
                         lo = hi
                     early_end = lo
                     if not early:
                         early, early_end = None, 0
                 g1 = torch.cuda.CUDAGraph()
+                if packed_early:
+                    for er_ in early_sets:                       # descriptor tables are built outside the capture
+                        self._pack_subtable(tuple(er_))
+                    self._pack_subtable(('skip',) + tuple(packed_early))
                 with capture(g1):
-                    self.forward(ws, train=True, pack_first=True)
+                    self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None)
                     self.backward(ws, train=True, early=early)
                     self.adam_step(ws['sid'], repack=False, skip_below=early_end)
-                g = (g1,)
+                g = (g1, tuple(packed_early))
             ws['graph'][key] = g
         # (a replay does not run forward(): an assessment in between may have left the flag off)
         ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
         if not dp:
+            if g[1] and self._img_early != 'all' and self._img_early != g[1]:
+                self.pack('p')           # the graph assumes that the images of ITS early-updated ranges are current
             g[0].replay()
-            self._packed = None          # the images are those of the weights BEFORE this step's update
+            self._packed = None          # the bottom layer's images are those of the weights BEFORE this step's update
+            self._img_early = g[1] if g[1] else None
             return
         cur = torch.cuda.current_stream(self.device)
 
@@ -1641,9 +1699,11 @@ class Seq2SeqEngine:
             sync.wait()                          # (all done: clears the lists)
             lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
             self._packed = None
+            self._img_early = None
             return
         sync.wait()
         g[1].replay()
+        self._img_early = None
         if lazy:
             self._packed = None          # the images are those of the weights BEFORE this step's update
 
