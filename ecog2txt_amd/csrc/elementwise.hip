@@ -656,6 +656,12 @@ __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, floa
     }
 }
 
+// fill of 32-bit words (zeroing the scatter-add target of the embedding gradient, decode-state resets): inside the
+// captured step this replaces the framework's own fill kernels
+__global__ __launch_bounds__(256) void k_fill_u32(unsigned* dst, size_t n, unsigned v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
+}
+
 // ---------------------------------------------------------------------------
 // a2/a3 batch assembly: rows of a partition kept resident in HBM -> the step's batch buffers.  One workgroup column
 // per destination row; idx < 0 (or beyond the list) = padding utterance: the row is zero-filled, which is exactly what
@@ -685,6 +691,13 @@ __global__ __launch_bounds__(256) void k_gather_rows(const unsigned* src, const 
 // ---------------------------------------------------------------------------
 #define ST ((hipStream_t)stream)
 
+extern "C" int e2t_fill_u32(void* dst, size_t n, uint32_t value, void* stream) {
+    E2T_CHECK_ARG(dst || n == 0);
+    if (n == 0) return E2T_OK;
+    size_t blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)dst, n, value);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
 extern "C" int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, void* dst, void* stream) {
     E2T_CHECK_ARG(src && dst && (idx || n == 0) && n >= 0 && rows_out >= n);
     if (rows_out == 0 || row_words == 0) return E2T_OK;

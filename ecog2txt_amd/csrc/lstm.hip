@@ -1522,6 +1522,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
                 if (__any((big & 0x40004000u) != 0u)) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[i] = (x[i] | (((x[i] & 0x40004000u) >> 14) * 0x3FFFu)) & 0xBFFFBFFFu;
+                    if (lane == 0) atomicAdd(pa.err + 8, 1);     // visible to the host: recurrent gate gradients were clipped
                 }
                 const u32x4 v0 = (u32x4){x[0] | PS, x[1] | PS, x[2] | PS, x[3] | PS}, v1 = (u32x4){x[4] | PS, x[5] | PS, x[6] | PS, x[7] | PS};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:256 sc1" :: "v"(hp), "v"(v0), "v"(v1) : "memory");

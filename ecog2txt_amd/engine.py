@@ -41,8 +41,11 @@ def capture(graph):
     gc.collect()
     was = gc.isenabled()
     gc.disable()
+    kw = {}
+    if os.environ.get('E2T_CAPTURE_PRIO'):      # diagnostics: capture on a high-priority stream (do kernel nodes inherit it?)
+        kw['stream'] = torch.cuda.Stream(priority=int(os.environ['E2T_CAPTURE_PRIO']))
     try:
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, **kw):
             yield
     finally:
         if was:
@@ -1375,7 +1378,8 @@ class Seq2SeqEngine:
         """Critical path of the head: gradient through the vocabulary projection, decoder BPTT (-> gradient into the
         encoder's final state and into the embedded tokens)."""
         s, store = self.spec, self.store
-        store.view('dec.emb', store.g).zero_()          # the embedding scatter-add accumulates by atomics
+        a_, b_ = store.seg_range('dec.emb')               # the embedding scatter-add accumulates by atomics
+        lib.e2t_fill_u32(store.g.data_ptr() + 4 * a_, b_ - a_, 0, self.stream)
         dd = self.dec.out_drop(train)
         self.proj.bwd_dx(ws['proj'], ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train, d_in_drop=dd)
         self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
@@ -1724,6 +1728,15 @@ class Seq2SeqEngine:
         raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid, the '
                            'weights were not updated; E2T_PERSISTENT=0 selects the launch-per-step kernels) %r' % (info,))
 
+    def saturation_events(self, reset=True):
+        """How often the persistent BPTT clipped a recurrent gate gradient at |x| >= 2 in its exchange copy since the last
+        call (e2t_lstm_seq_bwd_persistent, err[8]).  0 in healthy training; > 0 means that loss scales / penalties push gate
+        gradients three orders of magnitude above their usual size and the recurrent term of BPTT was clipped."""
+        n = int(self.sync_err[8].item())
+        if reset and n:
+            self.sync_err[8] = 0
+        return n
+
     def losses(self, ws):
         v = ws['loss'].cpu().numpy()
         self.check_sync(ws)
@@ -1744,10 +1757,10 @@ class Seq2SeqEngine:
         max_len = L if max_len is None else min(max_len, L)
         st = self.stream
         self.encode(ws, src, False)
-        ws['done'].zero_()
-        ws['hyp'].fill_(PAD_ID)
-        ws['U'][:B].fill_(EOS_ID)
-        ws['dlens'].fill_(L)
+        lib.e2t_fill_u32(ws['done'].data_ptr(), B, 0, st)
+        lib.e2t_fill_u32(ws['hyp'].data_ptr(), B * L, PAD_ID, st)
+        lib.e2t_fill_u32(ws['U'].data_ptr(), B, EOS_ID, st)
+        lib.e2t_fill_u32(ws['dlens'].data_ptr(), B, L, st)
         dw = ws['dec']
         dr = self._dropout(0.0, STREAM_DEC_EMB)
         pw = ws['proj']

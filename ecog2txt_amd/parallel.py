@@ -119,6 +119,9 @@ class RcclSync:
         self.sum_of_global_means = sum_of_global_means
         comm = C.c_void_p()
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
+        # CUs reserved for the exchange: the persistent recurrences of cfg2 occupy 200 (forward) / 224 (BPTT) of the 256 CUs
+        # for a whole layer sweep, one workgroup each; RCCL's channel kernels (one workgroup per channel) get the other 32
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
         lib.e2t_comm_init(C.byref(comm), rank, world, unique_id, int(device))
         self.comm = comm
         self.pending_ranges = []

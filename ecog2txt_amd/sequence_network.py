@@ -297,6 +297,10 @@ class SequenceNetwork:
                     keys = sorted(lo)
                     lo = dict(zip(keys, sync.allreduce_numpy(np.array([lo[k] for k in keys], np.float32)).tolist()))
                 res['training'].losses.append(lo)
+                nsat = eng.saturation_events()
+                if nsat:
+                    print('WARNING: epoch %d: the persistent BPTT clipped recurrent gate gradients at |x| >= 2 in %d publishes '
+                          '(check the penalty scales; E2T_PERSISTENT=fwd selects the unclipped launch-per-step BPTT)' % (start + epoch, nsat))
         eng.check_sync()                                             # never checkpoint the results of an invalid step
         self._epoch = start + self.N_epochs
         self._save(eng, self._epoch)

@@ -55,6 +55,8 @@ typedef struct e2t_dropout {
 /* ---- a2/a3: batch assembly from a partition kept resident in HBM (role of the tf.data pipeline that feeds net.fit,
  *      trainers.py:896-900): dst row r = src row idx[r] for r < n with idx[r] >= 0, else zeros (a padding utterance:
  *      zero samples = zero length, subjects.py:386-390).  Rows are row_words 32-bit words; idx is a DEVICE array. ---- */
+/* dst[0..n) = value (32-bit words; fp32 0.0 is word 0) */
+int e2t_fill_u32(void* dst, size_t n, uint32_t value, void* stream);
 int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, void* dst, void* stream);
 
 /* ---- a4: nn.sequences_tools (trainers.py:789-790, 806-807) ---- */
@@ -195,7 +197,8 @@ int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg
  * once by the caller; flags: uint32 [clusters*stride] with clusters*stride = ceil(B/16)*ndir*32 (H <= 416) or
  * ceil(B/32)*ndir*128 (only the last word of each cluster's row is used: the stamps its buffers were left with), both
  * zero-filled once by the caller and afterwards only touched by this entry point with the same S, B, H (zero them again
- * after an error); err as for the forward. */
+ * after an error); err as for the forward; additionally err[8] counts the publishes in which a gate gradient reached the
+ * saturating range of the exchange copy (|x| >= 2): 0 in healthy training, a warning sign for the loss scales otherwise. */
 int e2t_bwd_persist_kq(int H);
 int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
                                 const float* Gs, const float* Cs, const int32_t* lens, const float* c0,

@@ -326,6 +326,9 @@ def test_persistent_bptt_saturates_huge_gate_gradients_without_stalling(monkeypa
             eng.backward(ws, train=True)
         torch.cuda.synchronize()
         assert int(eng.sync_err[0].item()) == 0
+        # ... and the host can see that it happened (err[8]); the launch-per-step path never clips
+        assert (eng.saturation_events() > 0) == (flag == '1')
+        assert eng.saturation_events() == 0
         outs[flag] = (ws['enc'][0]['dG'].float().cpu().numpy(), ws['dec']['dG'].float().cpu().numpy())
     for a, b in zip(outs['0'], outs['1']):
         assert np.isfinite(b).all()
