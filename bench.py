@@ -126,7 +126,8 @@ def cpu_baseline(spec_kw, B, T, L, warmup=3, timed=10):
                        % (B, T, warmup, len(ts), med, min(ts), max(ts), cpu, os.cpu_count() or 0))
 
 
-GEMM_KERNELS = {'tn128': 'k_gemm_nt<128,128,2,2,true,true> (K-major operands: weight gradients)',
+GEMM_KERNELS = {'tn256': 'k_gemm_nt<256,256,2,4,false,true> (K-major operands, both output dimensions >= 1024)',
+                'tn128': 'k_gemm_nt<128,128,2,2,true,true> (K-major operands: weight gradients)',
                 'nt128': 'k_gemm_nt<128,128,2,2,true,false> (K-contiguous, full epilogue)',
                 'nt256': 'k_gemm_nt<256,256,2,4,false,false> (K-contiguous, large plain products)'}
 
@@ -253,7 +254,7 @@ def main():
                 traffic = json.load(f)
         except Exception:
             pass
-        for inst in ('tn128', 'nt128', 'nt256'):
+        for inst in ('tn128', 'tn256', 'nt128', 'nt256'):
             recs = [r for r in log if r['inst'] == inst]
             if not recs:
                 continue

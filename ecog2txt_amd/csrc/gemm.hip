@@ -566,6 +566,12 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool rich = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
     bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 64;
+    // K-major products with both output dimensions large (cfg4's weight gradients: 2049 x 8192, 1024 x 4096 x 2): 256 x 256 tiles
+    // halve the bytes staged per flop; E2T_TN256=0 keeps the 128 x 128 instance
+    static const bool tn256_ok = [] { const char* e = getenv("E2T_TN256"); return !(e && atoi(e) == 0); }();
+    const int nbatch = (ep && ep->batch > 1) ? ep->batch : 1;
+    const bool big_tn = tn && tn256_ok && kt == 64 && !rich && have_ws && M >= 1024 && N >= 1024 && t256 * nbatch >= 64 && forced != 128;
+    if (big_tn) big = true;
     if (forced == 128) big = false;
     if (forced == 256 && !tn && !want_split && !rich) big = true;
     GemmPlan pl;
@@ -577,7 +583,17 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
         const int ntm = (M + pl.tile - 1) / pl.tile, ntn = (N + pl.tile - 1) / pl.tile;
         const int tiles = ntm * ntn * pl.batch;
         const int slots = (tn && kt == 32) ? 1024 : 512;
-        int s = slots / tiles;                         // fill, but never exceed, the 2 (4) x 256 resident workgroups: one block
+        int s = slots / tiles;
+        if (big) {
+            // one 256 x 256 workgroup per CU: the split count that fills the last round best, smallest on ties
+            double bu = 0.0;
+            s = 1;
+            for (int c = 1; c <= 8 && (c == 1 || nfull / c >= 16); ++c) {
+                const long w = (long)tiles * c;
+                const double u = (double)w / (double)(((w + 255) / 256) * 256);
+                if (u > bu + 0.02) { bu = u; s = c; }
+            }
+        }                         // fill, but never exceed, the 2 (4) x 256 resident workgroups: one block
                                                        // too many costs a whole second round (175 x 3 = 525 -> 175 x 2)
         if (s > nfull * kt / 1024) s = nfull * kt / 1024;   // keep >= 16 K tiles (of 64) per split: a workgroup's fixed cost (DMA fill, slab
                                                        // store, its share of the reduction) is worth ~8 of them (measured on the
@@ -629,8 +645,11 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     if (pl.splits > 1 || pl.want_split) { p.splits = pl.splits; p.slab = (float*)ep->splitk_ws; }
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
-    if (attr_rc != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); return E2T_ERR_HIP; }
-    if (tn && tn_stage_depth() == 32) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 32>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 4 * 16, (hipStream_t)stream, p);
+    static const hipError_t attr_rc2 = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, true>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
+    if (attr_rc != hipSuccess || attr_rc2 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc != hipSuccess ? attr_rc : attr_rc2)); return E2T_ERR_HIP; }
+    if (big && tn) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, true>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
+    else if (tn && tn_stage_depth() == 32) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 32>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 4 * 16, (hipStream_t)stream, p);
     else if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);

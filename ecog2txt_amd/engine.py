@@ -795,7 +795,7 @@ class Seq2SeqEngine:
             lib.e2t_gemm_plan(int(tn), M, N, K, C.byref(ep), C.byref(tile), C.byref(splits))
             am, an, ak = alg or (M, N, K)
             nb = batch[0] if batch is not None else 1
-            self._gemm_log.append(dict(inst=('tn128' if tn else 'nt%d' % tile.value), M=M, N=N, K=K, batch=nb, splits=splits.value,
+            self._gemm_log.append(dict(inst=('tn%d' % tile.value if tn else 'nt%d' % tile.value), M=M, N=N, K=K, batch=nb, splits=splits.value,
                                        flops=2 * am * an * ak * nb, out_bytes=(2 if out_bf16 else 4) * am * an * nb,
                                        in_bytes=2 * (am * ak + an * ak) * nb, side=self._on_side,
                                        call=(A, lda, B, ldb, Cp, ldc, M, N, K), ep=ep, tn=tn))

@@ -467,3 +467,30 @@ def test_fused_conv_forward_matches_pack_plus_gemm(hl, C_, F, N, T, B):
     np.testing.assert_allclose(got[:, :F], want, rtol=1e-2, atol=1e-2)          # bf16 output: one ulp where fp32 vs fp64 sums straddle
     assert (got[:, F:] == 7.0).all()                                              # padding columns untouched (the ones column lives there)
     assert np.abs(got[:, :F] - want).mean() < 2e-4
+
+
+@pytest.mark.parametrize('M,N,K,nb', [(2049, 2050, 1100, 1), (1024, 2304, 2100, 2)])
+def test_gemm_tn_256_tile_instance(hl, M, N, K, nb):
+    """The 256 x 256 K-major instance (both output dimensions >= 1024: cfg4's weight gradients), ragged edges, split-K
+    slabs + reduction, batched: against NumPy on the bf16-rounded operands."""
+    rng = np.random.default_rng(M + N + K)
+    lda, ldb = nb * r8(M) + 8, nb * r8(N)
+    A = rng.standard_normal((K, lda)); Bm = rng.standard_normal((K, ldb))
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    wsb = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue(); ep.alpha = 1.0
+    ep.flags = hl.GEMM_SPLITK
+    ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    if nb > 1:
+        ep.batch, ep.a_batch_stride, ep.b_batch_stride, ep.c_batch_stride = nb, r8(M), r8(N), M * r8(N)
+    tile, splits = C.c_int(0), C.c_int(0)
+    hl.lib.e2t_gemm_plan(1, M, N, K, C.byref(ep), C.byref(tile), C.byref(splits))
+    assert tile.value == 256, 'case must exercise the 256 x 256 K-major instance'
+    c = torch.full((nb, M, r8(N)), 7.0, dtype=torch.float32, device='cuda')
+    hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), r8(N), M, N, K, C.byref(ep), st())
+    torch.cuda.synchronize()
+    got = host(c)
+    for z in range(nb):
+        want = round_bf16(A[:, z * r8(M):z * r8(M) + M]).T @ round_bf16(Bm[:, z * r8(N):z * r8(N) + N])
+        np.testing.assert_allclose(got[z][:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+        assert np.all(got[z][:, N:] == 7.0)
