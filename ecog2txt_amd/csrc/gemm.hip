@@ -132,7 +132,7 @@ extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
 // KT = K depth of a stage (64; 32 for the K-major instance with 4 workgroups per CU: a K tile costs ~0.8 us of LDS-DMA
 // issue + wait + barrier whether one or two workgroups share the CU, so the K-major products -- whose k-rows are full
 // 256-B lines at any depth -- trade pipeline depth for occupancy: 32 KiB of LDS and <= 128 registers per workgroup)
-template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64>
+template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64, bool RS = false>
 __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 4 : 2) : 1) void k_gemm_nt(GemmArgs p_in) {
     const GemmArgs p = gemm_batch_view(p_in, blockIdx.z);
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
     auto tn_swz = [](int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); };
     // one DMA instruction (1 KiB) of tile t into stage buf: pieces 0..IA-1 belong to the A tile, IA..IA+IB-1 to the B tile
     constexpr int NP = IA + IB;
-    auto issue_piece = [&](int t, int buf, int pc_) {
+    // source address of this lane's 16 B of piece pc_ of tile t, and the LDS unit its wave-instruction starts at
+    auto piece_addr = [&](int t, int buf, int pc_, const bf16_t*& src, uint4*& dst) {
         const int k0 = t * KT;
         uint4* sa = smem + buf * STAGE;
         uint4* sb = sa + BM * (KT / 8);
@@ -199,14 +200,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
                 const int rb = (wave * IA + i) * RA, r = rb + lane / CA, pc = lane % CA;
                 const int c = pc ^ (tn_swz(r) & (CA - 1));
                 const int gm = min(m0 + c * 8, (p.M - 1) & ~7);    // 8-column chunks; lda % 8 == 0 keeps them in the row
-                const bf16_t* src = (k0 + r < p.K) ? p.A + (size_t)(k0 + r) * p.lda + gm : g_gemm_zero_page;
-                dma16_to_lds(src, lds_addr_of(sa + rb * CA));
+                src = (k0 + r < p.K) ? p.A + (size_t)(k0 + r) * p.lda + gm : g_gemm_zero_page;
+                dst = sa + rb * CA;
             } else {
                 const int rb = (wave * IB + i) * RB_, r = rb + lane / CB, pc = lane % CB;
                 const int c = pc ^ (tn_swz(r) & (CB - 1));
                 const int gn = min(n0 + c * 8, (p.N - 1) & ~7);
-                const bf16_t* src = (k0 + r < p.K) ? p.B + (size_t)(k0 + r) * p.ldb + gn : g_gemm_zero_page;
-                dma16_to_lds(src, lds_addr_of(sb + rb * CB));
+                src = (k0 + r < p.K) ? p.B + (size_t)(k0 + r) * p.ldb + gn : g_gemm_zero_page;
+                dst = sb + rb * CB;
             }
             return;
         }
@@ -214,14 +215,34 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
             const int rb = (wave * IA + i) * 8;
             const int r = rb + drow;
             const int gm = min(m0 + r, p.M - 1);
-            dma16_to_lds(p.A + (size_t)gm * p.lda + k0 + (dpc ^ (r & 7)) * 8, lds_addr_of(sa + rb * 8));
+            src = p.A + (size_t)gm * p.lda + k0 + (dpc ^ (r & 7)) * 8;
+            dst = sa + rb * 8;
         } else {
             const int rb = (wave * IB + i) * 8;
             const int r = rb + drow;
             const int gn = min(n0 + r, p.N - 1);
-            dma16_to_lds(p.B + (size_t)gn * p.ldb + k0 + (dpc ^ (r & 7)) * 8, lds_addr_of(sb + rb * 8));
+            src = p.B + (size_t)gn * p.ldb + k0 + (dpc ^ (r & 7)) * 8;
+            dst = sb + rb * 8;
         }
     };
+    auto issue_piece = [&](int t, int buf, int pc_) {
+        const bf16_t* src; uint4* dst;
+        piece_addr(t, buf, pc_, src, dst);
+        dma16_to_lds(src, lds_addr_of(dst));
+    };
+    // RS (register staging): the same 1-KiB pieces go through registers -- a global_load_dwordx4 (a few issue cycles) now, a
+    // ds_write_b128 (~13) after the current tile's MFMAs -- instead of an LDS-DMA instruction each (60-180 issue cycles with
+    // its M0 set-up: 8 of them per K tile were ~1000 cycles of a wave's in-order issue stream against ~550 of MFMA)
+    // eight named registers, spelled out (NP == 8 for the 128 x 128 instances): as an array -- behind a lambda capture or a
+    // rolled loop -- hipcc gives the staging registers a home in scratch memory
+    static_assert(!RS || NP == 8, "register staging is written for 8 pieces per wave");
+    uint4 stg0, stg1, stg2, stg3, stg4, stg5, stg6, stg7;
+#define E2T_RS_ONE_LOAD(T_, BUF_, Q_) { const bf16_t* src_; uint4* dst_; piece_addr((T_), (BUF_), Q_, src_, dst_); stg##Q_ = *(const uint4*)src_; }
+#define E2T_RS_ONE_STORE(T_, BUF_, Q_) { const bf16_t* src_; uint4* dst_; piece_addr((T_), (BUF_), Q_, src_, dst_); dst_[lane] = stg##Q_; }
+#define E2T_RS_LOAD(T_, BUF_) E2T_RS_ONE_LOAD(T_, BUF_, 0) E2T_RS_ONE_LOAD(T_, BUF_, 1) E2T_RS_ONE_LOAD(T_, BUF_, 2) E2T_RS_ONE_LOAD(T_, BUF_, 3) \
+                              E2T_RS_ONE_LOAD(T_, BUF_, 4) E2T_RS_ONE_LOAD(T_, BUF_, 5) E2T_RS_ONE_LOAD(T_, BUF_, 6) E2T_RS_ONE_LOAD(T_, BUF_, 7)
+#define E2T_RS_STORE(T_, BUF_) E2T_RS_ONE_STORE(T_, BUF_, 0) E2T_RS_ONE_STORE(T_, BUF_, 1) E2T_RS_ONE_STORE(T_, BUF_, 2) E2T_RS_ONE_STORE(T_, BUF_, 3) \
+                               E2T_RS_ONE_STORE(T_, BUF_, 4) E2T_RS_ONE_STORE(T_, BUF_, 5) E2T_RS_ONE_STORE(T_, BUF_, 6) E2T_RS_ONE_STORE(T_, BUF_, 7)
     auto issue = [&](int t, int buf) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) issue_piece(t, buf, q);
@@ -304,6 +325,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
     };
 
     int cur = 0;
+    if (RS) {
+        if (t0 < t1) { E2T_RS_LOAD(t0, 0) E2T_RS_STORE(t0, 0) }
+        __syncthreads();
+        for (int t = t0; t < t1; ++t) {
+            if (t + 1 < t1) { E2T_RS_LOAD(t + 1, cur ^ 1) }     // in flight while tile t is multiplied
+            compute(cur, -1);
+            if (t + 1 < t1) { E2T_RS_STORE(t + 1, cur ^ 1) }    // the other stage: everybody left it at the last barrier
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
     if (t0 < t1) issue(t0, 0);
     for (int t = t0; t < t1; ++t) {
         dma_wait_all();                                        // tile t has landed (only tile t is in flight here)
@@ -314,6 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
         if (!INTERLEAVE && t + 1 < t1) issue(t + 1, cur ^ 1);
         compute(cur, (INTERLEAVE && t + 1 < t1) ? t + 1 : -1);
         cur ^= 1;
+    }
     }
     if (my_tail) {
         // register-staged, zero-filled K tail into the same swizzled image
@@ -544,6 +577,11 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
 }
 
 struct GemmPlan { int tile, splits, batch; bool want_split; };
+// operand staging of the 128 x 128 instances: registers (E2T_GEMM_RS=1) or LDS-DMA
+static bool gemm_rs() {
+    static const bool rs = [] { const char* e = getenv("E2T_GEMM_RS"); return e && atoi(e) == 1; }();
+    return rs;
+}
 // stage depth of the K-major instance: 64; E2T_TN_KT=32 selects the 4-workgroups-per-CU variant (diagnostics -- measured:
 // dW_x 801 x 3200 x 8704 88-92 us vs 93, batched dW_h 63 vs 56, whole step 1.94 vs 1.87 ms: more occupancy does not help, the
 // instance is bound by the bytes a CU can pull into LDS per flop, not by latency)
@@ -650,8 +688,10 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     if (attr_rc != hipSuccess || attr_rc2 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc != hipSuccess ? attr_rc : attr_rc2)); return E2T_ERR_HIP; }
     if (big && tn) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, true>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
     else if (tn && tn_stage_depth() == 32) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 32>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 4 * 16, (hipStream_t)stream, p);
+    else if (tn && gemm_rs()) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 64, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     else if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
+    else if (gemm_rs()) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false, 64, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
     if (p.splits > 1) {
         const size_t n = (size_t)M * ((N + 3) / 4);
