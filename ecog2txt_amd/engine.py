@@ -84,6 +84,9 @@ class NetSpec:
     aux_dim: int = 13
     aux_dist: str = 'Gaussian'
     aux_scale: float = 1.0
+    # further auxiliary heads (one per additional 'encoder_<k>_targets' data key, trainers.py:94-102): dicts with layer,
+    # hidden, dim, dist, scale -- a simple path on the main stream; the first head keeps the overlapped schedule
+    aux_extra: List[dict] = field(default_factory=list)
     dec_scale: float = 1.0
     ff_dropout: float = 0.1
     rnn_dropout: float = 0.5
@@ -142,6 +145,14 @@ class ParamStore:
                         add('aux%d.WT' % i, asz[i + 1], asz[i]); add('aux%d.b' % i, asz[i + 1])
                     else:
                         add('aux%d.W' % i, asz[i] + 1, asz[i + 1])
+            for j, hx in enumerate(spec.aux_extra):
+                if hx['layer'] == l:
+                    asz = [2 * Hh] + list(hx.get('hidden', [])) + [hx['dim']]
+                    for i in range(len(asz) - 2, -1, -1):
+                        if i == len(asz) - 2:
+                            add('auxx%d_%d.WT' % (j, i), asz[i + 1], asz[i]); add('auxx%d_%d.b' % (j, i), asz[i + 1])
+                        else:
+                            add('auxx%d_%d.W' % (j, i), asz[i] + 1, asz[i + 1])
             D = spec.enc_embed if l == 0 else 2 * spec.enc_rnn[l - 1]
             add('enc%d.Wx' % l, D + 1, 2 * 4 * Hh)
             add('enc%d.Wh' % l, 2, Hh, 4 * Hh)
@@ -199,6 +210,9 @@ class ParamStore:
                 put('enc%d.Wh' % l, np.stack(wh, 0))
             self._ff_io(P, 'aux', 'encoder_%s_projection' % s.aux_layer,
                         None if s.aux_layer is None else [2 * s.enc_rnn[s.aux_layer]] + list(s.aux_hidden) + [s.aux_dim], put)
+            for j, hx in enumerate(s.aux_extra):
+                self._ff_io(P, 'auxx%d_' % j, 'encoder_%s_projection' % hx['layer'],
+                            [2 * s.enc_rnn[hx['layer']]] + list(hx.get('hidden', [])) + [hx['dim']], put)
             put('dec.emb', P['seq2seq/decoder_embedding_%d_%d_0/weights' % (s.vocab, s.dec_embed)])
             K = P['seq2seq/decoder_rnn/cell_0/kernel']
             b = P['seq2seq/decoder_rnn/cell_0/bias']
@@ -244,6 +258,9 @@ class ParamStore:
         if s.aux_layer is not None:
             self._ff_out(out, get, 'aux', 'encoder_%s_projection' % s.aux_layer,
                          [2 * s.enc_rnn[s.aux_layer]] + list(s.aux_hidden) + [s.aux_dim])
+        for j, hx in enumerate(s.aux_extra):
+            self._ff_out(out, get, 'auxx%d_' % j, 'encoder_%s_projection' % hx['layer'],
+                         [2 * s.enc_rnn[hx['layer']]] + list(hx.get('hidden', [])) + [hx['dim']])
         out['seq2seq/decoder_embedding_%d_%d_0/weights' % (s.vocab, s.dec_embed)] = get('dec.emb').copy()
         wx, wh = get('dec.Wx'), get('dec.Wh')
         out['seq2seq/decoder_rnn/cell_0/kernel'] = np.concatenate(
@@ -695,6 +712,12 @@ class Seq2SeqEngine:
             Hk = s.enc_rnn[s.aux_layer]
             self.aux = _FFStack(self, 'aux', [2 * Hk] + list(s.aux_hidden) + [s.aux_dim],
                                 [(0, Hk, 0), (Hk, Hk, r8(Hk))], rk(2 * r8(Hk) + 1), STREAM_AUX)
+        self.aux_x = []
+        for j, hx in enumerate(s.aux_extra):
+            assert hx['layer'] != s.aux_layer and 0 <= hx['layer'] < len(s.enc_rnn), 'one auxiliary head per encoder layer'
+            Hk = s.enc_rnn[hx['layer']]
+            self.aux_x.append(_FFStack(self, 'auxx%d_' % j, [2 * Hk] + list(hx.get('hidden', [])) + [hx['dim']],
+                                       [(0, Hk, 0), (Hk, Hk, r8(Hk))], rk(2 * r8(Hk) + 1), STREAM_AUX + 4 * (j + 1)))
         self.E8 = rk(s.dec_embed)
         self.emb = _bf(s.vocab, self.E8, device=dev)
         self.dec = _Lstm(self, 'dec', 1, s.dec_embed, [(0, s.dec_embed, 0)], self.E8, s.dec_rnn, STREAM_DEC_OUT)
@@ -709,6 +732,8 @@ class Seq2SeqEngine:
         if self.aux:
             k = s.aux_layer
             self.aux.ones_col_set = self.enc[k].ldy > 2 * self.enc[k].H8
+        for ax, hx in zip(self.aux_x, s.aux_extra):
+            ax.ones_col_set = self.enc[hx['layer']].ldy > 2 * self.enc[hx['layer']].H8
         self._pack_table = None
         self._pack_ops, self._pack_sub = None, {}
         self._img_early = None        # 'all' after a full pack of the masters, else the ranges the last replay re-packed itself
@@ -896,6 +921,8 @@ class Seq2SeqEngine:
                 lay.pack_ops(ops, base)
             if self.aux:
                 self.aux.pack_ops(ops, base)
+            for ax in self.aux_x:
+                ax.pack_ops(ops, base)
             ops.append(('cast', st.ptr('dec.emb', base), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
             self.dec.pack_ops(ops, base)
             self.proj.pack_ops(ops, base)
@@ -998,7 +1025,15 @@ class Seq2SeqEngine:
         Md = L * B
         ws['Md'] = Md
         ws['dlens'], ws['ntok'] = _i32(B, device=dev), _i32(1, device=dev)
-        ws['cnt_g'] = _i32(2, device=dev)         # data parallel: GLOBAL (all ranks) token / aux-sample counts of the batch
+        ws['cnt_g'] = _i32(2 + len(self.aux_x), device=dev)     # data parallel: GLOBAL (all ranks) token / aux-sample counts of the batch
+        ws['auxx'] = []
+        for ax, hx in zip(self.aux_x, s.aux_extra):
+            cat = hx.get('dist', 'Gaussian') == 'categorical'
+            ws['auxx'].append(dict(
+                T=(_i32(B, T, device=dev) if cat else _f32(B, T, hx['dim'], device=dev)), tlens=_i32(B, device=dev),
+                tlens_d=_i32(B, device=dev), nval=_i32(1, device=dev),
+                At=(_i32(M, device=dev) if cat else _f32(M, hx['dim'], device=dev)), ff=ax.alloc(M),
+                dP=_bf(M, rk(hx['dim']), device=dev), rowloss=_f32(M, device=dev), loss=_f32(1, device=dev), cat=cat))
         ws['U'], ws['Tg'] = _i32(Md, device=dev), _i32(Md, device=dev)
         ws['e'] = _bf(Md, self.E8, device=dev)
         if self.E8 > s.dec_embed:
@@ -1036,14 +1071,17 @@ class Seq2SeqEngine:
         ws['Y'].copy_(torch.as_tensor(np.asarray(batch['decoder_targets']), dtype=torch.int32))
         if self.aux and 'encoder_targets' in batch:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
+        for wx, tg in zip(ws['auxx'], batch.get('encoder_targets_extra') or []):
+            wx['T'].copy_(torch.as_tensor(np.asarray(tg), dtype=wx['T'].dtype))
 
-    def set_global_counts(self, ws, ntok, nval=0):
-        """Data parallel: the batch's token count and auxiliary-sample count over ALL ranks (host integers; every rank
+    def set_global_counts(self, ws, ntok, nval=0, nval_extra=()):
+        """Data parallel: the batch's token count and auxiliary-sample count(s) over ALL ranks (host integers; every rank
         holds the targets of the whole global batch, or sums its own counts over the ranks once)."""
-        ws['cnt_g'].copy_(torch.tensor([max(int(ntok), 1), max(int(nval), 1)], dtype=torch.int32))
+        extra = [max(int(v), 1) for v in nval_extra] + [1] * (len(self.aux_x) - len(nval_extra))
+        ws['cnt_g'].copy_(torch.tensor([max(int(ntok), 1), max(int(nval), 1)] + extra, dtype=torch.int32))
         ws['global_counts'] = True
 
-    def local_counts(self, batch_Y, batch_A=None):
+    def local_counts(self, batch_Y, batch_A=None, extra=()):
         """(tokens, auxiliary samples) this rank's slice contributes, counted on the host exactly as the kernels do:
         non-pad target tokens; ceil(valid target length / decimation) per utterance (non-zero rows / non-pad ids)."""
         Y = np.asarray(batch_Y)
@@ -1053,6 +1091,13 @@ class Seq2SeqEngine:
             A = np.asarray(batch_A)
             tl = (A != PAD_ID).sum(1) if A.ndim == 2 else (np.abs(A).max(axis=2) > 0).sum(1)
             nval = int((-(-tl // self.spec.decimation)).sum())
+        if extra:
+            nx = []
+            for A in extra:
+                A = np.asarray(A)
+                tl = (A != PAD_ID).sum(1) if A.ndim == 2 else (np.abs(A).max(axis=2) > 0).sum(1)
+                nx.append(int((-(-tl // self.spec.decimation)).sum()))
+            return ntok, nval, nx
         return ntok, nval
 
     # ------------------------------------------------------------------ forward
@@ -1199,6 +1244,29 @@ class Seq2SeqEngine:
         self.encode(ws, src, train, after_layer, after_first, after_gx, before_weights, before_enc)
         if 'aux_ev' in pend:
             joins.append(self.run_side(pend.pop('aux_ev'), aux_forward))
+        for j, (ax, hx, wx) in enumerate(zip(self.aux_x, s.aux_extra, ws['auxx'])):
+            wx['use'] = bool(with_aux and hx.get('scale', 1.0) != 0.0)
+            if not wx['use']:
+                continue
+            # further auxiliary heads: targets (lengths, reversal, decimation), stack, loss + d(output) -- on the main stream
+            if wx['cat']:
+                lib.e2t_seq_lengths_i32(wx['T'].data_ptr(), B, T, PAD_ID, N, wx['tlens'].data_ptr(), wx['tlens_d'].data_ptr(), st)
+                lib.e2t_gather_rev_decim_i32(wx['T'].data_ptr(), wx['tlens'].data_ptr(), B, T, N, wx['At'].data_ptr(), st)
+            else:
+                lib.e2t_seq_lengths_f32(wx['T'].data_ptr(), B, T, hx['dim'], N, wx['tlens'].data_ptr(), wx['tlens_d'].data_ptr(), st)
+                lib.e2t_gather_rev_decim_f32(wx['T'].data_ptr(), wx['tlens'].data_ptr(), B, T, hx['dim'], N, wx['At'].data_ptr(), st)
+            lib.e2t_sum_i32(wx['tlens_d'].data_ptr(), B, wx['nval'].data_ptr(), st)
+            nvp = (ws['cnt_g'].data_ptr() + 4 * (2 + j)) if global_counts else wx['nval'].data_ptr()
+            out = ax.fwd(wx['ff'], ws['enc'][hx['layer']]['Ydrop'].data_ptr(), src, train)
+            sc = float(hx.get('scale', 1.0))
+            if wx['cat']:
+                lib.e2t_softmax_ce(out.data_ptr(), hx['dim'], M, hx['dim'], wx['At'].data_ptr(), wx['tlens_d'].data_ptr(), B, nvp, sc,
+                                   wx['rowloss'].data_ptr(), None, None, wx['dP'].data_ptr(), rk(hx['dim']), st)
+                lib.e2t_sum_f32(wx['rowloss'].data_ptr(), M, nvp, 1.0, wx['loss'].data_ptr(), st)
+            else:
+                lib.e2t_mse(out.data_ptr(), hx['dim'], wx['At'].data_ptr(), M, hx['dim'], wx['tlens_d'].data_ptr(), B, nvp, sc,
+                            wx['rowloss'].data_ptr(), wx['dP'].data_ptr(), rk(hx['dim']), st)
+                lib.e2t_sum_f32(wx['rowloss'].data_ptr(), M, nvp, 1.0 / hx['dim'], wx['loss'].data_ptr(), st)
         jdec = pend.get('dec')
         if ws['use_aux'] and not ahead:
             aux_targets()
@@ -1409,7 +1477,12 @@ class Seq2SeqEngine:
         dY = ws['dY'][l].data_ptr() if have_dy[l] else None
         fin = dict(dh_final=ws['dh0'], dc_final=ws['dc0']) if l == nl - 1 else {}
         aj = ws.get('_aux_join')
-        if aj is not None and s.aux_layer is not None and (l == s.aux_layer or l == s.aux_layer + 1):
+        if aj is not None and self.aux_x:
+            # further heads tap other layers: their share of dY must be complete before ANY layer's BPTT or input gradient
+            # touches it -- joined once, in front of the top layer
+            ws['_aux_join'] = None
+            self.join_side(aj)
+        elif aj is not None and s.aux_layer is not None and (l == s.aux_layer or l == s.aux_layer + 1):
             # the auxiliary head's backward runs on the side stream since the start of the backward pass; it writes
             # dY[aux_layer], which this layer's input gradient accumulates onto (l = aux_layer + 1) or whose BPTT reads
             # (l = aux_layer, when the head taps the top layer)
@@ -1430,13 +1503,20 @@ class Seq2SeqEngine:
 
     def _bwd_aux(self, ws, train):
         s = self.spec
-        if not ws['use_aux']:
-            return
-        l = s.aux_layer
-        lay, lw = self.enc[l], ws['enc'][l]
-        self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train,
-                     d_in_drop=lay.out_drop(train))
-        ws['have_dy'][l] = True
+        if ws['use_aux']:
+            l = s.aux_layer
+            lay, lw = self.enc[l], ws['enc'][l]
+            self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train,
+                         d_in_drop=lay.out_drop(train))
+            ws['have_dy'][l] = True
+        for ax, hx, wx in zip(self.aux_x, s.aux_extra, ws['auxx']):
+            if not wx.get('use'):
+                continue
+            l = hx['layer']
+            lay, lw = self.enc[l], ws['enc'][l]
+            ax.bwd(wx['ff'], lw['Ydrop'].data_ptr(), wx['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train,
+                   d_in_drop=lay.out_drop(train))
+            ws['have_dy'][l] = True
 
     def _bwd_enc_weights(self, ws, l, part=None):
         """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end).
@@ -1644,6 +1724,8 @@ class Seq2SeqEngine:
             ws['graph'][key] = g
         # (a replay does not run forward(): an assessment in between may have left the flag off)
         ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
+        for hx, wx in zip(self.spec.aux_extra, ws['auxx']):
+            wx['use'] = hx.get('scale', 1.0) != 0.0
         if not dp:
             if g[1] and self._img_early != 'all' and self._img_early != g[1]:
                 self.pack('p')           # the graph assumes that the images of ITS early-updated ranges are current
@@ -1744,6 +1826,10 @@ class Seq2SeqEngine:
         if ws.get('use_aux'):
             out['aux'] = float(v[1])
         out['total'] = self.spec.dec_scale * out['decoder'] + self.spec.aux_scale * out.get('aux', 0.0)
+        for j, (hx, wx) in enumerate(zip(self.spec.aux_extra, ws.get('auxx', []))):
+            if wx.get('use'):
+                out['aux_x%d' % j] = float(wx['loss'].item())
+                out['total'] += float(hx.get('scale', 1.0)) * out['aux_x%d' % j]
         return out
 
     # ------------------------------------------------------------------ decode

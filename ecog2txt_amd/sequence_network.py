@@ -92,23 +92,28 @@ class SequenceNetwork:
         ls = self.layer_sizes
         last = subjects[-1]
         dms = last.data_manifests
-        aux_keys = [k for k in dms if re.fullmatch(r'encoder_\d+_targets', k)]
-        assert len(aux_keys) <= 1, 'one auxiliary encoder target is supported'
-        kw = {}
-        if aux_keys:
-            k = aux_keys[0]
+        # every 'encoder_<k>_targets' data key is an auxiliary head on encoder layer k (trainers.py:94-102, 786-799); the
+        # first one runs on the overlapped schedule, further ones on the main stream
+        aux_keys = sorted((k for k in dms if re.fullmatch(r'encoder_\d+_targets', k) and dms[k].num_features),
+                          key=lambda k: int(k.split('_')[1]))
+        self._aux_keys = aux_keys
+        kw = dict(aux_layer=None)
+        extra = []
+        for n_, k in enumerate(aux_keys):
             layer = int(k.split('_')[1])
             dm = dms[k]
             dist = 'Gaussian' if dm.distribution == 'Gaussian' else 'categorical'
-            kw.update(aux_layer=layer, aux_hidden=list(ls.get('encoder_%d_projection' % layer, [])),
-                      aux_dim=int(dm.num_features), aux_dist=dist, aux_scale=float(dm.penalty_scale))
-            if not dm.num_features:
-                kw.update(aux_layer=None)
-        else:
-            kw.update(aux_layer=None)
+            hidden = list(ls.get('encoder_%d_projection' % layer, []))
+            if n_ == 0:
+                kw.update(aux_layer=layer, aux_hidden=hidden, aux_dim=int(dm.num_features), aux_dist=dist, aux_scale=float(dm.penalty_scale))
+            else:
+                extra.append(dict(layer=layer, hidden=hidden, dim=int(dm.num_features), dist=dist, scale=float(dm.penalty_scale)))
+        kw['aux_extra'] = extra
         N = {int(s.decimation_factor) if self.TEMPORALLY_CONVOLVE else 1 for s in subjects}
         assert len(N) == 1, 'all subjects must share one decimation factor'
-        assert len(ls['encoder_embedding']) == 1 and len(ls['decoder_embedding']) == 1 and len(ls['decoder_rnn']) == 1
+        assert len(ls['encoder_embedding']) == 1, ('a multi-layer temporal-convolution front-end is not built: how the reference splits '
+                                                   'decimation_factor over its layers is not in its tree (DESIGN.md section 7)')
+        assert len(ls['decoder_embedding']) == 1 and len(ls['decoder_rnn']) == 1, 'one decoder embedding / RNN layer'
         return NetSpec(channels={s.subnet_id: int(s.data_manifests['encoder_inputs'].num_features) for s in subjects},
                        decimation=N.pop(), enc_embed=ls['encoder_embedding'][0], enc_rnn=list(ls['encoder_rnn']),
                        dec_embed=ls['decoder_embedding'][0], dec_rnn=ls['decoder_rnn'][0],
@@ -143,30 +148,31 @@ class SequenceNetwork:
         C = ex[0]['encoder_inputs'].shape[1]
         X = np.zeros((n, T, C), np.float32)
         Y = np.zeros((n, L), np.int32)
-        aux_key = next((k for k in ex[0] if re.fullmatch(r'encoder_\d+_targets', k)), None)
-        A = None
-        if aux_key is not None and self._engine.aux is not None:
-            a0 = np.asarray(ex[0][aux_key])
-            A = np.zeros((n, T) + a0.shape[1:], np.float32 if a0.dtype.kind == 'f' else np.int32)
+        aux_keys = [k for k in getattr(self, '_aux_keys', []) if k in ex[0]] if self._engine.aux is not None else []
+        As = []
+        for k in aux_keys:
+            a0 = np.asarray(ex[0][k])
+            As.append(np.zeros((n, T) + a0.shape[1:], np.float32 if a0.dtype.kind == 'f' else np.int32))
         for i, e in enumerate(ex):
             x = e['encoder_inputs']
             X[i, :x.shape[0]] = x
             y = np.asarray(e['decoder_targets'])[:L]
             Y[i, :len(y)] = y
-            if A is not None:
-                a = np.asarray(e[aux_key])[:T]
-                A[i, :a.shape[0]] = a if A.ndim == 3 else a.reshape(-1)
+            for k, A_ in zip(aux_keys, As):
+                a = np.asarray(e[k])[:T]
+                A_[i, :a.shape[0]] = a if A_.ndim == 3 else a.reshape(-1)
         # per-utterance loss-normalisation counts (what the kernels count on the device): non-pad target tokens, and
         # ceil(valid auxiliary-target length / decimation) samples -- data parallel: every rank can sum them over a
         # GLOBAL batch without any exchange
         from .engine import Seq2SeqEngine
         Seq2SeqEngine.check_end_padded(X)
         tok = (Y != 0).sum(1).astype(np.int64)
-        val = np.zeros(n, np.int64)
-        if A is not None:
-            tl = (A != 0).sum(1) if A.ndim == 2 else (np.abs(A).max(axis=2) > 0).sum(1)
-            val = -(-tl // N)
-        return dict(X=X, Y=Y, A=A, n=n, T=T, L=L, tok=tok, val=val)
+        vals = []
+        for A_ in As:
+            tl = (A_ != 0).sum(1) if A_.ndim == 2 else (np.abs(A_).max(axis=2) > 0).sum(1)
+            vals.append(-(-tl // N))
+        A = As[0] if As else None
+        return dict(X=X, Y=Y, A=A, Ax=As[1:], n=n, T=T, L=L, tok=tok, val=(vals[0] if vals else np.zeros(n, np.int64)), valx=vals[1:])
 
     def _batches(self, data, rng=None):
         B = self.N_cases
@@ -181,11 +187,12 @@ class SequenceNetwork:
         the host and go through a pinned staging buffer."""
         import torch
         if 'dev' not in data:
-            nbytes = sum(a.nbytes for a in (data['X'], data['Y'], data['A']) if a is not None)
+            nbytes = sum(a.nbytes for a in [data['X'], data['Y'], data['A']] + list(data.get('Ax', [])) if a is not None)
             if nbytes > float(os.environ.get('E2T_RESIDENT_GB', '64')) * 2 ** 30:
                 data['dev'] = None
             else:
                 data['dev'] = {k: torch.from_numpy(data[k]).to(eng.device) for k in ('X', 'Y', 'A') if data[k] is not None}
+                data['dev']['Ax'] = [torch.from_numpy(a).to(eng.device) for a in data.get('Ax', [])]
         return data['dev']
 
     def _load_batch(self, eng, ws, data, idx, idx_dev=None):
@@ -204,6 +211,7 @@ class SequenceNetwork:
             pairs = [(dev['X'], ws['X']), (dev['Y'], ws['Y'])]
             if 'A' in dev and eng.aux is not None:
                 pairs.append((dev['A'], ws['auxT']))
+            pairs += [(a, wx['T']) for a, wx in zip(dev.get('Ax', []), ws['auxx'])]
             for src, dst in pairs:
                 lib.e2t_gather_rows_u32(src.data_ptr(), idx_dev.data_ptr(), B, B, src[0].numel(), dst.data_ptr(), st)
             ws['_keep'] = idx_dev            # alive until the next batch replaces it
@@ -223,6 +231,8 @@ class SequenceNetwork:
         put(ws['Y'], data['Y'])
         if data['A'] is not None and eng.aux is not None:
             put(ws['auxT'], data['A'])
+        for a, wx in zip(data.get('Ax', []), ws['auxx']):
+            put(wx['T'], a)
         torch.cuda.current_stream(eng.device).synchronize()      # the pinned buffers are reused by the next batch
 
     # ------------------------------------------------------------------ fit
@@ -274,11 +284,11 @@ class SequenceNetwork:
                     continue
                 gb = global_batches(d['n'], B, world, rng)
                 idx = np.full((len(gb), B), -1, np.int32)
-                cnt = np.zeros((len(gb), 2), np.int64)
+                cnt = np.zeros((len(gb), 2 + len(d.get('valx', []))), np.int64)
                 for k, g in enumerate(gb):
                     mine = rank_slice(g, B, rank)
                     idx[k, :len(mine)] = mine
-                    cnt[k] = (d['tok'][g].sum(), d['val'][g].sum())
+                    cnt[k] = [d['tok'][g].sum(), d['val'][g].sum()] + [v[g].sum() for v in d.get('valx', [])]
                 plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt))
             ws = None
             for k in range(max((len(p[2]) for p in plans), default=0)):      # round-robin over subjects ('parallel' learning)
@@ -288,7 +298,7 @@ class SequenceNetwork:
                     ws = eng.workspace(sid, B, d['T'], d['L'])
                     self._load_batch(eng, ws, d, idx[k], idx_dev[k])
                     if sync is not None:
-                        eng.set_global_counts(ws, int(cnt[k, 0]), int(cnt[k, 1]))
+                        eng.set_global_counts(ws, int(cnt[k, 0]), int(cnt[k, 1]), [int(v) for v in cnt[k, 2:]])
                     eng.train_step(ws, sync=sync)
             if ws is not None:
                 lo = eng.losses(ws)                                  # (also raises if an in-kernel wait timed out this epoch)
@@ -475,6 +485,8 @@ class SequenceNetwork:
                 out[seg] = 'seq2seq/subnet_%s/encoder_embedding' % seg[4:-2]
             elif seg.startswith('enc'):
                 out[seg] = 'seq2seq/encoder_rnn_%s' % seg[3:].split('.')[0]
+            elif seg.startswith('auxx'):
+                out[seg] = 'seq2seq/encoder_%s_projection' % eng.spec.aux_extra[int(seg[4:].split('_')[0])]['layer']
             elif seg.startswith('aux'):
                 out[seg] = 'seq2seq/encoder_%s_projection' % eng.spec.aux_layer
             elif seg == 'dec.emb':

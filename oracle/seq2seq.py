@@ -52,6 +52,10 @@ class NetSpec:
     aux_dim: int = 13
     aux_dist: str = 'Gaussian'             # subjects.py:369-380
     aux_scale: float = 1.0                 # '<data_key>_penalty_scale' trainers.py:98-102
+    # further auxiliary heads, one per additional 'encoder_<k>_targets' data key (the reference loops over every data key:
+    # trainers.py:94-102, 786-799): dicts with layer, hidden, dim, dist, scale; their targets come in
+    # batch['encoder_targets_extra'][i]; Philox stream STREAM_AUX + 4 * (i + 1)
+    aux_extra: List[dict] = field(default_factory=list)
     dec_scale: float = 1.0
     ff_dropout: float = 0.1
     rnn_dropout: float = 0.5
@@ -75,6 +79,20 @@ def ff_names(prefix, sizes):
     return ['seq2seq/%s_%d_%d_%d' % (prefix, sizes[i], sizes[i + 1], i) for i in range(len(sizes) - 1)]
 
 
+def aux_heads(spec):
+    """All auxiliary heads of a network: the primary one (aux_layer & co.) first, then aux_extra.  One head per tapped
+    layer (the variable names carry the layer index only: 'encoder_<layer>_projection_...')."""
+    heads = []
+    if spec.aux_layer is not None:
+        heads.append(dict(layer=spec.aux_layer, hidden=list(spec.aux_hidden), dim=spec.aux_dim, dist=spec.aux_dist,
+                          scale=spec.aux_scale, key='encoder_targets', stream=STREAM_AUX, name='aux'))
+    for i, h in enumerate(spec.aux_extra):
+        heads.append(dict(layer=h['layer'], hidden=list(h.get('hidden', [])), dim=h['dim'], dist=h.get('dist', 'Gaussian'),
+                          scale=h.get('scale', 1.0), key=i, stream=STREAM_AUX + 4 * (i + 1), name='aux_x%d' % i))
+    assert len({h['layer'] for h in heads}) == len(heads), 'one auxiliary head per encoder layer'
+    return heads
+
+
 def init_params(spec, seed=0, dtype=np.float64):
     """Glorot-uniform weights, zero biases [BUILD-DEFINES]."""
     rng = np.random.default_rng(seed)
@@ -95,9 +113,9 @@ def init_params(spec, seed=0, dtype=np.float64):
         for d in ('fw', 'bw'):
             P['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, d)] = glorot(D + H, 4 * H)
             P['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, d)] = np.zeros(4 * H, dtype)
-    if spec.aux_layer is not None:
-        sizes = [2 * spec.enc_rnn[spec.aux_layer]] + list(spec.aux_hidden) + [spec.aux_dim]
-        names = ff_names('encoder_%d_projection' % spec.aux_layer, sizes)
+    for hd in aux_heads(spec):
+        sizes = [2 * spec.enc_rnn[hd['layer']]] + list(hd['hidden']) + [hd['dim']]
+        names = ff_names('encoder_%d_projection' % hd['layer'], sizes)
         for i, nm in enumerate(names):
             last = i == len(names) - 1
             w = glorot(sizes[i], sizes[i + 1])
@@ -365,35 +383,48 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False, counts=None
     cache.update(h0=h0, c0=c0)
 
     losses = {}
-    # a8: auxiliary encoder-target head
-    if spec.aux_layer is not None and 'encoder_targets' in batch and spec.aux_scale != 0.0:
-        tg = np.asarray(batch['encoder_targets'])
-        cat = spec.aux_dist == 'categorical'
+    # a8: auxiliary encoder-target heads (one per 'encoder_<k>_targets' data key)
+    cache['aux_heads'] = {}
+    for hi, hd in enumerate(aux_heads(spec)):
+        if hd['key'] == 'encoder_targets':
+            tg = batch.get('encoder_targets')
+        else:
+            ex = batch.get('encoder_targets_extra')
+            tg = ex[hd['key']] if ex is not None else None
+        if tg is None or hd['scale'] == 0.0:
+            continue
+        tg = np.asarray(tg)
+        cat = hd['dist'] == 'categorical'
         tlens = sequence_lengths(tg)
         tr = reverse_time_major(tg if not cat else tg[..., None], tlens)     # [T,B,K]
         trp = np.zeros((S * N,) + tr.shape[1:], dtype=tr.dtype)
         trp[:T] = tr
         At = trp[0::N]                                   # trainers.py:794-795
         avalid = (np.arange(S)[:, None] * N < tlens[None, :])
-        names = ff_names('encoder_%d_projection' % spec.aux_layer,
-                         [2 * spec.enc_rnn[spec.aux_layer]] + list(spec.aux_hidden) + [spec.aux_dim])
-        Pout, ffc = ff_fwd(P, names, enc[spec.aux_layer]['Ydrop'], spec, q, train, seed, STREAM_AUX)
-        nval = max(int(avalid.sum()), 1) if counts is None else max(int(counts[1]), 1)
+        names = ff_names('encoder_%d_projection' % hd['layer'], [2 * spec.enc_rnn[hd['layer']]] + list(hd['hidden']) + [hd['dim']])
+        Pout, ffc = ff_fwd(P, names, enc[hd['layer']]['Ydrop'], spec, q, train, seed, hd['stream'])
+        if counts is None:
+            nval = max(int(avalid.sum()), 1)
+        else:
+            nval = max(int(counts[1] if hd['name'] == 'aux' else counts[2 + hd['key']]), 1)
         if cat:
             ids = At[..., 0].astype(np.int64)
             mx = Pout.max(-1, keepdims=True)
             lse = mx[..., 0] + np.log(np.exp(Pout - mx).sum(-1))
             ce = lse - np.take_along_axis(Pout, ids[..., None], -1)[..., 0]
-            losses['aux'] = float((ce * avalid).sum() / nval)
+            losses[hd['name']] = float((ce * avalid).sum() / nval)
             prob = np.exp(Pout - lse[..., None])
             onehot = np.zeros_like(Pout)
             np.put_along_axis(onehot, ids[..., None], 1.0, -1)
             dP = (prob - onehot) * avalid[..., None] / nval
         else:
             diff = (Pout - At) * avalid[..., None]
-            losses['aux'] = float((diff ** 2).sum() / (nval * spec.aux_dim))
-            dP = 2.0 * diff / (nval * spec.aux_dim)
-        cache.update(aux=dict(ff=ffc, dP=dP, names=names, Pout=Pout, At=At, avalid=avalid))
+            losses[hd['name']] = float((diff ** 2).sum() / (nval * hd['dim']))
+            dP = 2.0 * diff / (nval * hd['dim'])
+        rec = dict(ff=ffc, dP=dP, names=names, Pout=Pout, At=At, avalid=avalid, head=hd)
+        cache['aux_heads'][hd['layer']] = rec
+        if hd['name'] == 'aux':
+            cache['aux'] = rec
 
     # a9: decoder, teacher-forced; <EOS> doubles as the start symbol [BUILD-DEFINES]
     Yt = np.asarray(batch['decoder_targets'], dtype=np.int64)            # [B,L]
@@ -427,7 +458,7 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False, counts=None
     dlogits = (prob - onehot) * tvalid[..., None] / ntok
     pred = logits.argmax(-1)
     losses['accuracy'] = float(((pred == tgt) * tvalid).sum() / ntok)
-    losses['total'] = spec.dec_scale * losses['decoder'] + spec.aux_scale * losses.get('aux', 0.0)
+    losses['total'] = spec.dec_scale * losses['decoder'] + sum(hd['scale'] * losses.get(hd['name'], 0.0) for hd in aux_heads(spec))
     cache.update(dec=dict(U=U, e=e, mEm=mEm, lstm=dc_, Hdrop=Hdrop, mH=mH, pff=pffc, pnames=pnames,
                           dlogits=dlogits, dlens=dlens, logits=logits, L=L, Ydq=Ydq))
     return losses, cache
@@ -470,9 +501,9 @@ def backward(P, cache):
         lay = enc[l]
         H = spec.enc_rnn[l]
         dYd = np.zeros((S, B, 2 * H)) if dYdrop is None else dYdrop
-        if 'aux' in cache and spec.aux_layer == l:
-            a = cache['aux']
-            dYd = dYd + ff_bwd(P, a['ff'], a['dP'] * spec.aux_scale, spec, q, G)
+        if l in cache.get('aux_heads', {}):
+            a = cache['aux_heads'][l]
+            dYd = dYd + ff_bwd(P, a['ff'], a['dP'] * a['head']['scale'], spec, q, G)
         dYraw = dYd * lay['mY'] if lay['mY'] is not None else dYd
         inp = lay['inp']
         D = inp.shape[-1]

@@ -32,10 +32,10 @@ MANIFEST_TEMPLATE = """
   data_mapping:
     decoder_targets: text_sequence
     encoder_1_targets: audio_sequence
-    encoder_inputs: ecog_sequence
+{extra_map}    encoder_inputs: ecog_sequence
   decimation_factor: null
   encoder_1_targets_penalty_scale: 0.5
-  grid_size:
+{extra_scale}  grid_size:
   - {g0}
   - {g1}
   grid_step: 1
@@ -48,7 +48,7 @@ MANIFEST_TEMPLATE = """
     - 64
     encoder_1_projection:
     - 24
-    encoder_embedding:
+{extra_proj}    encoder_embedding:
     - 24
     encoder_rnn:
     - 32
@@ -68,8 +68,9 @@ MANIFEST_TEMPLATE = """
 """
 
 
-def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None):
-    """grids: {subject id: (rows, cols)} for participants whose electrode grids differ from `grid`."""
+def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None, extra_aux=False):
+    """grids: {subject id: (rows, cols)} for participants whose electrode grids differ from `grid`; extra_aux: a second
+    auxiliary head ('encoder_0_targets', also on the audio sequence, one hidden layer of 12, penalty scale 0.25)."""
     root = str(root)
     os.makedirs(root, exist_ok=True)
     blocks = {}
@@ -93,5 +94,8 @@ def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4),
     with open(path, 'w') as f:
         for sid in subject_ids:
             g = (grids or {}).get(sid, grid)
-            f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=g[0], g1=g[1], rate=rate))
+            f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=g[0], g1=g[1], rate=rate,
+                                            extra_map='    encoder_0_targets: audio_sequence\n' if extra_aux else '',
+                                            extra_scale='  encoder_0_targets_penalty_scale: 0.25\n' if extra_aux else '',
+                                            extra_proj='    encoder_0_projection:\n    - 12\n' if extra_aux else ''))
     return path

@@ -41,4 +41,18 @@ def make_batch(spec, B, T, L, seed=0, ragged=True, sid=None, categorical=False):
             for b in range(B):
                 A[b, lens[b]:] = 0.0
         batch['encoder_targets'] = A
+    extra = []
+    for hx in getattr(spec, 'aux_extra', []):
+        if hx.get('dist', 'Gaussian') == 'categorical':
+            A = rng.integers(1, hx['dim'], size=(B, T))
+            for b in range(B):
+                A[b, lens[b]:] = 0
+        else:
+            A = rng.standard_normal((B, T, hx['dim']))
+            A[np.abs(A) < 1e-3] = 0.5
+            for b in range(B):
+                A[b, lens[b]:] = 0.0
+        extra.append(A)
+    if extra:
+        batch['encoder_targets_extra'] = extra
     return batch

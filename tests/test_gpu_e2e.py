@@ -301,3 +301,33 @@ def eng_initial_loss(kw, batch):
     eng.forward(ws, train=False)
     torch.cuda.synchronize()
     return eng.losses(ws)['total']
+
+
+def test_fit_with_two_auxiliary_target_keys(small):
+    """Every 'encoder_<k>_targets' data key is an auxiliary head on encoder layer k (trainers.py:94-102, 786-799): two audio
+    heads (layers 0 and 1), both losses reported and falling, both heads' variables in the checkpoint under the reference's
+    names, restore + assess intact."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    path = make_experiment(small, subject_ids=(401,), epochs=30, interval=15, extra_aux=True)
+    ck = str(small / 'ck2'); os.makedirs(ck)
+    tr = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False,
+                             SN_kwargs={'N_cases': 32, 'learning_rate': 3e-3, 'FF_dropout': 0.0, 'RNN_dropout': 0.1, 'EMA_decay': 0.9},
+                             DG_kwargs={'max_samples': 420})
+    dms = tr.ecog_subjects[-1].data_manifests
+    assert dms['encoder_0_targets'].penalty_scale == 0.25 and dms['encoder_1_targets'].penalty_scale == 0.5
+    for s in tr.ecog_subjects:
+        s.write_tf_records_maybe()
+    a = tr.parallel_transfer_learn()
+    spec = tr.net._engine.spec
+    assert spec.aux_layer == 0 and spec.aux_hidden == [12] and spec.aux_scale == 0.25
+    assert spec.aux_extra == [dict(layer=1, hidden=[24], dim=5, dist='Gaussian', scale=0.5)]
+    lo = a['training'].losses
+    assert 'aux' in lo[0] and 'aux_x0' in lo[0]
+    assert lo[-1]['aux'] < lo[0]['aux'] and lo[-1]['aux_x0'] < lo[0]['aux_x0'] and lo[-1]['decoder'] < lo[0]['decoder']
+    from ecog2txt_amd import tf_checkpoint
+    names = {k: list(v) for k, v in tf_checkpoint.list_variables(os.path.join(ck, 'model.ckpt-30'))}
+    assert names['seq2seq/encoder_0_projection_64_12_0/weights'] == [64, 12]
+    assert names['seq2seq/encoder_1_projection_64_24_0/weights'] == [64, 24]
+    assert names['seq2seq/encoder_0_projection_12_5_1/weights'] == [5, 12] and names['seq2seq/encoder_1_projection_24_5_1/weights'] == [5, 24]
+    res = tr.assess_saved_model()
+    assert np.isfinite(res['validation'].word_error_rate)

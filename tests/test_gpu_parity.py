@@ -73,6 +73,13 @@ SPECS = {
     # cfg5's front-end width (1024 electrodes x decimation 12 -> K = 12288 conv GEMM) on a short sequence
     'cfg5_frontend': dict(channels={401: 1024}, decimation=12, enc_embed=100, enc_rnn=[16], dec_embed=8, dec_rnn=32,
                           vocab=20, aux_layer=0, aux_hidden=[12], aux_dim=13, ff_dropout=0.1, rnn_dropout=0.0),
+    # several auxiliary heads (one per 'encoder_<k>_targets' key, trainers.py:94-102): a categorical head on layer 0 and
+    # a plain linear Gaussian head on the top layer beside the main Gaussian head on layer 1 (one head per tapped layer: the
+    # variable names carry the layer index only)
+    'three_heads': dict(channels={401: 16}, decimation=4, enc_embed=24, enc_rnn=[32, 24, 24], dec_embed=16, dec_rnn=48,
+                        vocab=50, aux_layer=1, aux_hidden=[24], aux_dim=5, ff_dropout=0.1, rnn_dropout=0.3,
+                        aux_extra=[dict(layer=0, hidden=[12], dim=7, dist='categorical', scale=0.5),
+                                   dict(layer=2, hidden=[], dim=3, dist='Gaussian', scale=0.25)]),
     'cfg4_widths': dict(channels={401: 16}, decimation=4, enc_embed=40, enc_rnn=[1024], dec_embed=30, dec_rnn=2048,
                         vocab=90, aux_layer=None, ff_dropout=0.0, rnn_dropout=0.2),
 }
@@ -95,6 +102,9 @@ def test_forward_backward_parity(name, ragged):
     assert abs(got['decoder'] - want['decoder']) <= LOSS_RTOL * max(1.0, abs(want['decoder'])), (got, want)
     if 'aux' in want:
         assert abs(got['aux'] - want['aux']) <= LOSS_RTOL * max(1.0, abs(want['aux'])), (got, want)
+    for j in range(len(kw.get('aux_extra', []))):
+        k = 'aux_x%d' % j
+        assert abs(got[k] - want[k]) <= LOSS_RTOL * max(1.0, abs(want[k])), (got, want)
     assert abs(got['accuracy'] - want['accuracy']) < 0.02
     # encoder lengths and final state
     np.testing.assert_array_equal(ws['lens'].cpu().numpy(), cache['lens'])

@@ -102,3 +102,52 @@ def test_interior_zero_rows_are_rejected_on_the_host():
     X[0, 2] = 0
     with pytest.raises(ValueError, match='all-zero sample rows'):
         Seq2SeqEngine.check_end_padded(X)
+
+
+def test_oracle_with_several_auxiliary_heads_is_the_sum_of_its_parts():
+    """One head per 'encoder_<k>_targets' data key (trainers.py:94-102, 786-799).  The single-head oracle is pinned against
+    torch autograd; with further heads the loss is additive and the gradient linear in the heads, so
+    G(head A + head B) = G(A only) + G(B only) - G(no head) must hold exactly (same dropout masks: stream ids are per head)."""
+    extra = [dict(layer=0, hidden=[5], dim=4, dist='categorical', scale=0.7)]
+    both = tiny_spec(aux_extra=extra, ff_dropout=0.2, rnn_dropout=0.3)
+    P = O.init_params(both, seed=5)
+    batch = make_batch(both, B=5, T=11, L=6, seed=2)
+    assert 'encoder_targets_extra' in batch and len(O.aux_heads(both)) == 2
+
+    def run(spec, b):
+        lo, c = O.forward(P, spec, b, train=True, seed=9)
+        return lo, O.backward(P, c)
+    l_ab, g_ab = run(both, batch)
+    only_a = dict(batch); only_a.pop('encoder_targets_extra')
+    l_a, g_a = run(both, only_a)
+    only_b = dict(batch); only_b.pop('encoder_targets')
+    l_b, g_b = run(both, only_b)
+    none = dict(only_a); none.pop('encoder_targets')
+    l_0, g_0 = run(both, none)
+    assert abs(l_ab['total'] - (l_a['total'] + l_b['total'] - l_0['total'])) < 1e-12
+    assert 'aux' in l_ab and 'aux_x0' in l_ab and 'aux_x0' not in l_a and 'aux' not in l_b
+    for k in g_ab:
+        want = g_a.get(k, 0) + g_b.get(k, 0) - g_0.get(k, 0)
+        np.testing.assert_allclose(g_ab[k], want, atol=1e-12, err_msg=k)
+    # the extra head's own parameters only move when its targets are there, and a finite difference confirms one of them
+    nm = 'seq2seq/encoder_0_projection_8_5_0/weights'
+    assert nm in g_ab and nm not in g_a and np.abs(g_ab[nm]).max() > 0
+    e = 1e-6
+    Pp = {k: v.copy() for k, v in P.items()}; Pp[nm][2, 1] += e
+    Pm = {k: v.copy() for k, v in P.items()}; Pm[nm][2, 1] -= e
+    fd = (O.forward(Pp, both, batch, train=True, seed=9)[0]['total'] - O.forward(Pm, both, batch, train=True, seed=9)[0]['total']) / (2 * e)
+    assert abs(fd - g_ab[nm][2, 1]) < 1e-7
+
+
+def test_param_store_roundtrip_with_extra_heads():
+    from ecog2txt_amd.engine import ParamStore, NetSpec
+    ospec = tiny_spec(enc_rnn=[4, 6, 8], dec_rnn=16, aux_layer=2, aux_extra=[dict(layer=0, hidden=[5], dim=4, dist='categorical', scale=0.7),
+                                                                               dict(layer=1, hidden=[], dim=3)])
+    spec = NetSpec(**{k: getattr(ospec, k) for k in NetSpec.__dataclass_fields__})
+    P = O.init_params(ospec, seed=2)
+    st = ParamStore(spec, 'cpu')
+    st.import_tf(P)
+    out = st.export_tf('p')
+    assert set(out) == set(P)
+    for k in P:
+        np.testing.assert_allclose(out[k], P[k].astype(np.float32), rtol=0, atol=0)
