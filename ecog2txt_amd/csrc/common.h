@@ -81,6 +81,13 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_addr
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(m) : "memory");
 }
+// same, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit VALU address arithmetic per piece
+__device__ __forceinline__ void dma16_to_lds_sbase(const void* sbase, unsigned voff_bytes, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(m) : "memory");
+}
 // same, with the sc1 cache policy: bypasses the CU's L1, so data another workgroup published with
 // write-through (sc1 / agent-scope atomic) stores during THIS launch is seen (cdna_hip_programming.md G16, R1)
 __device__ __forceinline__ void dma16_to_lds_sc1(const void* gsrc, unsigned lds_addr) {
@@ -91,6 +98,8 @@ __device__ __forceinline__ void dma16_to_lds_sc1(const void* gsrc, unsigned lds_
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void dma_wait_all_but2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+// at most N vector-memory operations of this wave still outstanding (they retire in issue order)
+template <int N> __device__ __forceinline__ void dma_wait_but() { static_assert(N >= 0 && N < 64, "vmcnt"); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // wave-level reductions (64 lanes) via shuffles
 __device__ __forceinline__ float wave_max(float v) {

@@ -47,7 +47,9 @@ struct GemmArgs {
     float* last_col_out;       // if set: column N-1 of the product goes to last_col_out[row] instead of C
     int splits;
     float* slab;               // split-K partials [splits][M][N] fp32 (dense), reduced by k_splitk_reduce
-    long long a_bs, b_bs, c_bs; // batched launch (grid.z): element strides of A, B, C between products
+    long long a_bs, b_bs, c_bs; // batched launch: element strides of A, B, C between products
+    int batch;                 // number of products in the launch (>= 1)
+    int order;                 // 1: locality order of the flattened grid (default); 0: round-1 order (diagnostics)
 };
 // product z of a batched launch: operands, output and slabs moved to that product's
 __device__ __forceinline__ GemmArgs gemm_batch_view(const GemmArgs& in, int z) {
@@ -127,31 +129,60 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, 
 
 extern __shared__ __attribute__((aligned(16))) uint4 gemm_smem[];
 
+// LDS bytes of an instance and the workgroups of it that fit a CU (160 KiB of LDS; at most 2 with 64 accumulators and
+// the fragments in <= 256 registers per lane, 4 for the 32-deep two-stage diagnostic form)
+constexpr int gemm_lds_bytes(int bm, int bn, int kt, int ns) { return ns * (bm + bn) * (kt / 8) * 16; }
+constexpr int gemm_wgs_per_cu(int bm, int bn, int kt, int ns) {
+    return bm * bn > 128 * 128 ? 1 : (160 * 1024 / gemm_lds_bytes(bm, bn, kt, ns) >= 2 ? 2 : 1);
+}
+
 // RICH = false drops the ReLU / mask / dropout epilogue: with 32 accumulator tiles per wave the full epilogue body is too
 // large for hipcc to unroll, and a rolled loop indexes the accumulators dynamically (= scratch memory, 4x slower kernel).
-// KT = K depth of a stage (64; 32 for the K-major instance with 4 workgroups per CU: a K tile costs ~0.8 us of LDS-DMA
-// issue + wait + barrier whether one or two workgroups share the CU, so the K-major products -- whose k-rows are full
-// 256-B lines at any depth -- trade pipeline depth for occupancy: 32 KiB of LDS and <= 128 registers per workgroup)
-template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64, bool RS = false>
-__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 4 : 2) : 1) void k_gemm_nt(GemmArgs p_in) {
-    const GemmArgs p = gemm_batch_view(p_in, blockIdx.z);
+// KT = K depth of a stage, NS = stages.  Every shipped instance is 64 x 2.  Measured on the main loop in isolation
+// (scripts/gemm_loop_probe.py, two 128 x 128 workgroups per CU, per pair of 64-deep K tiles): loads only 0.73 us, fragment
+// reads + MFMAs only 0.77 (MFMA pipe alone: 0.43), both 1.31-1.40 K-major / 1.06 NT with random operands -- but 0.93 / 0.74
+// with all-zero operands: the loop runs into the chip's power limit, not into a latency (deeper pipelines 64 x 3, 32 x 4,
+// 32 x 3, 64 x 4, and a software pipeline across the barrier, were all slower: they add instructions, not overlap).  What
+// pays is fewer bytes and fewer instructions per flop: the locality order of the grid and the scalar-base DMA form below.
+// DBG (diagnostics, scripts/gemm_loop_probe.py): 1 = no operand loads after the prologue, 2 = loads and barriers only (no
+// fragment reads, no MFMA), 3 = fragment reads without MFMAs -- wrong results by design, timing only
+template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64, int NS = 2, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void k_gemm_nt(GemmArgs p_in) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE = (BM + BN) * (KT / 8);  // 16-B units per stage: [A: BM rows | B: BN rows][KT/8 chunks]
     static_assert(KT == 64 || (TN && KT == 32), "a 32-deep stage exists for the K-major form only");
+    static_assert(NS >= 2 && NS <= 6, "stages");
     constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
     constexpr int IA = BM / 8 / NW * KT / 64, IB = BN / 8 / NW * KT / 64;      // DMA instructions per wave and operand (1 KiB each)
-    uint4* smem = gemm_smem;                     // [2 stages][STAGE], ONE object
+    uint4* smem = gemm_smem;                     // [NS stages][STAGE], ONE object
 
-    // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): each XCD walks a
-    // contiguous run of tiles so an A row-panel is re-read from that XCD's own L2.
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    // The grid is ONE dimension over (product of a batched launch, K split, output tile); workgroup L runs on XCD L % 8
+    // (cdna_hip_programming.md T1).  Work items are laid out product-major, then split, then tiles with the SHORTER tile
+    // dimension innermost, and XCD x takes the x-th contiguous eighth of that list (bijective form): what runs together on
+    // one XCD is then one K range of a compact block of tiles, so each operand panel is fetched into that XCD's L2 once and
+    // shared by the workgroups that need it.  (Round 1 ordered tiles row-major whatever the shape and let splits and
+    // products fall on the XCDs as the 3-D grid happened to: for dW_x, 7 x 25 tiles x 2 splits, every XCD streamed nearly
+    // all of the wide operand -- L2 hit rate 0.48, 3.8 x the algorithmic bytes from HBM.)
+    const int ntm = (p_in.M + BM - 1) / BM, ntn = (p_in.N + BN - 1) / BN;
     const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
+    int ksplit, tm, tn, zprod;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int W = nwg * p_in.splits * p_in.batch;
+        const int L = blockIdx.x;
+        const int q = W >> 3, r = W & 7, xcd = L & 7, idx = L >> 3;
+        int w = p_in.order ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : L;
+        zprod = w / (nwg * p_in.splits);
+        w -= zprod * (nwg * p_in.splits);
+        ksplit = w / nwg;
+        int bid = w - ksplit * nwg;
+        if (!p_in.order) {
+            const int q2 = nwg >> 3, r2 = nwg & 7, x2 = bid & 7, i2 = bid >> 3;
+            bid = (x2 < r2 ? x2 * (q2 + 1) : r2 * (q2 + 1) + (x2 - r2) * q2) + i2;
+        }
+        if (p_in.order && ntm <= ntn) { tn = bid / ntm; tm = bid - tn * ntm; }
+        else { tm = bid / ntn; tn = bid - tm * ntn; }
     }
-    const int tm = bid / ntn, tn = bid % ntn;
+    const GemmArgs p = gemm_batch_view(p_in, zprod);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,9 +193,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
     const int nfull = TN ? (p.K + KT - 1) / KT : p.K / BK;
     const bool has_tail = !TN && (p.K % BK) != 0;
     const int per = (nfull + p.splits - 1) / p.splits;
-    const int t0 = blockIdx.y * per;
+    const int t0 = ksplit * per;
     const int t1 = min(nfull, t0 + per);
-    const bool my_tail = has_tail && (blockIdx.y == p.splits - 1);
+    const bool my_tail = has_tail && (ksplit == p.splits - 1);
 
     f32x4 acc[TI][TJ];
 #pragma unroll
@@ -225,24 +256,34 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
             dst = sb + rb * 8;
         }
     };
+    // K-major fast path: for a tile that lies wholly inside K the lane's source is (uniform tile base) + (a byte offset that
+    // does not depend on the tile) -- the offsets are computed once, the base lives in scalar registers, and the DMA
+    // instruction takes them as they are (the general form spent ~20 instructions per piece on 64-bit multiplies, the
+    // K-tail select and the zero page's address)
+    unsigned tn_off[TN ? NP : 1];
+    if (TN) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const bf16_t* src; uint4* dst;
+            piece_addr(0, 0, q, src, dst);              // (rows of tile 0 beyond K give the zero page here; such tiles take the general form)
+            tn_off[q] = (unsigned)((const char*)src - (const char*)(q < IA ? p.A : p.B));
+        }
+    }
     auto issue_piece = [&](int t, int buf, int pc_) {
         const bf16_t* src; uint4* dst;
+        if (TN && (t + 1) * KT <= p.K) {
+            uint4* sa = smem + buf * STAGE;
+            uint4* sb = sa + BM * (KT / 8);
+            constexpr int CA = BM / 8, CB = BN / 8, RA = 64 / CA, RB_ = 64 / CB;
+            const bool isA = pc_ < IA;
+            dst = isA ? sa + (wave * IA + pc_) * RA * CA : sb + (wave * IB + (pc_ - IA)) * RB_ * CB;
+            const bf16_t* base = isA ? p.A + (size_t)t * KT * p.lda : p.B + (size_t)t * KT * p.ldb;
+            dma16_to_lds_sbase(base, tn_off[pc_], lds_addr_of(dst));
+            return;
+        }
         piece_addr(t, buf, pc_, src, dst);
         dma16_to_lds(src, lds_addr_of(dst));
     };
-    // RS (register staging): the same 1-KiB pieces go through registers -- a global_load_dwordx4 (a few issue cycles) now, a
-    // ds_write_b128 (~13) after the current tile's MFMAs -- instead of an LDS-DMA instruction each (60-180 issue cycles with
-    // its M0 set-up: 8 of them per K tile were ~1000 cycles of a wave's in-order issue stream against ~550 of MFMA)
-    // eight named registers, spelled out (NP == 8 for the 128 x 128 instances): as an array -- behind a lambda capture or a
-    // rolled loop -- hipcc gives the staging registers a home in scratch memory
-    static_assert(!RS || NP == 8, "register staging is written for 8 pieces per wave");
-    uint4 stg0, stg1, stg2, stg3, stg4, stg5, stg6, stg7;
-#define E2T_RS_ONE_LOAD(T_, BUF_, Q_) { const bf16_t* src_; uint4* dst_; piece_addr((T_), (BUF_), Q_, src_, dst_); stg##Q_ = *(const uint4*)src_; }
-#define E2T_RS_ONE_STORE(T_, BUF_, Q_) { const bf16_t* src_; uint4* dst_; piece_addr((T_), (BUF_), Q_, src_, dst_); dst_[lane] = stg##Q_; }
-#define E2T_RS_LOAD(T_, BUF_) E2T_RS_ONE_LOAD(T_, BUF_, 0) E2T_RS_ONE_LOAD(T_, BUF_, 1) E2T_RS_ONE_LOAD(T_, BUF_, 2) E2T_RS_ONE_LOAD(T_, BUF_, 3) \
-                              E2T_RS_ONE_LOAD(T_, BUF_, 4) E2T_RS_ONE_LOAD(T_, BUF_, 5) E2T_RS_ONE_LOAD(T_, BUF_, 6) E2T_RS_ONE_LOAD(T_, BUF_, 7)
-#define E2T_RS_STORE(T_, BUF_) E2T_RS_ONE_STORE(T_, BUF_, 0) E2T_RS_ONE_STORE(T_, BUF_, 1) E2T_RS_ONE_STORE(T_, BUF_, 2) E2T_RS_ONE_STORE(T_, BUF_, 3) \
-                               E2T_RS_ONE_STORE(T_, BUF_, 4) E2T_RS_ONE_STORE(T_, BUF_, 5) E2T_RS_ONE_STORE(T_, BUF_, 6) E2T_RS_ONE_STORE(T_, BUF_, 7)
     auto issue = [&](int t, int buf) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) issue_piece(t, buf, q);
@@ -252,7 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
     // nt >= 0: the DMA pieces of tile nt (into the other stage) are issued between the MFMA rows of the first K block, so
     // their issue cost (m0 set-up, address VALU, 60-180 cycles of issue each) overlaps MFMA execution instead of
     // preceding it
-    auto compute = [&](int buf, int nt) {
+    auto compute = [&](int buf, int nt, int nbuf) {
         const uint4* sa = smem + buf * STAGE;
         const uint4* sb = sa + BM * (KT / 8);
         // 128 x 128 instances: the fragments of BOTH K blocks are requested before the first MFMA (registers to spare), so
@@ -305,11 +346,13 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
                     constexpr int PER = (NP + TI - 1) / TI;        // pieces per row of the first K block
 #pragma unroll
                     for (int q = 0; q < PER; ++q)
-                        if (kb == 0 && i * PER + q < NP) issue_piece(nt, buf ^ 1, i * PER + q);
+                        if (kb == 0 && i * PER + q < NP) issue_piece(nt, nbuf, i * PER + q);
                 }
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
+                for (int j = 0; j < TJ; ++j) {
+                    if (DBG == 3) { asm volatile("" :: "v"(fb[j]), "v"(fa[i])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
             }
         }
         if (BOTH) {
@@ -325,27 +368,28 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
     };
 
     int cur = 0;
-    if (RS) {
-        if (t0 < t1) { E2T_RS_LOAD(t0, 0) E2T_RS_STORE(t0, 0) }
-        __syncthreads();
-        for (int t = t0; t < t1; ++t) {
-            if (t + 1 < t1) { E2T_RS_LOAD(t + 1, cur ^ 1) }     // in flight while tile t is multiplied
-            compute(cur, -1);
-            if (t + 1 < t1) { E2T_RS_STORE(t + 1, cur ^ 1) }    // the other stage: everybody left it at the last barrier
-            __syncthreads();
-            cur ^= 1;
-        }
-    } else {
-    if (t0 < t1) issue(t0, 0);
+    {
+    // NS stages: tiles t .. t+NS-2 are in flight while tile t is awaited; tile t+NS-1 goes into the stage tile t-1 was read
+    // from (every wave left it before the barrier of this iteration)
+    constexpr int NP_ = IA + IB;
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_) if (t0 + s_ < t1) issue(t0 + s_, s_);
     for (int t = t0; t < t1; ++t) {
-        dma_wait_all();                                        // tile t has landed (only tile t is in flight here)
-        __syncthreads();                                       // ... for every wave; and buf[cur^1] is free again
+        const int ahead = min(NS - 2, t1 - 1 - t);             // later tiles that may stay in flight (loads retire in order)
+        if (NS == 2 || ahead == 0) dma_wait_but<0>();
+        else if (ahead == 1) dma_wait_but<NP_>();
+        else if (ahead == 2) dma_wait_but<2 * NP_>();
+        else if (ahead == 3) dma_wait_but<3 * NP_>();
+        else dma_wait_but<4 * NP_>();
+        __syncthreads();                                       // tile t has landed for every wave; the stage of tile t-1 is free
         // interleaving pays on the 256x256 instance (one workgroup per CU: nobody else hides the issue phase, 4 % faster);
         // with two workgroups per CU it only delays the loads (TN weight gradients 88 -> 107 us)
         constexpr bool INTERLEAVE = (BM * BN > 128 * 128);
-        if (!INTERLEAVE && t + 1 < t1) issue(t + 1, cur ^ 1);
-        compute(cur, (INTERLEAVE && t + 1 < t1) ? t + 1 : -1);
-        cur ^= 1;
+        const int nxt = t + NS - 1;
+        int nbuf = cur + NS - 1; if (nbuf >= NS) nbuf -= NS;
+        if (DBG != 1 && !INTERLEAVE && nxt < t1) issue(nxt, nbuf);
+        if (DBG != 2) compute(cur, (DBG != 1 && INTERLEAVE && nxt < t1) ? nxt : -1, nbuf);
+        if (++cur == NS) cur = 0;
     }
     }
     if (my_tail) {
@@ -368,7 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
             sb[swz(r, schunk)] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
         }
         __syncthreads();
-        compute(cur, -1);
+        compute(cur, -1, 0);
     }
 
     // epilogue.  MFMA roles are (B-tile fragment, A-tile fragment), so D[i][j]: column j = lane&15 is the
@@ -401,7 +445,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 128) ? (KT == 32 ? 
             if (atomic) {
                 // split-K: dense partial slab (all N columns incl. the bias column); summed in fixed order, and run
                 // through the same epilogue, by k_splitk_reduce
-                float* c = p.slab + ((size_t)blockIdx.y * p.M + gm) * p.N + gn0;
+                float* c = p.slab + ((size_t)ksplit * p.M + gm) * p.N + gn0;
                 const int nn = min(4, p.N - gn0);
                 if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
                 else for (int r = 0; r < nn; ++r) c[r] = v[r];
@@ -577,17 +621,9 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
 }
 
 struct GemmPlan { int tile, splits, batch; bool want_split; };
-// operand staging of the 128 x 128 instances: registers (E2T_GEMM_RS=1) or LDS-DMA
-static bool gemm_rs() {
-    static const bool rs = [] { const char* e = getenv("E2T_GEMM_RS"); return e && atoi(e) == 1; }();
-    return rs;
-}
-// stage depth of the K-major instance: 64; E2T_TN_KT=32 selects the 4-workgroups-per-CU variant (diagnostics -- measured:
-// dW_x 801 x 3200 x 8704 88-92 us vs 93, batched dW_h 63 vs 56, whole step 1.94 vs 1.87 ms: more occupancy does not help, the
-// instance is bound by the bytes a CU can pull into LDS per flop, not by latency)
-static int tn_stage_depth() {
-    static const int kt = [] { const char* e = getenv("E2T_TN_KT"); return (e && atoi(e) == 32) ? 32 : 64; }();
-    return kt;
+static int gemm_order() {
+    static const int o = [] { const char* e = getenv("E2T_GEMM_ORDER"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    return o;
 }
 // Which instance a product runs on, and its split count (shared by the launcher and e2t_gemm_plan).
 static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue* ep) {
@@ -596,7 +632,7 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
     // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
     // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
-    const int kt = tn ? tn_stage_depth() : BK;
+    const int kt = BK;
     const int nfull = tn ? (K + kt - 1) / kt : K / BK;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool have_ws = ep && ep->splitk_ws && ep->splitk_ws_bytes > 0;
@@ -608,7 +644,9 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     // halve the bytes staged per flop; E2T_TN256=0 keeps the 128 x 128 instance
     static const bool tn256_ok = [] { const char* e = getenv("E2T_TN256"); return !(e && atoi(e) == 0); }();
     const int nbatch = (ep && ep->batch > 1) ? ep->batch : 1;
-    const bool big_tn = tn && tn256_ok && kt == 64 && !rich && have_ws && M >= 1024 && N >= 1024 && t256 * nbatch >= 64 && forced != 128;
+    static const int tn256_min = [] { const char* e = getenv("E2T_TN256_MIN"); return e ? atoi(e) : 1024; }();        // (diagnostics)
+    static const int tn256_tiles = [] { const char* e = getenv("E2T_TN256_TILES"); return e ? atoi(e) : 64; }();
+    const bool big_tn = tn && tn256_ok && !rich && have_ws && M >= tn256_min && N >= tn256_min && t256 * nbatch >= tn256_tiles && forced != 128;
     if (big_tn) big = true;
     if (forced == 128) big = false;
     if (forced == 256 && !tn && !want_split && !rich) big = true;
@@ -620,7 +658,7 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     if (want_split) {
         const int ntm = (M + pl.tile - 1) / pl.tile, ntn = (N + pl.tile - 1) / pl.tile;
         const int tiles = ntm * ntn * pl.batch;
-        const int slots = (tn && kt == 32) ? 1024 : 512;
+        const int slots = 512;
         int s = slots / tiles;
         if (big) {
             // one 256 x 256 workgroup per CU: the split count that fills the last round best, smallest on ties
@@ -681,18 +719,31 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     const int batch = pl.batch;
     if (batch > 1) { p.a_bs = ep->a_batch_stride; p.b_bs = ep->b_batch_stride; p.c_bs = ep->c_batch_stride; }
     if (pl.splits > 1 || pl.want_split) { p.splits = pl.splits; p.slab = (float*)ep->splitk_ws; }
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, false>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
-    static const hipError_t attr_rc2 = hipFuncSetAttribute((const void*)k_gemm_nt<256, 256, 2, 4, false, true>,
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16);
-    if (attr_rc != hipSuccess || attr_rc2 != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc != hipSuccess ? attr_rc : attr_rc2)); return E2T_ERR_HIP; }
-    if (big && tn) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, true>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
-    else if (tn && tn_stage_depth() == 32) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 32>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 4 * 16, (hipStream_t)stream, p);
-    else if (tn && gemm_rs()) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true, 64, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
-    else if (tn) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
-    else if (big) hipLaunchKernelGGL((k_gemm_nt<256, 256, 2, 4, false, false>), dim3(ntm * ntn, p.splits, batch), dim3(512), 2 * (256 + 256) * 8 * 16, (hipStream_t)stream, p);
-    else if (gemm_rs()) hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false, 64, true>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, true, false>), dim3(ntm * ntn, p.splits, batch), dim3(256), 2 * (128 + 128) * 8 * 16, (hipStream_t)stream, p);
+    p.batch = batch;
+    p.order = gemm_order();
+    const dim3 grid((unsigned)(ntm * ntn * p.splits * batch));
+    const hipStream_t st = (hipStream_t)stream;
+    // every instance asks for its LDS explicitly (above the 64-KiB default for most of them)
+#define E2T_GEMM_GO(BM_, BN_, WM_, WN_, RICH_, TN_, KT_, NS_, D_)                                                           \
+    do {                                                                                                                    \
+        constexpr int lds_ = gemm_lds_bytes(BM_, BN_, KT_, NS_);                                                            \
+        static const hipError_t rc_ = hipFuncSetAttribute((const void*)k_gemm_nt<BM_, BN_, WM_, WN_, RICH_, TN_, KT_, NS_, D_>, \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                \
+        if (rc_ != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(rc_)); return E2T_ERR_HIP; }    \
+        hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, RICH_, TN_, KT_, NS_, D_>), grid, dim3(64 * WM_ * WN_), lds_, st, p); \
+    } while (0)
+    // E2T_GEMM_DBG=1|2|3 selects the timing-only forms of the 128 x 128 instances (scripts/gemm_loop_probe.py)
+    static const int dbg = [] { const char* e = getenv("E2T_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    if (tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 1);
+    else if (tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 2);
+    else if (tn && !big && dbg == 3) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 3);
+    else if (!tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 1);
+    else if (!tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 2);
+    else if (big && tn) E2T_GEMM_GO(256, 256, 2, 4, false, true, 64, 2, 0);
+    else if (tn) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 0);
+    else if (big) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 0);
+    else E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 0);
+#undef E2T_GEMM_GO
     if (p.splits > 1) {
         const size_t n = (size_t)M * ((N + 3) / 4);
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, p);
