@@ -16,6 +16,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two at once on the hardware converter (v_cvt_pk_bf16_f32): low half = bf16(a), high half = bf16(b).  Same bits as f2bf for
+// every fp32 pattern that is not a NaN (scripts/probes/cvt_bf16_probe.hip walks all 2^32 on the GPU: 0 mismatches); a NaN
+// stays a (quiet) NaN here, f2bf carries its upper bits along
+typedef float e2t_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 e2t_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f2bf_pk(float a, float b) {
+    const e2t_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, e2t_bf16x2));
+}
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

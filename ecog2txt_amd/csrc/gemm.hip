@@ -496,94 +496,150 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // a5 + a6 fused: tf.reverse_sequence (trainers.py:808-810) + strided temporal convolution (_convolve_sequences,
-// trainers.py:813-818) straight from the fp32 electrode grid x [B][T][C] -- ONE pass over the input, no packed bf16 copy
-// (config 5: 2.1 GB of input; the im2row copy cost a second pass plus 1.05 GB of writes and 1.05 GB of re-reads).
+// trainers.py:813-818) straight from the fp32 electrode grid x [B][T][C] -- ONE pass over the input.
 //   E[m][n] = epilogue( sum_k bf16(x[b][len_b - 1 - (t'*N + w)][c]) * W[n][k] ),  m = t'*B + b,  k = w*C + c
-// A workgroup owns 64 output rows x all F <= 128 columns; per K step it gathers 64 rows x 64 fp32 (256 contiguous bytes
-// per row: C % 64 == 0 keeps a step inside one source row), rounds them to bf16 on the way into LDS (the rounding point of
-// e2t_conv_pack, so the products are the same), and multiplies with the matching 128 x 64 slice of the weight image.
-// HBM-bound by design: 3 workgroups per CU keep ~48 KiB of fp32 loads in flight per CU.  Epilogue = the GEMM's (bias,
-// ReLU, dropout, rows beyond an utterance's decimated length zeroed).
+// HBM-bound by design (config 5: 2.1 GB of input against 134 GFLOP), so the kernel is built around the input stream:
+//  * a workgroup owns 64 output rows x all F <= 128 columns; a row's operand is ONE contiguous run of N*C floats of x
+//    (N consecutive samples, walked backwards in time), so per K step (KS floats per row) every row contributes a
+//    KS*4-byte run;
+//  * the raw fp32 runs and the matching [128][KS] slice of the bf16 weight image go to LDS by DMA (no registers, no
+//    waiting wave), NS stages deep -- (NS-1) x 64 x KS x 4 bytes of x in flight per workgroup; samples beyond an
+//    utterance's length come from the zero page;
+//  * fragments: a lane reads its row's 8 consecutive floats (2 x 16 B, chunk index XOR-swizzled with the row on the source
+//    side of the DMA), rounds them to bf16 exactly as e2t_conv_pack does, and multiplies; with a_out != NULL it also writes
+//    those 16 bytes to the packed im2row copy A[m][k] the weight-gradient product of the backward pass reads (training:
+//    2.1 GB in + 1.05 GB out instead of 2.1 + 1.05 + 1.05; inference: 2.1 GB);
+//  * K can be cut into `splits` ranges (grid = tiles x splits: fills the last round of workgroups); partial sums then go to
+//    fp32 slabs and k_splitk_reduce applies the epilogue, as for the GEMM.
+// Epilogue = the GEMM's (bias, ReLU, dropout, rows beyond an utterance's decimated length zeroed).
 // ---------------------------------------------------------------------------------------------------------------------
 struct ConvFwdArgs {
     const float* x; const int* lens; const bf16_t* WT; int ldw;
     int B, T, C, N, M, F;
-    GemmArgs epi;               // C = E, ldc, N = F, flags, drop, ld_logical, lens (decimated) / rowsB
+    bf16_t* a_out; int lda_out;
+    int ub, S;                  // tile = (64 / ub) consecutive decimated steps x ub consecutive utterances
+    GemmArgs epi;               // C = E, ldc, N = F, flags, drop, ld_logical, lens (decimated) / rowsB, splits, slab
 };
 
-__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvFwdArgs a) {
+constexpr int conv_lds_bytes(int ks, int ns) { return ns * (64 * ks * 4 + 128 * ks * 2); }
+constexpr int conv_wgs_per_cu(int ks, int ns) { return 160 * 1024 / conv_lds_bytes(ks, ns) >= 5 ? 5 : 160 * 1024 / conv_lds_bytes(ks, ns); }
+
+template <int KS, int NS, int DBG = 0>
+__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NS)) void k_conv_fwd(ConvFwdArgs a) {
     constexpr int BMc = 64, BNc = 128;
-    __shared__ __attribute__((aligned(16))) uint4 sm[2][(BMc + BNc) * 8];
+    constexpr int A_U = BMc * KS * 4 / 16, W_U = BNc * KS * 2 / 16, STAGE_U = A_U + W_U;      // 16-B units
+    constexpr int CHA = KS * 4 / 16, RPA = 64 / CHA;          // chunks per fp32 row; rows per 1-KiB DMA piece
+    constexpr int CHW = KS * 2 / 16, RPW = 64 / CHW;
+    constexpr int PA = BMc / RPA / 4, PW = BNc / RPW / 4;     // pieces per wave and stage
+    constexpr int NPc = (DBG == 3 ? 0 : PA) + ((DBG == 2 || DBG == 4) ? 0 : PW);
+    static_assert(KS == 64 || KS == 32, "K step");
+    uint4* smem = gemm_smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BMc;
-    const int K = a.N * a.C, nk = K / 64;
-    // gather map: thread -> (row r = tid/4, 16 consecutive k = two 16-B bf16 chunks q*2, q*2+1)
-    const int r = tid >> 2, q = tid & 3;
-    const int m = min(m0 + r, a.M - 1);
-    const int tp = m / a.B, b = m - tp * a.B;
-    const int len = a.lens[b];
-    const float* xb = a.x + (size_t)b * a.T * a.C;
-    // weight map: thread -> rows n = tid/8 + 32*i (i < 4), chunk tid%8
-    const int wn = tid >> 3, wc = tid & 7;
-    float4 av[4];
-    uint4 wv[4];
-    auto gload = [&](int t) {
-        const int k0 = t * 64, w = k0 / a.C, c0 = k0 - w * a.C;
-        const int tt = tp * a.N + w;
-        if (tt < len) {
-            const f32x4* src = (const f32x4*)(xb + (size_t)(len - 1 - tt) * a.C + c0 + q * 16);
+    const GemmArgs& p = a.epi;
+    const int tile = blockIdx.x / p.splits, ksplit = blockIdx.x - tile * p.splits;
+    const int tb = (a.B + a.ub - 1) / a.ub;                       // tiles along the utterances
+    const int tp0 = (tile / tb) * (BMc / a.ub), b0 = (tile - (tile / tb) * tb) * a.ub;
+    // row r of the tile -> output row m = t' * B + b, or -1 outside the batch
+    auto row_of = [&](int r) { const int tp = tp0 + r / a.ub, b = b0 + r % a.ub; return (tp < a.S && b < a.B) ? tp * a.B + b : -1; };
+    const int K = a.N * a.C, nk = K / KS;
+    const int per = (nk + p.splits - 1) / p.splits;
+    const int t0 = ksplit * per, t1 = min(nk, t0 + per);
+
+    // per piece of the input tile: this lane's row, the start of that row's run (tap w = 0, channel 0) and how many taps exist
+    const float* rowbase[PA];
+    int ntaps[PA];
+    unsigned srcoff[PA];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const f32x4 v = __builtin_nontemporal_load(src + i); av[i] = make_float4(v[0], v[1], v[2], v[3]); }   // read once
-        } else {
+    for (int i = 0; i < PA; ++i) {
+        const int r = (wave * PA + i) * RPA + lane / CHA, pc = lane % CHA;
+        const int m = row_of(r);
+        const int tp = max(m, 0) / a.B, b = max(m, 0) - tp * a.B;
+        const int len = m >= 0 ? a.lens[b] : 0;
+        ntaps[i] = len - tp * a.N;                              // tap w is a real sample iff w < ntaps
+        rowbase[i] = a.x + ((size_t)b * a.T + (len - 1 - tp * a.N)) * a.C;
+        srcoff[i] = (unsigned)((pc ^ (r & (CHA - 1))) * 4);      // in floats
+    }
+    auto issue = [&](int t, int buf) {
+        const int k0 = t * KS, w = k0 / a.C, c0 = k0 - w * a.C;
+        uint4* sa = smem + buf * STAGE_U;
+        uint4* sw = sa + A_U;
+        const long back = (long)c0 - (long)w * a.C;              // tap w lies w samples EARLIER in memory
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < (DBG == 3 ? 0 : PA); ++i) {
+            const float* src = (w < ntaps[i]) ? rowbase[i] + back + srcoff[i] : (const float*)g_gemm_zero_page + srcoff[i];
+            dma16_to_lds(src, lds_addr_of(sa + (wave * PA + i) * 64));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv[i] = *(const uint4*)(a.WT + (size_t)min(wn + 32 * i, a.F - 1) * a.ldw + k0 + wc * 8);
-    };
-    auto lstore = [&](int buf) {
-        uint4* sa = sm[buf];
-        uint4* sb = sa + BMc * 8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 v0 = av[2 * h], v1 = av[2 * h + 1];
-            uint4 o;
-            o.x = f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16); o.y = f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
-            o.z = f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16); o.w = f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
-            sa[swz(r, q * 2 + h)] = o;
+        for (int i = 0; i < ((DBG == 2 || DBG == 4) ? 0 : PW); ++i) {
+            const int r = (wave * PW + i) * RPW + lane / CHW, pc = lane % CHW;
+            const int sc = (KS == 64) ? (pc ^ (r & 7)) : (pc ^ ((r >> 2) & 3));
+            const bf16_t* src = a.WT + (size_t)min(r, a.F - 1) * a.ldw + k0 + sc * 8;
+            dma16_to_lds(src, lds_addr_of(sw + (wave * PW + i) * 64));
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sb[swz(wn + 32 * i, wc)] = wv[i];
     };
     f32x4 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fq = lane >> 4;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) gload(t + 1);                           // in flight while tile t is multiplied
-        const uint4* sa = sm[t & 1];
-        const uint4* sb = sa + BMc * 8;
+    const int arow = wave * 16 + frow;
+    const int gm_mine = row_of(arow);
+    bf16_t* aout = (a.a_out && gm_mine >= 0) ? a.a_out + (size_t)gm_mine * a.lda_out : nullptr;
+    auto compute = [&](int t, int buf) {
+        const uint4* sa = smem + buf * STAGE_U;
+        const uint4* sw = sa + A_U;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const uint4 fa = sa[swz(wave * 16 + frow, kb * 4 + fq)];
+        for (int kb = 0; kb < KS / 32; ++kb) {
+            const int c = kb * 8 + fq * 2;
+            const uint4 lo = sa[arow * CHA + (c ^ (arow & (CHA - 1)))];
+            const uint4 hi = sa[arow * CHA + ((c + 1) ^ (arow & (CHA - 1)))];
+            uint4 fa;
+            fa.x = f2bf_pk(__uint_as_float(lo.x), __uint_as_float(lo.y));
+            fa.y = f2bf_pk(__uint_as_float(lo.z), __uint_as_float(lo.w));
+            fa.z = f2bf_pk(__uint_as_float(hi.x), __uint_as_float(hi.y));
+            fa.w = f2bf_pk(__uint_as_float(hi.z), __uint_as_float(hi.w));
+            if (aout) *(uint4*)(aout + t * KS + kb * 32 + fq * 8) = fa;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint4 fb = sb[swz(j * 16 + frow, kb * 4 + fq)];
+                const int n = j * 16 + frow, ch = kb * 4 + fq;
+                const uint4 fb = sw[n * CHW + ((KS == 64) ? (ch ^ (n & 7)) : (ch ^ ((n >> 2) & 3)))];
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fb, *(const bf16x8*)&fa, acc[j], 0, 0, 0);
             }
         }
-        if (t + 1 < nk) lstore((t + 1) & 1);                    // the other stage: nobody reads it before the barrier
+    };
+    int cur = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_) if (t0 + s_ < t1) issue(t0 + s_, s_);
+    for (int t = t0; t < t1; ++t) {
+        const int ahead = min(NS - 2, t1 - 1 - t);
+        if (ahead == 0) dma_wait_but<0>();
+        else if (ahead == 1) dma_wait_but<NPc>();
+        else if (ahead == 2) dma_wait_but<2 * NPc>();
+        else if (ahead == 3) dma_wait_but<3 * NPc>();
+        else dma_wait_but<4 * NPc>();
         __syncthreads();
+        const int nxt = t + NS - 1;
+        int nbuf = cur + NS - 1; if (nbuf >= NS) nbuf -= NS;
+        if (nxt < t1) issue(nxt, nbuf);
+        if (DBG != 1 && DBG != 4) compute(t, cur);
+        if (++cur == NS) cur = 0;
     }
     // epilogue: D[i][j]: column j = lane&15 is the output row, rows (lane>>4)*4 + r are four consecutive channels
-    const GemmArgs& p = a.epi;
     const EpiCtx ec = epi_ctx(p);
-    const int gm = m0 + wave * 16 + frow;
-    if (gm >= a.M) return;
+    const int gm = gm_mine;
+    if (gm < 0) return;
+    if (p.splits > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gn0 = j * 16 + fq * 4;
+            if (gn0 >= p.N) continue;
+            float* c = p.slab + ((size_t)ksplit * p.M + gm) * p.N + gn0;
+            const int nn = min(4, p.N - gn0);
+            if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            else for (int r = 0; r < nn; ++r) c[r] = acc[j][r];
+        }
+        return;
+    }
     const bool rowvalid = p.lens ? (gm / p.rowsB) < p.lens[gm % p.rowsB] : true;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -596,26 +652,81 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvFwdArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in);
+
 extern "C" int e2t_conv_fwd_fused_ok(int C, int F) { return (C % 64 == 0 && F >= 1 && F <= 128) ? 1 : 0; }
 
 extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, int T, int C, int N, const void* WT, int ldw,
-                                  void* E, int lde, int F, const e2t_gemm_epilogue* ep, void* stream) {
+                                  void* E, int lde, int F, void* A_out, int lda_out, const e2t_gemm_epilogue* ep, void* stream) {
     E2T_CHECK_ARG(x && lens && WT && E && ep);
     E2T_CHECK_ARG(B > 0 && T > 0 && N > 0 && e2t_conv_fwd_fused_ok(C, F) && ldw % 8 == 0 && ldw >= N * C && lde >= F);
     E2T_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)WT) & 15) == 0 && (ep->flags & E2T_GEMM_OUT_BF16));
+    E2T_CHECK_ARG(!A_out || (lda_out % 8 == 0 && lda_out >= N * C && (((uintptr_t)A_out) & 15) == 0));
     ConvFwdArgs a{};
     a.x = x; a.lens = lens; a.WT = (const bf16_t*)WT; a.ldw = ldw;
     a.B = B; a.T = T; a.C = C; a.N = N; a.F = F;
+    a.a_out = (bf16_t*)A_out; a.lda_out = lda_out;
     const int S = (T + N - 1) / N;
     a.M = S * B;
     GemmArgs& p = a.epi;
-    p.C = E; p.ldc = lde; p.M = a.M; p.N = F; p.K = N * C; p.alpha = 1.0f; p.splits = 1;
+    p.C = E; p.ldc = lde; p.M = a.M; p.N = F; p.K = N * C; p.alpha = 1.0f; p.splits = 1; p.batch = 1; p.order = 1;
     p.bias = ep->bias;
     p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1;
     p.flags = ep->flags;
     p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;
     p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : F;
-    hipLaunchKernelGGL(k_conv_fwd, dim3((a.M + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+    // E2T_CONV_FWD="<K step>x<stages>[x<splits>[x<utterances per tile>]]" (diagnostics); default 64 x 2 (three workgroups per CU), K cut
+    // so that the last round of workgroups is full
+    struct ConvCfg { int ks, ns, splits, ub; };
+    static const ConvCfg cfg = [] {
+        ConvCfg r{64, 2, 0, 64};
+        const char* e = getenv("E2T_CONV_FWD");
+        if (e) { int k = 0, n = 0, s = 0, u = 0; const int got = sscanf(e, "%dx%dx%dx%d", &k, &n, &s, &u); if (got >= 2) { r.ks = k; r.ns = n; } if (got >= 3) r.splits = s; if (got >= 4 && u >= 1 && u <= 64 && 64 % u == 0) r.ub = u; }
+        return r;
+    }();
+    a.ub = cfg.ub; a.S = S;
+    const int tiles = ((S + 64 / a.ub - 1) / (64 / a.ub)) * ((B + a.ub - 1) / a.ub);
+    const int nk = N * C / cfg.ks;
+    int splits = cfg.splits;
+    if (splits <= 0) {
+        const int wgs = 256 * conv_wgs_per_cu(cfg.ks, cfg.ns);
+        double best = 0.0;
+        splits = 1;
+        for (int c = 1; c <= 4 && nk / c >= 32; ++c) {
+            const long w = (long)tiles * c;
+            const double u = (double)w / (double)(((w + wgs - 1) / wgs) * wgs);
+            if (u > best + 0.03) { best = u; splits = c; }
+        }
+    }
+    if (splits > 1) {
+        const size_t need = (size_t)splits * a.M * F * sizeof(float);
+        if (!ep->splitk_ws || ep->splitk_ws_bytes < need) splits = 1;
+    }
+    if (splits > 1) { p.splits = splits; p.slab = (float*)ep->splitk_ws; }
+    const dim3 grid((unsigned)(tiles * p.splits));
+    const hipStream_t st = (hipStream_t)stream;
+#define E2T_CONV_GO1(KS_, NS_, D_)                                                                                           \
+    do {                                                                                                                    \
+        constexpr int lds_ = conv_lds_bytes(KS_, NS_);                                                                      \
+        static const hipError_t rc_ = hipFuncSetAttribute((const void*)k_conv_fwd<KS_, NS_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        if (rc_ != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(rc_)); return E2T_ERR_HIP; }    \
+        hipLaunchKernelGGL((k_conv_fwd<KS_, NS_, D_>), grid, dim3(256), lds_, st, a);                                       \
+    } while (0)
+#define E2T_CONV_GO(KS_, NS_)                                                                                               \
+    do { if (cdbg == 1) E2T_CONV_GO1(KS_, NS_, 1); else if (cdbg == 2) E2T_CONV_GO1(KS_, NS_, 2); else if (cdbg == 3) E2T_CONV_GO1(KS_, NS_, 3); \
+         else if (cdbg == 4) E2T_CONV_GO1(KS_, NS_, 4); else E2T_CONV_GO1(KS_, NS_, 0); } while (0)
+    static const int cdbg = [] { const char* e = getenv("E2T_CONV_DBG"); return e ? atoi(e) : 0; }();    // timing-only forms (wrong results)
+    if (cfg.ks == 32 && cfg.ns == 2) E2T_CONV_GO(32, 2);
+    else if (cfg.ks == 32) E2T_CONV_GO(32, 5);
+    else if (cfg.ks == 64 && cfg.ns == 5) E2T_CONV_GO(64, 5);
+    else if (cfg.ks == 64 && cfg.ns == 2) E2T_CONV_GO(64, 2);
+    else E2T_CONV_GO(64, 4);
+#undef E2T_CONV_GO1
+#undef E2T_CONV_GO
+    if (p.splits > 1) {
+        const size_t n = (size_t)a.M * ((F + 3) / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, p);
+    }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
 }

@@ -756,7 +756,10 @@ class Seq2SeqEngine:
         self._wstream = None
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
         self._ovl = os.environ.get('E2T_OVERLAP', '1')          # diagnostics: 'auxf' / 'stage' / 'defer' subsets
-        self.fused_conv = os.environ.get('E2T_FUSED_CONV', '0') != '0'     # front-end in one pass over x (no packed copy in forward): measured SLOWER (cfg5 1296 vs 847 us, cfg2 132 vs 60), off
+        # front-end in ONE pass over x (e2t_conv_fwd_fused: reversal + im2row + bf16 rounding in the DMA path of the product, the
+        # packed copy for the backward pass emitted on the way): 'auto' = when the input batch is HBM-sized (>= 256 MiB: cfg5
+        # 894 -> 483 us inference / 729 us training; at cfg2's 105 MB the two-kernel path is as fast), '1' / '0' force it
+        self.fused_conv = os.environ.get('E2T_FUSED_CONV', 'auto')
         self.early_pack = os.environ.get('E2T_EARLY_PACK', '1') != '0'     # images of early-updated ranges re-packed under the backward pass
         self.tn = os.environ.get('E2T_TN', '1') != '0'       # weight gradients straight from the K-major activations (no transposes)
         self.trainable = None         # None = everything; else set of segment names
@@ -1109,10 +1112,11 @@ class Seq2SeqEngine:
         lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
         if after_first is not None:
             after_first()
-        fused = self.fused_conv and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed))
+        fused = (self.fused_conv == '1' or (self.fused_conv == 'auto' and B * T * Cc * 4 >= (1 << 28))) \
+            and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed))
         if not fused:
             lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
-        ws['A_stale'] = fused                 # the im2row copy is made in the backward pass, where the conv gradient needs it
+        ws['A_stale'] = fused and not train   # (inference through the fused kernel leaves no im2row copy; a backward pass after it packs first)
         if before_weights is not None:
             before_weights()
         if fused:
@@ -1126,8 +1130,11 @@ class Seq2SeqEngine:
                 ep.flags |= H.GEMM_DROPOUT
                 ep.drop_rate, ep.drop_stream, ep.drop_ld = s.ff_dropout, STREAM_CONV, s.enc_embed
                 ep.drop_seed, ep.drop_step = self.seed, self.step_t.data_ptr()
+            ep.splitk_ws, ep.splitk_ws_bytes = self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4
+            # training: the packed im2row copy the conv weight gradient reads is emitted on the way (no second pass over x)
             lib.e2t_conv_fwd_fused(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, self.convT[ws['sid']].data_ptr(),
-                                   ws['Kc8'], ws['E'].data_ptr(), self.F8, s.enc_embed, C.byref(ep), st)
+                                   ws['Kc8'], ws['E'].data_ptr(), self.F8, s.enc_embed,
+                                   ws['A'].data_ptr() if train else None, ws['Kc8'], C.byref(ep), st)
         else:
             self.gemm(ws['A'].data_ptr(), ws['Kc8'], self.convT[ws['sid']].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), self.F8,
                       M, s.enc_embed, ws['Kc8'],

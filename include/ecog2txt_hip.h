@@ -120,13 +120,15 @@ int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
 /* which instance e2t_gemm_{nt,tn}_bf16 would run this product on: *tile = 128 or 256 (square tiles), *splits = K splits
  * (1: none).  For profiling tools that attribute time to kernel instances (bench.py). */
 int e2t_gemm_plan(int tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int* tile, int* splits);
-/* a5+a6 in ONE pass over x (no packed copy): E[(t',b)][n] = epilogue(sum_{w,c} bf16(x[b][len-1-(t'*N+w)][c]) * WT[n][w*C+c]),
+/* a5+a6 in ONE pass over x: E[(t',b)][n] = epilogue(sum_{w,c} bf16(x[b][len-1-(t'*N+w)][c]) * WT[n][w*C+c]),
  * WT bf16 [F][ldw] K-contiguous (the conv image of e2t_pack_batch), E bf16 [S*B][lde]; ep: bias, flags (OUT_BF16 required,
- * RELU, DROPOUT), row_lens / rows_per_step (decimated lengths: rows beyond them are zeroed), dropout fields -- as for
- * e2t_gemm_nt_bf16.  Applicable when e2t_conv_fwd_fused_ok(C, F): C % 64 == 0, F <= 128. */
+ * RELU, DROPOUT), row_lens / rows_per_step (decimated lengths: rows beyond them are zeroed), dropout fields, splitk_ws
+ * (optional: lets the launcher cut K to fill the chip) -- as for e2t_gemm_nt_bf16.  A_out (may be NULL): the packed bf16
+ * im2row copy [S*B][lda_out] that e2t_conv_pack would write, columns < N*C only, emitted on the way (training: the
+ * weight-gradient product reads it).  Applicable when e2t_conv_fwd_fused_ok(C, F): C % 64 == 0, F <= 128. */
 int e2t_conv_fwd_fused_ok(int C, int F);
 int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, int T, int C, int N, const void* WT, int ldw, void* E, int lde,
-                       int F, const e2t_gemm_epilogue* ep, void* stream);
+                       int F, void* A_out, int lda_out, const e2t_gemm_epilogue* ep, void* stream);
 int e2t_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
 
 /* ---- weight packing: fp32 masters -> bf16 operand images (after every optimiser step) ---- */

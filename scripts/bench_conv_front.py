@@ -19,8 +19,8 @@ def timeit(fn, reps=10):
         g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
-for fused in ('0', '1'):
-    os.environ['E2T_FUSED_CONV'] = fused
+for fused in ('0', '1', '1a'):
+    os.environ['E2T_FUSED_CONV'] = fused[0]
     eng = Seq2SeqEngine(NetSpec(**kw), seed=1)
     eng.init_params(0)
     sid = list(kw['channels'])[0]
@@ -34,14 +34,16 @@ for fused in ('0', '1'):
     def front():
         st = eng.stream
         lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
-        if fused == '1':
+        if fused != '0':
             ep = H.GemmEpilogue()
             ep.bias = eng.store.ptr('conv%s.W' % sid, eng.store.p, ws['Kc'] * sp.enc_embed)
             ep.alpha, ep.flags = 1.0, H.GEMM_RELU | H.GEMM_OUT_BF16 | H.GEMM_DROPOUT
             ep.row_lens, ep.rows_per_step = ws['lens_d'].data_ptr(), B
+            ep.splitk_ws, ep.splitk_ws_bytes = eng.splitk_ws.data_ptr(), eng.splitk_ws.numel() * 4
             ep.drop_rate, ep.drop_stream, ep.drop_ld, ep.drop_seed, ep.drop_step = sp.ff_dropout, 1, sp.enc_embed, eng.seed, eng.step_t.data_ptr()
             lib.e2t_conv_fwd_fused(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, eng.convT[sid].data_ptr(), ws['Kc8'],
-                                   ws['E'].data_ptr(), eng.F8, sp.enc_embed, C.byref(ep), st)
+                                   ws['E'].data_ptr(), eng.F8, sp.enc_embed,
+                                   ws['A'].data_ptr() if fused == '1a' else None, ws['Kc8'], C.byref(ep), st)
         else:
             lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
             eng.gemm(ws['A'].data_ptr(), ws['Kc8'], eng.convT[sid].data_ptr(), ws['Kc8'], ws['E'].data_ptr(), eng.F8, M, sp.enc_embed,

@@ -1,6 +1,8 @@
 """Kernel-level parity tests (call through the C ABI, compare with NumPy/oracle)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -454,7 +456,13 @@ def test_fused_conv_forward_matches_pack_plus_gemm(hl, C_, F, N, T, B):
     ep.bias, ep.alpha, ep.flags = bt.data_ptr(), 1.0, hl.GEMM_RELU | hl.GEMM_OUT_BF16
     ep.row_lens, ep.rows_per_step = ld.data_ptr(), B
     assert hl.load().e2t_conv_fwd_fused_ok(C_, F) == 1
-    hl.lib.e2t_conv_fwd_fused(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, WT.data_ptr(), ldw, E.data_ptr(), lde, F, C.byref(ep), st())
+    wsb = torch.zeros(4 * S * B * F, dtype=torch.float32, device='cuda')
+    ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    lda = (K + 1 + 7) // 8 * 8
+    Ap = torch.full((S * B, lda), 3.0, dtype=torch.bfloat16, device='cuda')
+    # (E2T_CONV_FWD=<K step>x<stages>[x<splits>] selects other pipeline shapes for the whole process: the same test covers them)
+    hl.lib.e2t_conv_fwd_fused(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, WT.data_ptr(), ldw, E.data_ptr(), lde, F,
+                              Ap.data_ptr(), lda, C.byref(ep), st())
     torch.cuda.synchronize()
     Xr = O.reverse_time_major(X.astype(np.float64), lens)
     Xp = np.zeros((S * N, B, C_))
@@ -467,6 +475,17 @@ def test_fused_conv_forward_matches_pack_plus_gemm(hl, C_, F, N, T, B):
     np.testing.assert_allclose(got[:, :F], want, rtol=1e-2, atol=1e-2)          # bf16 output: one ulp where fp32 vs fp64 sums straddle
     assert (got[:, F:] == 7.0).all()                                              # padding columns untouched (the ones column lives there)
     assert np.abs(got[:, :F] - want).mean() < 2e-4
+    # the packed im2row copy emitted on the way is e2t_conv_pack's, bit for bit (columns >= K untouched)
+    Aref = torch.full((S * B, lda), 3.0, dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_conv_pack(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, Aref.data_ptr(), lda, st())
+    torch.cuda.synchronize()
+    assert torch.equal(Ap[:, :K].view(torch.int16), Aref[:, :K].view(torch.int16))
+    assert (host(Ap[:, K:]) == 3.0).all()
+    # without the copy: same E
+    E2 = torch.full((S * B, lde), 7.0, dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_conv_fwd_fused(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, WT.data_ptr(), ldw, E2.data_ptr(), lde, F, None, 0, C.byref(ep), st())
+    torch.cuda.synchronize()
+    assert torch.equal(E.view(torch.int16), E2.view(torch.int16))
 
 
 @pytest.mark.parametrize('M,N,K,nb', [(2049, 2050, 1100, 1), (1024, 2304, 2100, 2)])

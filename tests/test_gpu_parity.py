@@ -85,9 +85,12 @@ SPECS = {
 }
 
 
-@pytest.mark.parametrize('name', list(SPECS))
+@pytest.mark.parametrize('name', list(SPECS) + ['cfg5_frontend+fused', 'mid+fused'])
 @pytest.mark.parametrize('ragged', [False, True])
-def test_forward_backward_parity(name, ragged):
+def test_forward_backward_parity(name, ragged, monkeypatch):
+    if name.endswith('+fused'):          # the one-pass front-end (engine default only for HBM-sized batches) forced on
+        monkeypatch.setenv('E2T_FUSED_CONV', '1')
+        name = name[:-6]
     kw = SPECS[name]
     B, T, L = (40, 100, 8) if name == 'mid' else ((70, 26, 5) if name.endswith('_widths') else ((24, 100, 5) if name == 'cfg5_frontend' else (19, 26, 6)))
     if name == 'cfg4_widths' and not ragged:
