@@ -498,19 +498,21 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
 // a5 + a6 fused: tf.reverse_sequence (trainers.py:808-810) + strided temporal convolution (_convolve_sequences,
 // trainers.py:813-818) straight from the fp32 electrode grid x [B][T][C] -- ONE pass over the input.
 //   E[m][n] = epilogue( sum_k bf16(x[b][len_b - 1 - (t'*N + w)][c]) * W[n][k] ),  m = t'*B + b,  k = w*C + c
-// HBM-bound by design (config 5: 2.1 GB of input against 134 GFLOP), so the kernel is built around the input stream:
+// HBM-bound by design (config 5: 2.1 GB of input against 134 GFLOP), so both forms below are built around the input stream:
 //  * a workgroup owns 64 output rows x all F <= 128 columns; a row's operand is ONE contiguous run of N*C floats of x
-//    (N consecutive samples, walked backwards in time), so per K step (KS floats per row) every row contributes a
-//    KS*4-byte run;
-//  * the raw fp32 runs and the matching [128][KS] slice of the bf16 weight image go to LDS by DMA (no registers, no
-//    waiting wave), NS stages deep -- (NS-1) x 64 x KS x 4 bytes of x in flight per workgroup; samples beyond an
-//    utterance's length come from the zero page;
-//  * fragments: a lane reads its row's 8 consecutive floats (2 x 16 B, chunk index XOR-swizzled with the row on the source
-//    side of the DMA), rounds them to bf16 exactly as e2t_conv_pack does, and multiplies; with a_out != NULL it also writes
-//    those 16 bytes to the packed im2row copy A[m][k] the weight-gradient product of the backward pass reads (training:
-//    2.1 GB in + 1.05 GB out instead of 2.1 + 1.05 + 1.05; inference: 2.1 GB);
+//    (N consecutive samples, walked backwards in time), so per K step of 64 floats every row contributes a 256-byte run;
+//  * samples beyond an utterance's length come from the zero page; the rounding to bf16 is e2t_conv_pack's (hardware
+//    converter, bit-identical); with a_out != NULL the rounded operand is also written to the packed im2row copy A[m][k] the
+//    weight-gradient product of the backward pass reads (training: 2.1 GB in + 1.05 GB out instead of 2.1 + 1.05 + 1.05);
 //  * K can be cut into `splits` ranges (grid = tiles x splits: fills the last round of workgroups); partial sums then go to
 //    fp32 slabs and k_splitk_reduce applies the epilogue, as for the GEMM.
+// k_conv_fwd (all-DMA form): raw fp32 runs AND the [128][KS] weight slice by LDS-DMA, NS stages; a lane reads its row's 8
+//    floats (chunk index XOR-swizzled with the row on the source side of the DMA) and rounds them in registers.  LDS holds
+//    fp32 x plus weights, which caps the bytes of x in flight at 48 KiB per CU: cfg5 507 us (4.1 TB/s) whatever the shape
+//    (64x2 ... 64x5, 32x2 ... 32x5, 1-3 splits, tiles of 64 utterances or of 64 steps of one utterance: 480-580 us).
+// k_conv_fwd_ws (wave-specialised form, the default): see below; cfg5 445 us (4.7 TB/s).
+// For scale: plain loads of the same access pattern with nothing else in the kernel read at 6.0-6.1 TB/s = 340 us
+// (scripts/probes/stream_pattern_probe.hip); the two-kernel path (e2t_conv_pack + GEMM) takes 894 us.
 // Epilogue = the GEMM's (bias, ReLU, dropout, rows beyond an utterance's decimated length zeroed).
 // ---------------------------------------------------------------------------------------------------------------------
 struct ConvFwdArgs {
@@ -524,14 +526,14 @@ struct ConvFwdArgs {
 constexpr int conv_lds_bytes(int ks, int ns) { return ns * (64 * ks * 4 + 128 * ks * 2); }
 constexpr int conv_wgs_per_cu(int ks, int ns) { return 160 * 1024 / conv_lds_bytes(ks, ns) >= 5 ? 5 : 160 * 1024 / conv_lds_bytes(ks, ns); }
 
-template <int KS, int NS, int DBG = 0>
+template <int KS, int NS>
 __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NS)) void k_conv_fwd(ConvFwdArgs a) {
     constexpr int BMc = 64, BNc = 128;
     constexpr int A_U = BMc * KS * 4 / 16, W_U = BNc * KS * 2 / 16, STAGE_U = A_U + W_U;      // 16-B units
     constexpr int CHA = KS * 4 / 16, RPA = 64 / CHA;          // chunks per fp32 row; rows per 1-KiB DMA piece
     constexpr int CHW = KS * 2 / 16, RPW = 64 / CHW;
     constexpr int PA = BMc / RPA / 4, PW = BNc / RPW / 4;     // pieces per wave and stage
-    constexpr int NPc = (DBG == 3 ? 0 : PA) + ((DBG == 2 || DBG == 4) ? 0 : PW);
+    constexpr int NPc = PA + PW;
     static_assert(KS == 64 || KS == 32, "K step");
     uint4* smem = gemm_smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -566,12 +568,12 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NS)) void k_conv_fwd(ConvF
         uint4* sw = sa + A_U;
         const long back = (long)c0 - (long)w * a.C;              // tap w lies w samples EARLIER in memory
 #pragma unroll
-        for (int i = 0; i < (DBG == 3 ? 0 : PA); ++i) {
+        for (int i = 0; i < PA; ++i) {
             const float* src = (w < ntaps[i]) ? rowbase[i] + back + srcoff[i] : (const float*)g_gemm_zero_page + srcoff[i];
             dma16_to_lds(src, lds_addr_of(sa + (wave * PA + i) * 64));
         }
 #pragma unroll
-        for (int i = 0; i < ((DBG == 2 || DBG == 4) ? 0 : PW); ++i) {
+        for (int i = 0; i < PW; ++i) {
             const int r = (wave * PW + i) * RPW + lane / CHW, pc = lane % CHW;
             const int sc = (KS == 64) ? (pc ^ (r & 7)) : (pc ^ ((r >> 2) & 3));
             const bf16_t* src = a.WT + (size_t)min(r, a.F - 1) * a.ldw + k0 + sc * 8;
@@ -585,26 +587,36 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NS)) void k_conv_fwd(ConvF
     const int arow = wave * 16 + frow;
     const int gm_mine = row_of(arow);
     bf16_t* aout = (a.a_out && gm_mine >= 0) ? a.a_out + (size_t)gm_mine * a.lda_out : nullptr;
+    // every LDS read of the step is requested before its first MFMA (left to itself hipcc issues read, wait, MFMA sixteen
+    // times over: ~1.5 us of exposed LDS latency per step and wave, which -- not HBM -- bounded the kernel at 4.3 TB/s)
     auto compute = [&](int t, int buf) {
         const uint4* sa = smem + buf * STAGE_U;
         const uint4* sw = sa + A_U;
+        constexpr int NKB = KS / 32;
+        uint4 lo[NKB], hi[NKB], fb[NKB][8];
 #pragma unroll
-        for (int kb = 0; kb < KS / 32; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             const int c = kb * 8 + fq * 2;
-            const uint4 lo = sa[arow * CHA + (c ^ (arow & (CHA - 1)))];
-            const uint4 hi = sa[arow * CHA + ((c + 1) ^ (arow & (CHA - 1)))];
-            uint4 fa;
-            fa.x = f2bf_pk(__uint_as_float(lo.x), __uint_as_float(lo.y));
-            fa.y = f2bf_pk(__uint_as_float(lo.z), __uint_as_float(lo.w));
-            fa.z = f2bf_pk(__uint_as_float(hi.x), __uint_as_float(hi.y));
-            fa.w = f2bf_pk(__uint_as_float(hi.z), __uint_as_float(hi.w));
-            if (aout) *(uint4*)(aout + t * KS + kb * 32 + fq * 8) = fa;
+            lo[kb] = sa[arow * CHA + (c ^ (arow & (CHA - 1)))];
+            hi[kb] = sa[arow * CHA + ((c + 1) ^ (arow & (CHA - 1)))];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int n = j * 16 + frow, ch = kb * 4 + fq;
-                const uint4 fb = sw[n * CHW + ((KS == 64) ? (ch ^ (n & 7)) : (ch ^ ((n >> 2) & 3)))];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fb, *(const bf16x8*)&fa, acc[j], 0, 0, 0);
+                fb[kb][j] = sw[n * CHW + ((KS == 64) ? (ch ^ (n & 7)) : (ch ^ ((n >> 2) & 3)))];
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            uint4 fa;
+            fa.x = f2bf_pk(__uint_as_float(lo[kb].x), __uint_as_float(lo[kb].y));
+            fa.y = f2bf_pk(__uint_as_float(lo[kb].z), __uint_as_float(lo[kb].w));
+            fa.z = f2bf_pk(__uint_as_float(hi[kb].x), __uint_as_float(hi[kb].y));
+            fa.w = f2bf_pk(__uint_as_float(hi[kb].z), __uint_as_float(hi[kb].w));
+            if (aout) *(uint4*)(aout + t * KS + kb * 32 + fq * 8) = fa;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fb[kb][j], *(const bf16x8*)&fa, acc[j], 0, 0, 0);
         }
     };
     int cur = 0;
@@ -621,12 +633,170 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NS)) void k_conv_fwd(ConvF
         const int nxt = t + NS - 1;
         int nbuf = cur + NS - 1; if (nbuf >= NS) nbuf -= NS;
         if (nxt < t1) issue(nxt, nbuf);
-        if (DBG != 1 && DBG != 4) compute(t, cur);
+        compute(t, cur);
         if (++cur == NS) cur = 0;
     }
     // epilogue: D[i][j]: column j = lane&15 is the output row, rows (lane>>4)*4 + r are four consecutive channels
     const EpiCtx ec = epi_ctx(p);
     const int gm = gm_mine;
+    if (gm < 0) return;
+    if (p.splits > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gn0 = j * 16 + fq * 4;
+            if (gn0 >= p.N) continue;
+            float* c = p.slab + ((size_t)ksplit * p.M + gm) * p.N + gn0;
+            const int nn = min(4, p.N - gn0);
+            if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            else for (int r = 0; r < nn; ++r) c[r] = acc[j][r];
+        }
+        return;
+    }
+    const bool rowvalid = p.lens ? (gm / p.rowsB) < p.lens[gm % p.rowsB] : true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gn0 = j * 16 + fq * 4;
+        if (gn0 >= a.F) continue;
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) v[rr] = acc[j][rr] + ((p.bias && gn0 + rr < a.F) ? p.bias[gn0 + rr] : 0.f);
+        epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
+    }
+}
+
+// The same product with the waves of a workgroup SPECIALISED (512 threads, two workgroups per CU):
+//  * waves 0-3 load: each owns 16 of the 64 rows and keeps D K steps of its rows' fp32 runs in flight IN REGISTERS (plain
+//    16-B loads, 4 per lane and step), rounds a step to bf16 when it has arrived, writes it into the LDS stage (and the
+//    packed copy A_out) and reloads the registers with step t+D.  The DMA form above holds the raw fp32 AND the weight
+//    slice in LDS, which caps the input bytes in flight at 48 KiB per CU (4.3 TB/s); here a CU holds 2 x 4 x D x 4 KiB
+//    (D = 6: 192 KiB) and LDS only carries bf16.
+//  * waves 4-7 multiply: weight slices by LDS-DMA one step ahead, A fragments with ds_read_b128 (NT image, as in the GEMM).
+// One s_barrier per K step couples the two halves: step t is written while step t-1 is multiplied.  Raw s_barrier (not
+// __syncthreads: its fence would drain the loaders' vmcnt and with it the prefetch).
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void k_conv_fwd_ws(ConvFwdArgs a) {
+    constexpr int BMc = 64, BNc = 128, KS = 64, NSL = 3;
+    constexpr int A_U = BMc * 8, W_U = BNc * 8, STAGE_U = A_U + W_U;       // 16-B units per stage (24 KiB)
+    uint4* smem = gemm_smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const GemmArgs& p = a.epi;
+    const int tile = blockIdx.x / p.splits, ksplit = blockIdx.x - tile * p.splits;
+    const int tb = (a.B + a.ub - 1) / a.ub;
+    const int tp0 = (tile / tb) * (BMc / a.ub), b0 = (tile - (tile / tb) * tb) * a.ub;
+    auto row_of = [&](int r) { const int tp = tp0 + r / a.ub, b = b0 + r % a.ub; return (tp < a.S && b < a.B) ? tp * a.B + b : -1; };
+    const int K = a.N * a.C, nk = K / KS;
+    const int per = (nk + p.splits - 1) / p.splits;
+    const int t0 = ksplit * per, t1 = min(nk, t0 + per);
+    if (wave < 4) {
+        // ---------------- loaders ----------------
+        // load instruction i of a step covers rows 4i .. 4i+3 of this wave's 16, 16 lanes x 16 B = one whole 256-B run per row
+        // (a lane reading 64 contiguous bytes with four instructions would touch every 64-B sector four times)
+        const int rg = lane >> 4, c = lane & 15;
+        const float* rowbase[4];
+        bf16_t* aout[4];
+        int ntaps[4], rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 16 + 4 * i + rg;
+            const int m = row_of(r);
+            const int tp = max(m, 0) / a.B, b = max(m, 0) - tp * a.B;
+            const int len = m >= 0 ? a.lens[b] : 0;
+            rows[i] = r;
+            ntaps[i] = len - tp * a.N;
+            rowbase[i] = a.x + ((size_t)b * a.T + (len - 1 - tp * a.N)) * a.C + c * 4;
+            aout[i] = (a.a_out && m >= 0) ? a.a_out + (size_t)m * a.lda_out + c * 4 : nullptr;
+        }
+        // The loads are inline asm and the waits are counted by hand: hipcc, seeing loads behind uniform and divergent branches,
+        // put s_waitcnt vmcnt(0) in front of every conversion (= one step in flight).  Every sub-iteration therefore issues
+        // EXACTLY four loads, whatever the row or the step: samples beyond an utterance's length, rows outside the batch and the
+        // steps past the end of the K range read the zero page instead.  "At most 4 (D-1) younger operations outstanding" then
+        // means "the oldest group has arrived" (the A_out stores in between only make the wait stricter).
+        f32x4 R[D][4];
+        auto load = [&](int t, f32x4 (&dst)[4]) {
+            const int k0 = t * KS, w = k0 / a.C, c0 = k0 - w * a.C;
+            const long off = (long)c0 - (long)w * a.C;
+            const float* s0 = (t < t1 && w < ntaps[0]) ? rowbase[0] + off : (const float*)g_gemm_zero_page + c * 4;
+            const float* s1 = (t < t1 && w < ntaps[1]) ? rowbase[1] + off : (const float*)g_gemm_zero_page + c * 4;
+            const float* s2 = (t < t1 && w < ntaps[2]) ? rowbase[2] + off : (const float*)g_gemm_zero_page + c * 4;
+            const float* s3 = (t < t1 && w < ntaps[3]) ? rowbase[3] + off : (const float*)g_gemm_zero_page + c * 4;
+            asm volatile("global_load_dwordx4 %0, %4, off nt\n\tglobal_load_dwordx4 %1, %5, off nt\n\t"
+                         "global_load_dwordx4 %2, %6, off nt\n\tglobal_load_dwordx4 %3, %7, off nt"
+                         : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(s0), "v"(s1), "v"(s2), "v"(s3) : "memory");
+        };
+        auto arrived = [&](f32x4 (&dst)[4]) {
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]) : "n"(4 * (D - 1)) : "memory");
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(t0 + d, R[d]);
+        for (int base = t0; base <= t1; base += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int tt = base + d;
+                if (tt > t1) break;
+                if (tt < t1) {
+                    char* sa = (char*)(smem + (tt % NSL) * STAGE_U);
+                    arrived(R[d]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint2 o;
+                        o.x = f2bf_pk(R[d][i][0], R[d][i][1]); o.y = f2bf_pk(R[d][i][2], R[d][i][3]);
+                        *(uint2*)(sa + swz(rows[i], c >> 1) * 16 + (c & 1) * 8) = o;
+                        if (aout[i]) *(uint2*)(aout[i] + tt * KS) = o;
+                    }
+                    load(tt + D, R[d]);
+                }
+                wg_barrier_lds();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the padding loads of the last steps still target this wave's registers)
+        return;
+    }
+    // ---------------- multipliers ----------------
+    const int cw = wave - 4;
+    auto issue_w = [&](int t) {
+        uint4* sw = smem + (t % NSL) * STAGE_U + A_U;
+        const int k0 = t * KS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = (cw * 4 + i) * 8 + (lane >> 3), pc = lane & 7;
+            const bf16_t* src = a.WT + (size_t)min(rr, a.F - 1) * a.ldw + k0 + (pc ^ (rr & 7)) * 8;
+            dma16_to_lds(src, lds_addr_of(sw + (cw * 4 + i) * 64));
+        }
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    const int arow = cw * 16 + frow;
+    auto compute = [&](int t) {
+        const uint4* sa = smem + (t % NSL) * STAGE_U;
+        const uint4* sw = sa + A_U;
+        uint4 fa[2], fb[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            fa[kb] = sa[swz(arow, kb * 4 + fq)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[kb][j] = sw[swz(j * 16 + frow, kb * 4 + fq)];
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // all 18 reads requested before the first MFMA
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fb[kb][j], *(const bf16x8*)&fa[kb], acc[j], 0, 0, 0);
+    };
+    if (t0 < t1) issue_w(t0);
+    for (int tt = t0; tt <= t1; ++tt) {
+        if (tt + 1 < t1) issue_w(tt + 1);
+        if (tt > t0) compute(tt - 1);
+        if (tt + 1 < t1) dma_wait_but<4>(); else dma_wait_but<0>();      // the slice of step tt has landed (that of tt+1 may be on its way)
+        wg_barrier_lds();
+    }
+    const EpiCtx ec = epi_ctx(p);
+    const int gm = row_of(arow);
     if (gm < 0) return;
     if (p.splits > 1) {
 #pragma unroll
@@ -675,13 +845,19 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
     p.flags = ep->flags;
     p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;
     p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : F;
-    // E2T_CONV_FWD="<K step>x<stages>[x<splits>[x<utterances per tile>]]" (diagnostics); default 64 x 2 (three workgroups per CU), K cut
-    // so that the last round of workgroups is full
-    struct ConvCfg { int ks, ns, splits, ub; };
+    // E2T_CONV_FWD (diagnostics): "ws<D>[x<splits>]" = the wave-specialised form (default ws4), "<K step>x<stages>[x<splits>[x<utterances
+    // per tile>]]" = the all-DMA form (64x2, 64x4, 32x2).  splits 0 / absent: K is cut so that the last round of workgroups is full.
+    struct ConvCfg { int ks, ns, splits, ub, ws; };
     static const ConvCfg cfg = [] {
-        ConvCfg r{64, 2, 0, 64};
+        ConvCfg r{64, 2, 0, 64, 4};
         const char* e = getenv("E2T_CONV_FWD");
-        if (e) { int k = 0, n = 0, s = 0, u = 0; const int got = sscanf(e, "%dx%dx%dx%d", &k, &n, &s, &u); if (got >= 2) { r.ks = k; r.ns = n; } if (got >= 3) r.splits = s; if (got >= 4 && u >= 1 && u <= 64 && 64 % u == 0) r.ub = u; }
+        if (!e) return r;
+        if (e[0] == 'w' && e[1] == 's') { int d = 0, sp = 0; const int got = sscanf(e + 2, "%dx%d", &d, &sp); if (got >= 1 && (d == 4 || d == 6)) r.ws = d; if (got >= 2) r.splits = sp; return r; }
+        int k = 0, n = 0, sp = 0, u = 0;
+        const int got = sscanf(e, "%dx%dx%dx%d", &k, &n, &sp, &u);
+        if (got >= 2 && ((k == 64 && (n == 2 || n == 4)) || (k == 32 && n == 2))) { r.ks = k; r.ns = n; r.ws = 0; }
+        if (got >= 3) r.splits = sp;
+        if (got >= 4 && u >= 1 && u <= 64 && 64 % u == 0) r.ub = u;
         return r;
     }();
     a.ub = cfg.ub; a.S = S;
@@ -689,7 +865,7 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
     const int nk = N * C / cfg.ks;
     int splits = cfg.splits;
     if (splits <= 0) {
-        const int wgs = 256 * conv_wgs_per_cu(cfg.ks, cfg.ns);
+        const int wgs = 256 * (cfg.ws ? 2 : conv_wgs_per_cu(cfg.ks, cfg.ns));
         double best = 0.0;
         splits = 1;
         for (int c = 1; c <= 4 && nk / c >= 32; ++c) {
@@ -705,23 +881,18 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
     if (splits > 1) { p.splits = splits; p.slab = (float*)ep->splitk_ws; }
     const dim3 grid((unsigned)(tiles * p.splits));
     const hipStream_t st = (hipStream_t)stream;
-#define E2T_CONV_GO1(KS_, NS_, D_)                                                                                           \
+#define E2T_CONV_GO(KERNEL_, THREADS_, LDS_)                                                                                \
     do {                                                                                                                    \
-        constexpr int lds_ = conv_lds_bytes(KS_, NS_);                                                                      \
-        static const hipError_t rc_ = hipFuncSetAttribute((const void*)k_conv_fwd<KS_, NS_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        static const hipError_t rc_ = hipFuncSetAttribute((const void*)KERNEL_, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
         if (rc_ != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(rc_)); return E2T_ERR_HIP; }    \
-        hipLaunchKernelGGL((k_conv_fwd<KS_, NS_, D_>), grid, dim3(256), lds_, st, a);                                       \
+        hipLaunchKernelGGL(KERNEL_, grid, dim3(THREADS_), LDS_, st, a);                                                     \
     } while (0)
-#define E2T_CONV_GO(KS_, NS_)                                                                                               \
-    do { if (cdbg == 1) E2T_CONV_GO1(KS_, NS_, 1); else if (cdbg == 2) E2T_CONV_GO1(KS_, NS_, 2); else if (cdbg == 3) E2T_CONV_GO1(KS_, NS_, 3); \
-         else if (cdbg == 4) E2T_CONV_GO1(KS_, NS_, 4); else E2T_CONV_GO1(KS_, NS_, 0); } while (0)
-    static const int cdbg = [] { const char* e = getenv("E2T_CONV_DBG"); return e ? atoi(e) : 0; }();    // timing-only forms (wrong results)
-    if (cfg.ks == 32 && cfg.ns == 2) E2T_CONV_GO(32, 2);
-    else if (cfg.ks == 32) E2T_CONV_GO(32, 5);
-    else if (cfg.ks == 64 && cfg.ns == 5) E2T_CONV_GO(64, 5);
-    else if (cfg.ks == 64 && cfg.ns == 2) E2T_CONV_GO(64, 2);
-    else E2T_CONV_GO(64, 4);
-#undef E2T_CONV_GO1
+    constexpr int ws_lds = 3 * (64 + 128) * 8 * 16;
+    if (cfg.ws == 6) E2T_CONV_GO((k_conv_fwd_ws<6>), 512, ws_lds);
+    else if (cfg.ws) E2T_CONV_GO((k_conv_fwd_ws<4>), 512, ws_lds);
+    else if (cfg.ks == 32) E2T_CONV_GO((k_conv_fwd<32, 2>), 256, conv_lds_bytes(32, 2));
+    else if (cfg.ns == 4) E2T_CONV_GO((k_conv_fwd<64, 4>), 256, conv_lds_bytes(64, 4));
+    else E2T_CONV_GO((k_conv_fwd<64, 2>), 256, conv_lds_bytes(64, 2));
 #undef E2T_CONV_GO
     if (p.splits > 1) {
         const size_t n = (size_t)a.M * ((F + 3) / 4);
