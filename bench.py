@@ -250,7 +250,7 @@ def main():
         log, eng._gemm_log = eng._gemm_log, None
         traffic = {}
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r02_pmc_gemm.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r02c_pmc_gemm.json')) as f:
                 traffic = json.load(f)
         except Exception:
             pass
