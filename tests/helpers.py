@@ -23,7 +23,7 @@ def make_batch(spec, B, T, L, seed=0, ragged=True, sid=None, categorical=False):
     for b in range(B):
         X[b, lens[b]:] = 0.0
     Y = np.zeros((B, L), np.int64)
-    dl = rng.integers(2, L + 1, size=B) if ragged else np.full(B, L)
+    dl = rng.integers(min(2, L), L + 1, size=B) if ragged else np.full(B, L)
     dl[0] = L
     for b in range(B):
         n = dl[b]

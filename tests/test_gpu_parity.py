@@ -121,6 +121,31 @@ def test_forward_backward_parity(name, ragged, monkeypatch):
         check_grad(k, Gd[k], G[k])
 
 
+@pytest.mark.parametrize('B,T,L', [(1, 9, 1), (1, 3, 2), (3, 5, 1), (2, 400, 10), (17, 2, 3)])
+def test_smallest_shapes(B, T, L):
+    """Edge shapes: a single utterance, one decimated step (T <= decimation), one target token, T not a multiple of the
+    decimation -- forward losses, every gradient and the greedy sequence against the oracle."""
+    kw = SPECS['tiny_odd']
+    eng, ws, ospec, P, batch = build(kw, B, T, L, seed=B + T + L, ragged=True)
+    eng.forward(ws, train=False)
+    eng.backward(ws, train=False)
+    torch.cuda.synchronize()
+    got = eng.losses(ws)
+    want, cache = O.forward(P, ospec, batch, train=False, emulate_bf16=True)
+    assert abs(got['decoder'] - want['decoder']) <= LOSS_RTOL * max(1.0, abs(want['decoder'])), (got, want)
+    assert abs(got['aux'] - want['aux']) <= LOSS_RTOL * max(1.0, abs(want['aux'])), (got, want)
+    G = O.backward(P, cache)
+    Gd = eng.store.export_tf('g')
+    for k in sorted(G):
+        check_grad(k, Gd[k], G[k])
+    hyp = eng.greedy_decode(ws, which='p').cpu().numpy()
+    ref, logits = O.greedy_decode(P, ospec, batch, max_len=L, emulate_bf16=True)
+    top2 = np.sort(logits, -1)[..., -2:]
+    margin = (top2[..., 1] - top2[..., 0]).T
+    diff = hyp[:, :margin.shape[1]] != ref[:, :margin.shape[1]]
+    assert not (diff & (margin > 5e-2)).any()
+
+
 @pytest.mark.parametrize('name', ['small_dropout', 'mid', 'no_aux_linear_conv', 'cfg5_frontend'])
 def test_input_gradient_matches_oracle(name):
     """Row a12 (restore_and_get_saliencies, trainers.py:703-732): d loss / d encoder_inputs, per sample ('sequences') and
