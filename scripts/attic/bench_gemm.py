@@ -1,6 +1,6 @@
 """Micro-benchmark of e2t_gemm_nt_bf16 on the shapes of the cfg2 train step."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from ecog2txt_amd import hip_lib as H

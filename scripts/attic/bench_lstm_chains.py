@@ -1,6 +1,6 @@
 """Forward/backward recurrence of one encoder layer with 1/2/4 concurrent row-block chains."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch, bench
 from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec

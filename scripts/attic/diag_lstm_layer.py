@@ -1,6 +1,6 @@
 """Diagnostic: one bi-LSTM layer forward on the GPU vs the oracle; prints where they differ."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from oracle import seq2seq as O
