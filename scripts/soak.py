@@ -6,11 +6,11 @@ import numpy as np, torch
 import bench
 from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
 secs = float(os.environ.get('SOAK_SECONDS', '20'))
-for cfg, B, T in (('cfg2', 256, 400), ('cfg2', 200, 1212), ('cfg2', 64, 96)):
+for cfg, B, T in (('cfg2', 256, 400), ('cfg2', 200, 1212), ('cfg2', 64, 96), ('cfg5', 256, 2000), ('cfg4', 256, 400)):
     kw, _, _, L = bench.CONFIGS[cfg]
     eng = Seq2SeqEngine(NetSpec(**kw), seed=1)
     eng.init_params(0)
-    ws = eng.workspace(401, B, T, L)
+    ws = eng.workspace(list(kw['channels'])[0], B, T, L)
     batch = bench.synth_batch(kw, B, T, L, 1)
     eng.set_batch(ws, batch)
     X0 = ws['X'].clone()
