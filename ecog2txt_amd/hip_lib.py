@@ -106,6 +106,10 @@ def load():
         raise RuntimeError(
             'libecog2txt_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
             'or ecog2txt_amd/csrc/build.sh. There is no CPU fallback for this path.' % LIB_PATH)
+    # torch first: it ships its own libamdhip64 and the host side keeps tensors and streams in that runtime; loaded the other
+    # way round, this library binds the ROCm install's copy and the process ends up with two HIP runtimes (the second one
+    # reports "no ROCm-capable device" on the first launch -- seen with build() followed by smoke() in one process)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (args, res) in PLAIN.items():
         fn = getattr(lib, name)
