@@ -72,6 +72,32 @@ def test_readme_flow_learns(small):
         z = np.maximum(z, 0.0) * (np.arange(S)[:, None] < -(-lens[i] // 12))
         np.testing.assert_allclose(act['convolved_inputs'][i], round_bf16(z), rtol=2e-2, atol=2e-2)
     assert np.isfinite(act['final_RNN_state']).all() and np.abs(act['final_RNN_state'][1]).max() <= 1.0
+    # ... and every probed tensor against the oracle run on the checkpoint's EMA weights (dropout off): front-end output,
+    # decimated reversed auxiliary targets, and the (c, h) that initialise the decoder
+    from oracle import seq2seq as O
+    vals = dict(np.load(os.path.join(ck, 'model.ckpt-60.npz')))
+    sfx = '/ExponentialMovingAverage'
+    Pema = {k[:-len(sfx)]: v.astype(np.float64) for k, v in vals.items() if k.endswith(sfx)}
+    ospec = O.NetSpec(**tr.net._engine.spec.as_dict())
+    assert set(Pema) == set(O.init_params(ospec, seed=0))
+    vdata = tr.net._stage(tr.ecog_subjects[-1], 'validation')
+    obatch = dict(subnet_id=tr.ecog_subjects[-1].subnet_id, encoder_inputs=vdata['X'], decoder_targets=vdata['Y'], encoder_targets=vdata['A'])
+    _, oc = O.forward(Pema, ospec, obatch, train=False, emulate_bf16=True)
+    np.testing.assert_allclose(act['convolved_inputs'], oc['E'].transpose(1, 0, 2), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(act['final_RNN_state'][0], oc['c0'], rtol=2e-2, atol=5e-3)
+    np.testing.assert_allclose(act['final_RNN_state'][1], oc['h0'], rtol=2e-2, atol=5e-3)
+    np.testing.assert_allclose(act['decimated_reversed_targets'], oc['aux_heads'][ospec.aux_layer]['At'].transpose(1, 0, 2), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(act['reversed_inputs'], O.reverse_time_major(vdata['X'].astype(np.float64), oc['lens']).transpose(1, 0, 2).astype(np.float32))
+    # the assessment itself against the oracle: greedy hypotheses (as text), teacher-forced token accuracy, WER
+    from ecog2txt_amd.sequence_network import target_inds_to_sequences
+    from ecog2txt_amd.toolbox import wer_vector
+    feats = list(tr.ecog_subjects[-1].data_manifests['decoder_targets'].get_feature_list())
+    ohyp, _ = O.greedy_decode(Pema, ospec, obatch, max_len=vdata['L'], emulate_bf16=True)
+    otext = target_inds_to_sequences(ohyp, feats)
+    assert otext == res['validation'].hypotheses
+    olo, _ = O.forward(Pema, ospec, obatch, train=False, emulate_bf16=True)
+    assert abs(olo['accuracy'] - res['validation'].accuracy) < 1e-6
+    assert abs(float(np.mean(wer_vector(res['validation'].references, otext))) - res['validation'].word_error_rate) < 1e-9
     # online predictor (trainers.py:925-949): one utterance at a time reproduces the batch assessment's hypotheses
     predict = tr.construct_online_predictor()
     data = tr.net._stage(tr.ecog_subjects[-1], 'validation')
