@@ -98,6 +98,16 @@ def test_readme_flow_learns(small):
     olo, _ = O.forward(Pema, ospec, obatch, train=False, emulate_bf16=True)
     assert abs(olo['accuracy'] - res['validation'].accuracy) < 1e-6
     assert abs(float(np.mean(wer_vector(res['validation'].references, otext))) - res['validation'].word_error_rate) < 1e-9
+    # saliencies (trainers.py:703-732) against the oracle's input gradient of the same penalty-weighted loss
+    if vdata['n'] <= 32:                                     # one batch: the loss normalisation is the oracle's
+        import dataclasses
+        osal = dataclasses.replace(ospec, aux_scale=0.0, dec_scale=1.0)      # get_saliencies: every penalty zeroed but the named one
+        _, ocs = O.forward(Pema, osal, obatch, train=False, emulate_bf16=True)
+        O.backward(Pema, ocs)
+        want = O.input_gradient(Pema, ocs)
+        assert seqs.shape == want.shape
+        assert np.linalg.norm(seqs - want) / np.linalg.norm(want) < 3e-2
+        np.testing.assert_allclose(sal, np.sqrt((want ** 2).mean(axis=(0, 1))), rtol=3e-2)
     # online predictor (trainers.py:925-949): one utterance at a time reproduces the batch assessment's hypotheses
     predict = tr.construct_online_predictor()
     data = tr.net._stage(tr.ecog_subjects[-1], 'validation')
