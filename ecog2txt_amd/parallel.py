@@ -180,22 +180,35 @@ class RcclSync:
             self.comm = None
 
 
-def bootstrap_unique_id(rank, world, group=None, port_offset=1):
-    """Rank 0 makes the RCCL unique id; everybody gets it -- through an existing torch.distributed group if there is
-    one, else through a TCPStore at MASTER_ADDR:(MASTER_PORT + port_offset)."""
-    uid = RcclSync.unique_id() if rank == 0 else None
+def share_from_rank0(payload, rank, world, group=None, port_offset=1, key='e2t_rccl_uid'):
+    """Hand rank 0's bytes to every rank -- bootstrap only.  Through an existing torch.distributed group if there is one;
+    else through the launcher's own store when torch.distributed.run hosts one on MASTER_PORT (the workers connect as
+    clients: no second port to bind, nothing left in TIME_WAIT for the next launch); else through a TCPStore that rank 0
+    hosts at MASTER_ADDR:(MASTER_PORT + port_offset)."""
     if world == 1:
-        return uid
+        return payload
     if dist.is_available() and dist.is_initialized():
-        box = [uid]
+        box = [payload]
         dist.broadcast_object_list(box, src=0, group=group)
         return box[0]
+    import datetime
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
-    port = int(os.environ.get('MASTER_PORT', '29500')) + port_offset
-    store = dist.TCPStore(addr, port, world, is_master=(rank == 0), timeout=__import__('datetime').timedelta(seconds=300))
+    port = int(os.environ.get('MASTER_PORT', '29500'))
+    timeout = datetime.timedelta(seconds=300)
+    if os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True':
+        store = dist.TCPStore(addr, port, world, is_master=False, timeout=timeout, wait_for_workers=False)
+        key = '%s/%s/%s' % (key, os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
+    else:
+        store = dist.TCPStore(addr, port + port_offset, world, is_master=(rank == 0), timeout=timeout)
     if rank == 0:
-        store.set('e2t_rccl_uid', uid)
-    return store.get('e2t_rccl_uid')
+        store.set(key, payload)
+    return store.get(key)
+
+
+def bootstrap_unique_id(rank, world, group=None, port_offset=1):
+    """Rank 0 makes the RCCL unique id; everybody gets it (share_from_rank0)."""
+    uid = RcclSync.unique_id() if rank == 0 else None
+    return share_from_rank0(uid, rank, world, group, port_offset)
 
 
 def make_sync(flat_grad, group=None, sum_of_global_means=True):

@@ -185,3 +185,34 @@ def test_uneven_shards_two_ranks_gloo():
         assert steps == 3                  # ceil(9 / (2 * 2)) on BOTH ranks
         assert err < 1e-6                  # sum of globally-normalised shard gradients == gradient of the global batch
         assert ok
+
+
+def test_unique_id_bootstrap_through_the_launchers_store(tmp_path):
+    """bench.py / fit() under `python -m torch.distributed.run`: rank 0's RCCL unique id reaches the other ranks through the
+    store the launcher already hosts on MASTER_PORT (no second port), and through a rank-0-hosted TCPStore on
+    MASTER_PORT + 1 when the processes were started by hand."""
+    import subprocess, sys, socket
+    script = tmp_path / 'boot.py'
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ecog2txt_amd import parallel\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "got = parallel.share_from_rank0(bytes(range(128)) if rank == 0 else None, rank, world)\n"
+        "assert got == bytes(range(128)), got\n"
+        "print('rank', rank, 'ok', flush=True)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+    def free_port():
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            return s.getsockname()[1]
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(free_port()), str(script)], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and out.stdout.count('ok') == 2, out.stdout + out.stderr
+    port = free_port()
+    env = dict(os.environ, WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.pop('TORCHELASTIC_USE_AGENT_STORE', None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in (1, 0)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all('ok' in o for o in outs), outs
