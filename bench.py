@@ -153,13 +153,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)        # (diagnostics: several ranks on one GPU with E2T_BENCH_BACKEND=gloo)
+    torch.cuda.set_device(dev_index)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     spec_kw, B, T, L = CONFIGS[args.config]
     B = args.batch or B
     spec = NetSpec(**spec_kw)
-    eng = Seq2SeqEngine(spec, device='cuda:%d' % local_rank, seed=1234 + rank)
+    eng = Seq2SeqEngine(spec, device='cuda:%d' % dev_index, seed=1234 + rank)
     eng.init_params(seed=0)
     # data parallel: RCCL through the C ABI (e2t_comm_*); E2T_COMM=torch selects torch.distributed's "nccl" instead
     sync = None
@@ -172,7 +174,8 @@ def main():
                 os.environ['E2T_COMM'] = 'torch'
         if sync is None:
             import torch.distributed as dist
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            backend = os.environ.get('E2T_BENCH_BACKEND', 'nccl')
+            dist.init_process_group(backend, **({'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}))
             sync = parallel.make_sync(eng.store.g)
         sync.broadcast_([eng.store.p, eng.store.ema])
     eng.pack('p')

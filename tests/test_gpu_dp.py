@@ -88,3 +88,24 @@ def test_two_rank_fit_on_one_gpu_equals_the_single_process_fit(tmp_path):
         assert abs(a['decoder'] - b['decoder']) < 5e-2 * max(1.0, abs(a['decoder'])), (a, b)
     assert len(two[0]['hyp']) == len(one['hyp'])
     assert abs(two[0]['acc'][-1] - one['acc'][-1]) < 0.1
+
+
+def test_bench_under_the_launcher_with_two_ranks_on_one_gpu():
+    """bench.py exactly as the driver starts it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`),
+    with both ranks mapped onto the one GPU of this box (E2T_BENCH_BACKEND=gloo, launch-per-step recurrences): rank 0 prints
+    ONE JSON line for the whole job, the other rank waits at the closing barrier while rank 0 measures the rooflines, exit 0."""
+    import json, socket, subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, E2T_COMM='torch', E2T_BENCH_BACKEND='gloo', E2T_PERSISTENT='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2'],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['config']['global_batch'] == 512 and d['config']['parallelism'] == 'dp2'
+    assert d['scaling'] == 'weak' and d['roofline'] is not None and 'cpu_baseline' not in d and np.isfinite(d['final_loss'])
+    assert abs(d['value'] - 512 * 1e3 / d['ms_per_step']) < 1e-2 * d['value']
