@@ -25,7 +25,8 @@ from .bf16 import round_bf16
 PAD_ID, EOS_ID, OOV_ID = 0, 1, 2      # special-token order, trainers.py:191-196
 
 # dropout stream ids (shared with ecog2txt_amd/csrc/philox.h)
-STREAM_CONV = 1
+STREAM_CONV = 1          # the conv layer that feeds the encoder; earlier conv layers: STREAM_CONV_PRE + index
+STREAM_CONV_PRE = 40
 STREAM_ENC = 10          # + layer index
 STREAM_DEC_EMB = 20
 STREAM_DEC_OUT = 21
@@ -61,13 +62,29 @@ class NetSpec:
     rnn_dropout: float = 0.5
     forget_bias: float = 1.0
     conv_relu: bool = True
+    # conv layers IN FRONT of the one that feeds the encoder (layer_sizes['encoder_embedding'] with more than one entry;
+    # the reference only shows that the layers' strides multiply to decimation_factor and that width == stride,
+    # trainers.py:406-407, 535-541): dicts with out, stride.  [BUILD-DEFINES] the split of decimation_factor over the layers is
+    # given explicitly; the last layer (output enc_embed) gets decimation / prod(strides of conv_pre)
+    conv_pre: List[dict] = field(default_factory=list)
 
 
 # --------------------------------------------------------------------------
 # parameter naming: checkpoint grammar of trainers.py:444-554 (SURVEY App. B)
 # --------------------------------------------------------------------------
+def conv_layers(spec, sid):
+    """[(name, in width, out width, stride)] of the subject's temporal-convolution stack, bottom up."""
+    outs = [int(p['out']) for p in spec.conv_pre] + [spec.enc_embed]
+    strides = [int(p['stride']) for p in spec.conv_pre]
+    last = spec.decimation // int(np.prod(strides)) if strides else spec.decimation
+    assert last * int(np.prod(strides or [1])) == spec.decimation, 'the strides must multiply to the decimation factor'
+    strides.append(last)
+    ins = [spec.channels[sid]] + outs[:-1]
+    return [('seq2seq/subnet_%s/encoder_embedding_%d_%d_%d' % (sid, i, o, j), i, o, n) for j, (i, o, n) in enumerate(zip(ins, outs, strides))]
+
+
 def conv_name(spec, sid):
-    return 'seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, spec.channels[sid], spec.enc_embed)
+    return conv_layers(spec, sid)[-1][0] if not spec.conv_pre else conv_layers(spec, sid)[0][0]
 
 
 def enc_in_width(spec, l):
@@ -103,11 +120,10 @@ def init_params(spec, seed=0, dtype=np.float64):
         lim = np.sqrt(6.0 / (fi + fo))
         return rng.uniform(-lim, lim, size=shape).astype(dtype)
 
-    N = spec.decimation
-    for sid, C in spec.channels.items():
-        nm = conv_name(spec, sid)
-        P[nm + '/weights'] = glorot(1, N, C, spec.enc_embed, fan=(N * C, spec.enc_embed))
-        P[nm + '/biases'] = np.zeros(spec.enc_embed, dtype)
+    for sid in spec.channels:
+        for nm, ci, co, n in conv_layers(spec, sid):
+            P[nm + '/weights'] = glorot(1, n, ci, co, fan=(n * ci, co))
+            P[nm + '/biases'] = np.zeros(co, dtype)
     for l, H in enumerate(spec.enc_rnn):
         D = enc_in_width(spec, l)
         for d in ('fw', 'bw'):
@@ -339,20 +355,38 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False, counts=None
     Xr = reverse_time_major(X, lens)                  # a5, [T,B,C]
     S = ceil_div(T, N)
     lens_d = ceil_div(lens, N)
-    # a6: strided temporal convolution, kernel width == stride == N
-    # (trainers.py:535-541, plotters.py:511-514), zero-padded ragged tail.
+    # a6: strided temporal convolution(s), kernel width == stride (trainers.py:535-541, plotters.py:511-514), zero-padded
+    # ragged tail; with conv_pre the layers are stacked, total stride N
     Xp = np.zeros((S * N, B, C))
     Xp[:T] = Xr
-    A = q(Xp.reshape(S, N, B, C).transpose(0, 2, 1, 3).reshape(S, B, N * C))
-    nm = conv_name(spec, sid)
-    Kc = q(P[nm + '/weights'].reshape(N * C, spec.enc_embed))
-    Epre = A @ Kc + P[nm + '/biases']
-    Eact = np.maximum(Epre, 0.0) if spec.conv_relu else Epre
-    Edrop, mE = _drop(Eact, spec.ff_dropout, seed, STREAM_CONV, train)
-    valid = (np.arange(S)[:, None] < lens_d[None, :])
-    E = q(Edrop * valid[:, :, None])
+    cur, lens_cur, convs = Xp, lens, []
+    layers = conv_layers(spec, sid)
+    for j, (nm, ci, co, n) in enumerate(layers):
+        Tj = cur.shape[0] // n
+        Aj = q(cur.reshape(Tj, n, B, ci).transpose(0, 2, 1, 3).reshape(Tj, B, n * ci))
+        Kj = q(P[nm + '/weights'].reshape(n * ci, co))
+        Epre = Aj @ Kj + P[nm + '/biases']
+        Eact = np.maximum(Epre, 0.0) if spec.conv_relu else Epre
+        last = j == len(layers) - 1
+        if last:
+            Edrop, mE = _drop(Eact, spec.ff_dropout, seed, STREAM_CONV, train)
+        else:
+            # the mask is indexed in the order the device keeps a front layer's rows: (final step, utterance, step within
+            # the group of g steps that ends up in one final step) -- what makes the next layer's im2row a plain view
+            g = Tj // S
+            Eg = Eact.reshape(S, g, B, co).transpose(0, 2, 1, 3)
+            Edg, mg = _drop(Eg, spec.ff_dropout, seed, STREAM_CONV_PRE + j, train)
+            Edrop = Edg.transpose(0, 2, 1, 3).reshape(Tj, B, co)
+            mE = None if mg is None else mg.transpose(0, 2, 1, 3).reshape(Tj, B, co)
+        lens_cur = ceil_div(lens_cur, n)
+        vj = (np.arange(Tj)[:, None] < lens_cur[None, :])
+        Ej = q(Edrop * vj[:, :, None])
+        convs.append(dict(A=Aj, K=Kj, E=Ej, mE=mE, valid=vj, name=nm, n=n, ci=ci, co=co))
+        cur = Ej
+    E, A, Kc, mE, valid = cur, convs[0]['A'], convs[0]['K'], convs[-1]['mE'], convs[-1]['valid']
+    assert np.array_equal(lens_cur, lens_d)
     cache = dict(spec=spec, batch=batch, q=q, train=train, seed=seed, lens=lens, lens_d=lens_d,
-                 A=A, Kc=Kc, E=E, Eact=Eact, mE=mE, valid=valid, S=S, B=B)
+                 A=A, Kc=Kc, E=E, Eact=None, mE=mE, valid=valid, S=S, B=B, convs=convs)
 
     # a7: stacked bidirectional LSTM encoder
     inp = E
@@ -521,20 +555,23 @@ def backward(P, cache):
             G['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, name)] = dG2.sum(0)
             dIn = dIn + dGd @ c['Wx'].T
         dYdrop = dIn
-    # conv front-end
+    # conv front-end, top layer down
     dE = dYdrop
-    E = cache['E']
-    scale = cache['mE'] if cache['mE'] is not None else 1.0
-    if spec.conv_relu:
-        dEpre = dE * (E > 0) * scale
-    else:
-        dEpre = dE * scale * cache['valid'][:, :, None]
-    dEpre = q(dEpre)
-    nm = conv_name(spec, sid)
-    A2 = cache['A'].reshape(S * B, -1)
-    d2 = dEpre.reshape(S * B, -1)
-    G[nm + '/weights'] = (A2.T @ d2).reshape(P[nm + '/weights'].shape)
-    G[nm + '/biases'] = d2.sum(0)
+    for cv in reversed(cache['convs']):
+        scale = cv['mE'] if cv['mE'] is not None else 1.0
+        if spec.conv_relu:
+            dEpre = dE * (cv['E'] > 0) * scale
+        else:
+            dEpre = dE * scale * cv['valid'][:, :, None]
+        dEpre = q(dEpre)
+        Tj = dEpre.shape[0]
+        A2 = cv['A'].reshape(Tj * B, -1)
+        d2 = dEpre.reshape(Tj * B, -1)
+        G[cv['name'] + '/weights'] = (A2.T @ d2).reshape(P[cv['name'] + '/weights'].shape)
+        G[cv['name'] + '/biases'] = d2.sum(0)
+        if cv is not cache['convs'][0]:
+            dA = dEpre @ cv['K'].T                                           # [Tj, B, n*ci]
+            dE = dA.reshape(Tj, B, cv['n'], cv['ci']).transpose(0, 2, 1, 3).reshape(Tj * cv['n'], B, cv['ci'])
     cache['dEpre'] = dEpre                 # what input_gradient() back-projects
     return G
 
@@ -548,10 +585,11 @@ def input_gradient(P, cache):
     tf.reverse_sequence over each utterance's valid length (trainers.py:808-810).
     [BUILD-DEFINES] padding samples (t >= len) are not inputs: their gradient is defined as 0."""
     spec = cache['spec']
-    N = spec.decimation
-    S, B = cache['S'], cache['B']
+    B = cache['B']
     X = np.asarray(cache['batch']['encoder_inputs'])
     T, C = X.shape[1], X.shape[2]
+    N = cache['convs'][0]['n']                                           # the bottom layer's stride (= decimation without conv_pre)
+    S = cache['dEpre'].shape[0]
     dA = cache['dEpre'] @ cache['Kc'].T                                  # [S,B,N*C], K as the forward pass rounded it
     dXr = dA.reshape(S, B, N, C).transpose(0, 2, 1, 3).reshape(S * N, B, C)     # reversed-time, time-major
     dX = np.zeros((B, T, C))

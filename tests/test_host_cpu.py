@@ -151,3 +151,39 @@ def test_param_store_roundtrip_with_extra_heads():
     assert set(out) == set(P)
     for k in P:
         np.testing.assert_allclose(out[k], P[k].astype(np.float32), rtol=0, atol=0)
+
+
+def test_oracle_stacked_conv_front_end_by_finite_differences():
+    """conv_pre: temporal-convolution layers in front of the one that feeds the encoder (strides multiply to the decimation
+    factor, trainers.py:406-407, 535-541).  The single-layer oracle is pinned against torch autograd; the stack is checked
+    against central differences of its own loss -- one weight and the bias of every conv layer and a few input samples."""
+    spec = tiny_spec(decimation=6, conv_pre=[dict(out=7, stride=2), dict(out=4, stride=3)], enc_embed=5, ff_dropout=0.2, rnn_dropout=0.1)
+    layers = O.conv_layers(spec, 401)
+    assert [(ci, co, n) for _, ci, co, n in layers] == [(6, 7, 2), (7, 4, 3), (4, 5, 1)]
+    P = O.init_params(spec, seed=3)
+    rng = np.random.default_rng(0)
+    for k in P:
+        if k.endswith('biases') or k.endswith('bias'):
+            P[k] = 0.3 * rng.standard_normal(P[k].shape)          # away from the ReLU kink at 0
+    batch = make_batch(spec, B=4, T=23, L=4, seed=5)
+    lo, cache = O.forward(P, spec, batch, train=True, seed=4)
+    G = O.backward(P, cache)
+    dX = O.input_gradient(P, cache)
+    assert cache['E'].shape == (4, 4, 5) and cache['convs'][0]['E'].shape == (12, 4, 7)
+
+    def loss(Pq, b=batch):
+        return O.forward(Pq, spec, b, train=True, seed=4)[0]['total']
+    e = 1e-6
+    for nm, ci, co, n in layers:
+        for key, idx in ((nm + '/weights', (0, n - 1, ci // 2, co - 1)), (nm + '/biases', (co // 2,))):
+            Pp = {k: v.copy() for k, v in P.items()}; Pp[key][idx] += e
+            Pm = {k: v.copy() for k, v in P.items()}; Pm[key][idx] -= e
+            fd = (loss(Pp) - loss(Pm)) / (2 * e)
+            assert abs(fd - G[key][idx]) < 1e-6 * max(1.0, abs(fd)), (key, fd, G[key][idx])
+    X = batch['encoder_inputs']
+    for (b, t, c) in ((0, 0, 0), (1, 3, 2), (3, 10, 5)):
+        if X[b, t].any():
+            bp = dict(batch, encoder_inputs=X.copy()); bp['encoder_inputs'][b, t, c] += e
+            bm = dict(batch, encoder_inputs=X.copy()); bm['encoder_inputs'][b, t, c] -= e
+            fd = (loss(P, bp) - loss(P, bm)) / (2 * e)
+            assert abs(fd - dX[b, t, c]) < 1e-6 * max(1.0, abs(fd)), ((b, t, c), fd, dX[b, t, c])
