@@ -159,9 +159,12 @@ __global__ __launch_bounds__(256) void k_sum_f32(const float* x, int n, const in
 // read; every destination row one contiguous N*C*2-byte write.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_conv_pack(const float* x, const int* lens, int B, int T, int C, int N,
-                                                    int S, bf16_t* A, int lda) {
-    const int m = blockIdx.x;               // (t', b) time-major
-    const int tp = m / B, b = m % B;
+                                                    int S, bf16_t* A, int lda, int G) {
+    // row m <-> (t', b): time-major (G == 1), or grouped m = (tg*B + b)*G + g with t' = tg*G + g -- the order in which the G
+    // consecutive steps that a later conv layer folds into one are adjacent rows (its im2row is then a plain view)
+    const int m = blockIdx.x;
+    const int tgb = m / G, g = m - tgb * G;
+    const int tp = (tgb / B) * G + g, b = tgb % B;
     const int len = lens[b];
     bf16_t* arow = A + (size_t)m * lda;
     const int K = N * C;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_pack(const float* x, const int* le
 
 // scatter of d(loss)/dA back to the batch-major, un-reversed input (a12 saliency)
 __global__ __launch_bounds__(256) void k_conv_unpack_grad(const float* dA, int ldda, const int* lens, int B, int T, int C,
-                                                           int N, int S, float* dx) {
+                                                           int N, int S, float* dx, int G) {
     const int bt = blockIdx.x;              // (b, t) batch-major destination row
     const int b = bt / T, t = bt % T;
     const int len = lens[b];
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void k_conv_unpack_grad(const float* dA, int l
     if (t >= len) { for (int c = threadIdx.x; c < C; c += 256) drow[c] = 0.f; return; }
     const int tt = len - 1 - t;             // reversed time
     const int tp = tt / N, w = tt - tp * N;
-    const float* src = dA + ((size_t)tp * B + b) * ldda + (size_t)w * C;
+    const float* src = dA + ((size_t)((tp / G) * B + b) * G + tp % G) * ldda + (size_t)w * C;      // (grouped row order, see k_conv_pack)
     for (int c = threadIdx.x; c < C; c += 256) drow[c] = src[c];
 }
 
@@ -734,18 +737,24 @@ extern "C" int e2t_sum_f32(const float* x, int n, const int32_t* count, float sc
     hipLaunchKernelGGL(k_sum_f32, dim3(1), dim3(256), 0, ST, x, n, count, scale, out);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
-extern "C" int e2t_conv_pack(const float* x, const int32_t* lens, int B, int T, int C, int N, void* A, int lda, void* stream) {
-    E2T_CHECK_ARG(x && lens && A && B > 0 && T > 0 && C > 0 && N > 0);
+extern "C" int e2t_conv_pack_grouped(const float* x, const int32_t* lens, int B, int T, int C, int N, int G, void* A, int lda, void* stream) {
+    E2T_CHECK_ARG(x && lens && A && B > 0 && T > 0 && C > 0 && N > 0 && G > 0);
     E2T_CHECK_ARG(lda % 8 == 0 && lda >= N * C);
-    const int S = (T + N - 1) / N;
-    hipLaunchKernelGGL(k_conv_pack, dim3(S * B), dim3(256), 0, ST, x, lens, B, T, C, N, S, (bf16_t*)A, lda);
+    const int S = ((T + N * G - 1) / (N * G)) * G;          // steps of this layer: a whole number of groups
+    hipLaunchKernelGGL(k_conv_pack, dim3(S * B), dim3(256), 0, ST, x, lens, B, T, C, N, S, (bf16_t*)A, lda, G);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_conv_pack(const float* x, const int32_t* lens, int B, int T, int C, int N, void* A, int lda, void* stream) {
+    return e2t_conv_pack_grouped(x, lens, B, T, C, N, 1, A, lda, stream);
+}
+extern "C" int e2t_conv_unpack_grad_grouped(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, int G, float* dx, void* stream) {
+    E2T_CHECK_ARG(dA && lens && dx && B > 0 && T > 0 && C > 0 && N > 0 && G > 0 && ldda >= N * C);
+    const int S = ((T + N * G - 1) / (N * G)) * G;
+    hipLaunchKernelGGL(k_conv_unpack_grad, dim3(B * T), dim3(256), 0, ST, dA, ldda, lens, B, T, C, N, S, dx, G);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_conv_unpack_grad(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, float* dx, void* stream) {
-    E2T_CHECK_ARG(dA && lens && dx && B > 0 && T > 0 && C > 0 && N > 0 && ldda >= N * C);
-    const int S = (T + N - 1) / N;
-    hipLaunchKernelGGL(k_conv_unpack_grad, dim3(B * T), dim3(256), 0, ST, dA, ldda, lens, B, T, C, N, S, dx);
-    E2T_LAUNCH_CHECK(); return E2T_OK;
+    return e2t_conv_unpack_grad_grouped(dA, ldda, lens, B, T, C, N, 1, dx, stream);
 }
 extern "C" int e2t_gather_rev_decim_f32(const float* a, const int32_t* tlens, int B, int T, int K, int N, float* out, void* stream) {
     E2T_CHECK_ARG(a && tlens && out && B > 0 && T > 0 && K > 0 && N > 0);

@@ -41,6 +41,7 @@ struct GemmArgs {
     const float* bias;
     const bf16_t* mask_src; int ld_mask;
     const int* lens; int rowsB;
+    int rowsG;                 // row order of the output: m = (tg*rowsB + b)*rowsG + g, step t = tg*rowsG + g (1: plain time-major)
     float alpha;
     int flags;
     DropCfg drop; int ld_logical;
@@ -73,6 +74,13 @@ struct EpiCtx {
     int Nst;                          // columns that go to C (N-1 when the last column is diverted to last_col_out)
     unsigned long long dkey; unsigned dthresh; float dkeep;
 };
+// row m of the output is a real step of its utterance (rows beyond the decimated length are zeroed)
+__device__ __forceinline__ bool row_valid(const GemmArgs& p, int gm) {
+    if (!p.lens) return true;
+    if (p.rowsG <= 1) return (gm / p.rowsB) < p.lens[gm % p.rowsB];
+    const int tgb = gm / p.rowsG, g = gm - tgb * p.rowsG;
+    return (tgb / p.rowsB) * p.rowsG + g < p.lens[tgb % p.rowsB];
+}
 __device__ __forceinline__ EpiCtx epi_ctx(const GemmArgs& p) {
     EpiCtx c;
     c.out_bf16 = p.flags & E2T_GEMM_OUT_BF16;
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void
         const int gm = m0 + wm + i * 16 + frow;
         if (gm >= p.M) continue;
         bool rowvalid = true;
-        if (p.lens && !atomic) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
+        if (!atomic) rowvalid = row_valid(p, gm);
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int gn0 = n0 + wn + j * 16 + fq * 4;
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
     }
     if (p.bias) for (int r = 0; r < nn; ++r) if (gn0 + r < ec.Nst) v[r] += p.bias[gn0 + r];
     bool rowvalid = true;
-    if (p.lens) rowvalid = (gm / p.rowsB) < p.lens[gm % p.rowsB];
+    rowvalid = row_valid(p, gm);
     epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
 }
 
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NS)) void k_conv_fwd(ConvF
         }
         return;
     }
-    const bool rowvalid = p.lens ? (gm / p.rowsB) < p.lens[gm % p.rowsB] : true;
+    const bool rowvalid = row_valid(p, gm);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int gn0 = j * 16 + fq * 4;
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_fwd_ws(ConvFwdArgs a) {
         }
         return;
     }
-    const bool rowvalid = p.lens ? (gm / p.rowsB) < p.lens[gm % p.rowsB] : true;
+    const bool rowvalid = row_valid(p, gm);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int gn0 = j * 16 + fq * 4;
@@ -841,7 +849,7 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
     GemmArgs& p = a.epi;
     p.C = E; p.ldc = lde; p.M = a.M; p.N = F; p.K = N * C; p.alpha = 1.0f; p.splits = 1; p.batch = 1; p.order = 1;
     p.bias = ep->bias;
-    p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1;
+    p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1; p.rowsG = ep->row_group > 0 ? ep->row_group : 1;
     p.flags = ep->flags;
     p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;
     p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : F;
@@ -985,7 +993,7 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     if (ep) {
         p.bias = ep->bias;
         p.mask_src = (const bf16_t*)ep->relu_bwd_src; p.ld_mask = ep->ld_relu_bwd_src;
-        p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1;
+        p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1; p.rowsG = ep->row_group > 0 ? ep->row_group : 1;
         p.alpha = ep->alpha;
         p.flags = ep->flags;
         p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;

@@ -20,6 +20,7 @@ import contextlib
 import ctypes as C
 import gc
 import os
+import re
 
 import numpy as np
 import torch
@@ -30,6 +31,7 @@ from .hip_lib import lib
 PAD_ID, EOS_ID, OOV_ID = 0, 1, 2          # trainers.py:191-196
 
 STREAM_CONV, STREAM_ENC, STREAM_DEC_EMB, STREAM_DEC_OUT, STREAM_AUX = 1, 10, 20, 21, 30
+STREAM_CONV_PRE = 40      # + index of a conv layer in front of the one that feeds the encoder
 
 
 @contextlib.contextmanager
@@ -92,9 +94,31 @@ class NetSpec:
     rnn_dropout: float = 0.5
     forget_bias: float = 1.0
     conv_relu: bool = True
+    # conv layers in front of the one that feeds the encoder (dicts with out, stride; the strides of the whole stack
+    # multiply to `decimation`, trainers.py:406-407; [BUILD-DEFINES] the split is given explicitly -- oracle/seq2seq.py)
+    conv_pre: List[dict] = field(default_factory=list)
 
     def as_dict(self):
         return asdict(self)
+
+
+def conv_stack(spec, Cc):
+    """[(in width, out width, stride)] of a subject's temporal-convolution stack, bottom up (oracle.conv_layers)."""
+    outs = [int(p['out']) for p in spec.conv_pre] + [spec.enc_embed]
+    strides = [int(p['stride']) for p in spec.conv_pre]
+    last = spec.decimation // int(np.prod(strides)) if strides else spec.decimation
+    assert last >= 1 and last * int(np.prod(strides or [1])) == spec.decimation, 'the conv strides must multiply to the decimation factor'
+    return list(zip([Cc] + outs[:-1], outs, strides + [last]))
+
+
+def conv_seg(sid, j):
+    """Parameter segment of conv layer j of subject sid ([stride*in + 1][out], bias last): the bottom layer keeps the
+    single-layer name."""
+    return 'conv%s.W' % sid if j == 0 else 'conv%s.W%d' % (sid, j)
+
+
+def conv_tf_name(sid, j, ci, co):
+    return 'seq2seq/subnet_%s/encoder_embedding_%d_%d_%d' % (sid, ci, co, j)
 
 
 def _tf2int(w, Hh):
@@ -158,7 +182,10 @@ class ParamStore:
             add('enc%d.Wh' % l, 2, Hh, 4 * Hh)
         self.shared_end = off
         for sid, Cc in spec.channels.items():
-            add('conv%s.W' % sid, spec.decimation * Cc + 1, spec.enc_embed)
+            lays = conv_stack(spec, Cc)
+            for j in range(len(lays) - 1, -1, -1):          # top conv layer first: the order backward produces them in
+                ci, co, n = lays[j]
+                add(conv_seg(sid, j), n * ci + 1, co)
         self.n = off
         z = lambda: torch.zeros(self.n, dtype=torch.float32, device=device)
         self.p, self.g, self.m, self.v, self.ema = z(), z(), z(), z(), z()
@@ -195,9 +222,9 @@ class ParamStore:
             def put(name, arr):
                 self.view(name, buf).copy_(torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32))
             for sid, Cc in s.channels.items():
-                nm = 'seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, Cc, s.enc_embed)
-                put('conv%s.W' % sid, np.concatenate([P[nm + '/weights'].reshape(N * Cc, s.enc_embed),
-                                                     P[nm + '/biases'][None]], 0))
+                for j, (ci, co, n) in enumerate(conv_stack(s, Cc)):
+                    nm = conv_tf_name(sid, j, ci, co)
+                    put(conv_seg(sid, j), np.concatenate([P[nm + '/weights'].reshape(n * ci, co), P[nm + '/biases'][None]], 0))
             for l, Hh in enumerate(s.enc_rnn):
                 D = s.enc_embed if l == 0 else 2 * s.enc_rnn[l - 1]
                 wx, wh = [], []
@@ -243,10 +270,11 @@ class ParamStore:
             return host[off:off + int(np.prod(shape))].reshape(shape)
         out = {}
         for sid, Cc in s.channels.items():
-            nm = 'seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, Cc, s.enc_embed)
-            w = get('conv%s.W' % sid)
-            out[nm + '/weights'] = w[:-1].reshape(1, N, Cc, s.enc_embed).copy()
-            out[nm + '/biases'] = w[-1].copy()
+            for j, (ci, co, n) in enumerate(conv_stack(s, Cc)):
+                nm = conv_tf_name(sid, j, ci, co)
+                w = get(conv_seg(sid, j))
+                out[nm + '/weights'] = w[:-1].reshape(1, n, ci, co).copy()
+                out[nm + '/biases'] = w[-1].copy()
         for l, Hh in enumerate(s.enc_rnn):
             D = s.enc_embed if l == 0 else 2 * s.enc_rnn[l - 1]
             wx, wh = get('enc%d.Wx' % l), get('enc%d.Wh' % l)
@@ -697,7 +725,19 @@ class Seq2SeqEngine:
         dev = self.device
         self.F8 = rk(s.enc_embed)
         # conv operand per subject: B operand [F][Kc8]; input-gradient operand [Kc8][F8] made on demand
-        self.convT = {sid: _bf(s.enc_embed, rk(s.decimation * Cc + 1), device=dev) for sid, Cc in s.channels.items()}
+        # conv stack per subject.  Bottom layer: B operand [out_0][rk(N_0*C + 1)] of the im2row product.  Layer j >= 1 reads the
+        # layer below through a VIEW (rows in grouped order, e2t_conv_pack_grouped): operand [out_j][N_j * ld_{j-1}] with the
+        # weights of tap w at columns w*ld_{j-1} .., and [N_j * ld_{j-1}][ld_j] for the input gradient.  ld of an inner layer's
+        # output = rk(r8(out) + 1): the ones column (bias gradient of the layer above) sits at the 16-B aligned index r8(out)
+        self.conv = {sid: conv_stack(s, Cc) for sid, Cc in s.channels.items()}
+        self.conv_ld = {sid: [rk(r8(co) + 1) for (_, co, _) in lays[:-1]] + [self.F8] for sid, lays in self.conv.items()}
+        self.conv_G = {sid: [int(np.prod([n for (_, _, n) in lays[j + 1:]] or [1])) for j in range(len(lays))] for sid, lays in self.conv.items()}
+        assert not s.conv_pre or s.conv_relu, 'a conv stack is built with ReLU layers (the mask of the input gradient is E != 0)'
+        self.convT = {sid: _bf(lays[0][1], rk(lays[0][2] * lays[0][0] + 1), device=dev) for sid, lays in self.conv.items()}
+        self.convTj = {sid: {j: _bf(lays[j][1], lays[j][2] * self.conv_ld[sid][j - 1], device=dev) for j in range(1, len(lays))}
+                       for sid, lays in self.conv.items()}
+        self.convBj = {sid: {j: _bf(lays[j][2] * self.conv_ld[sid][j - 1], self.conv_ld[sid][j], device=dev) for j in range(1, len(lays))}
+                       for sid, lays in self.conv.items()}
         self.convB = {}
         self.enc = []
         for l, Hh in enumerate(s.enc_rnn):
@@ -794,7 +834,8 @@ class Seq2SeqEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
-             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False, batch=None, alg=None):
+             drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False, batch=None, alg=None,
+             row_group=1):
         """batch = (n, a_stride, b_stride, c_stride): n products of the same shape in one launch (element strides).
         alg = (M, N, K) of the product WITHOUT layout padding, for flop accounting in the launch log (bench.py)."""
         ep = H.GemmEpilogue()
@@ -817,6 +858,7 @@ class Seq2SeqEngine:
             ep.relu_bwd_src, ep.ld_relu_bwd_src = mask_src
         if row_lens is not None:
             ep.row_lens, ep.rows_per_step = row_lens
+            ep.row_group = row_group
         ep.flags = flags
         if self._gemm_log is not None:
             tile, splits = C.c_int(0), C.c_int(0)
@@ -917,8 +959,16 @@ class Seq2SeqEngine:
             base = st.p          # offsets are relative, identical for p and ema
             head = []
             for sid, Cc in s.channels.items():
-                Kc = s.decimation * Cc
-                head.append(('cast', st.ptr('conv%s.W' % sid, base), 1, s.enc_embed, s.enc_embed, Kc, self.convT[sid], 0, 0))
+                lays = self.conv[sid]
+                ci, co, n = lays[0]
+                head.append(('cast', st.ptr(conv_seg(sid, 0), base), 1, co, co, n * ci, self.convT[sid], 0, 0))
+                for j in range(1, len(lays)):
+                    ci, co, n = lays[j]
+                    ldp = self.conv_ld[sid][j - 1]
+                    for w in range(n):
+                        wsrc = st.ptr(conv_seg(sid, j), base, w * ci * co)
+                        head.append(('cast', wsrc, 1, co, co, ci, self.convTj[sid][j], w * ldp, 0))         # [out][w*ld + c]
+                        head.append(('cast', wsrc, co, 1, ci, co, self.convBj[sid][j], 0, w * ldp))         # [w*ld + c][out]
             ops = []
             for lay in self.enc:
                 lay.pack_ops(ops, base)
@@ -1001,20 +1051,38 @@ class Seq2SeqEngine:
         Cc, N = s.channels[sid], s.decimation
         S = ceil_div(T, N)
         M, Mk = S * B, rk(S * B)
-        Kc, Kc8 = N * Cc, rk(N * Cc + 1)         # + the ones column that turns dW = A^T . dE into [weights; bias]
-        ws = dict(sid=sid, B=B, T=T, L=L, S=S, M=M, Mk=Mk, C=Cc, Kc=Kc, Kc8=Kc8)
+        # conv stack (one layer unless spec.conv_pre): layer 0 is the im2row product over x, rows in grouped order when layers
+        # follow (G0 = product of their strides), so that every later layer reads the one below through a view
+        lays, lds, Gs = self.conv[sid], self.conv_ld[sid], self.conv_G[sid]
+        N0, out0, ld0, G0 = lays[0][2], lays[0][1], lds[0], Gs[0]
+        S0, M0 = S * G0, S * G0 * B
+        Kc, Kc8 = N0 * Cc, rk(N0 * Cc + 1)       # + the ones column that turns dW = A^T . dE into [weights; bias]
+        ws = dict(sid=sid, B=B, T=T, L=L, S=S, M=M, Mk=Mk, C=Cc, Kc=Kc, Kc8=Kc8, N0=N0, out0=out0, ld0=ld0, G0=G0, M0=M0)
         ws['X'] = _f32(B, T, Cc, device=dev)
         ws['Y'] = _i32(B, L, device=dev)
         ws['lens'], ws['lens_d'] = _i32(B, device=dev), _i32(B, device=dev)
-        ws['A'] = _bf(M, Kc8, device=dev)
+        ws['A'] = _bf(M0, Kc8, device=dev)
         ws['A'][:, Kc] = 1.0                      # never written by e2t_conv_pack; the weight image has a zero there
-        ws['AT'] = _bf(Kc + 1, Mk, device=dev)
-        ws['AT'][Kc, :M] = 1.0
+        if len(lays) == 1:
+            ws['AT'] = _bf(Kc + 1, Mk, device=dev)
+            ws['AT'][Kc, :M] = 1.0
         ws['E'] = _bf(M, self.F8, device=dev)
         if self.F8 > s.enc_embed:
             ws['E'][:, s.enc_embed] = 1.0         # ones column for layer 0's dW_x (see _Lstm.bwd_weights)
         ws['dEpre'] = _bf(M, self.F8, device=dev)
         ws['dEpreT'] = _bf(s.enc_embed, Mk, device=dev)
+        # outputs / pre-activation gradients / decimated lengths of the conv layers below the top one
+        ws['cv'] = []
+        cum = 1
+        for j in range(len(lays) - 1):
+            ci, co, n = lays[j]
+            cum *= n
+            Mj = S * Gs[j] * B
+            Ej = _bf(Mj, lds[j], device=dev)
+            Ej[:, r8(co)] = 1.0                   # ones column: A^T . dE of the layer above yields its bias gradient there
+            ws['cv'].append(dict(E=Ej, dEpre=_bf(Mj, lds[j], device=dev), lens=_i32(B, device=dev), M=Mj, cumN=cum))
+        ws['E0'] = ws['cv'][0]['E'] if ws['cv'] else ws['E']
+        ws['dEpre0'] = ws['cv'][0]['dEpre'] if ws['cv'] else ws['dEpre']
         ws['enc'] = [lay.alloc(S, B) for lay in self.enc]
         ws['dY'] = [_f32(M, lay.ldy, device=dev) for lay in self.enc]
         if self.aux:
@@ -1112,14 +1180,19 @@ class Seq2SeqEngine:
         lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
         if after_first is not None:
             after_first()
+        stack = len(self.conv[ws['sid']]) > 1
         fused = (self.fused_conv == '1' or (self.fused_conv == 'auto' and B * T * Cc * 4 >= (1 << 28))) \
-            and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed))
-        if not fused:
+            and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed)) and not stack
+        if stack:
+            self._conv_stack_fwd(ws, src, train, before_weights)
+        elif not fused:
             lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
         ws['A_stale'] = fused and not train   # (inference through the fused kernel leaves no im2row copy; a backward pass after it packs first)
-        if before_weights is not None:
+        if before_weights is not None and not stack:
             before_weights()
-        if fused:
+        if stack:
+            pass
+        elif fused:
             # one pass over the fp32 electrode grid: reversal + im2row + bf16 rounding in the GEMM's staging path
             ep = H.GemmEpilogue()
             ep.bias = self.store.ptr('conv%s.W' % ws['sid'], src, ws['Kc'] * s.enc_embed)
@@ -1153,6 +1226,59 @@ class Seq2SeqEngine:
         # encoder final state -> block 0 of the decoder's ext output array, and c0
         lib.e2t_final_state(lw['Yext'].data_ptr(), last.ldy, lw['Cs'].data_ptr(), ws['lens_d'].data_ptr(), B, last.H,
                             ws['dec']['Yext'].data_ptr(), self.dec.ldy, ws['c0'].data_ptr(), st)
+
+    # ------------------------------------------------------------------ conv stack (spec.conv_pre)
+    def _conv_stack_fwd(self, ws, src, train, before_weights=None):
+        """Several strided conv layers (trainers.py:406-407: their strides multiply to the decimation factor; width == stride,
+        :535-541).  Layer 0 is the im2row product over x with its rows in grouped order; layer j >= 1 multiplies a VIEW of the
+        layer below ([M_j][N_j * ld_{j-1}]) with an operand image that has the weights of tap w at columns w * ld_{j-1}."""
+        s, sid, st = self.spec, ws['sid'], self.stream
+        B, T, Cc = ws['B'], ws['T'], ws['C']
+        lays, lds, Gs = self.conv[sid], self.conv_ld[sid], self.conv_G[sid]
+        for cv in ws['cv']:          # decimated lengths after every layer below the top one (the top one's are lens_d)
+            lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, cv['cumN'], ws['lens'].data_ptr(), cv['lens'].data_ptr(), st)
+        lib.e2t_conv_pack_grouped(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, ws['N0'], ws['G0'], ws['A'].data_ptr(), ws['Kc8'], st)
+        if before_weights is not None:
+            before_weights()
+        rate = s.ff_dropout if train else 0.0
+        top = len(lays) - 1
+        for j, (ci, co, n) in enumerate(lays):
+            out = ws['E'] if j == top else ws['cv'][j]['E']
+            lens = ws['lens_d'] if j == top else ws['cv'][j]['lens']
+            Mj = ws['M'] if j == top else ws['cv'][j]['M']
+            if j == 0:
+                a_ptr, lda, b_ptr, K, kalg = ws['A'].data_ptr(), ws['Kc8'], self.convT[sid].data_ptr(), ws['Kc8'], ws['Kc']
+            else:
+                K = n * lds[j - 1]
+                a_ptr, lda, b_ptr, kalg = ws['cv'][j - 1]['E'].data_ptr(), K, self.convTj[sid][j].data_ptr(), n * ci
+            self.gemm(a_ptr, lda, b_ptr, K, out.data_ptr(), lds[j], Mj, co, K,
+                      bias=self.store.ptr(conv_seg(sid, j), src, n * ci * co), relu=True, out_bf16=True,
+                      drop=(rate, STREAM_CONV if j == top else STREAM_CONV_PRE + j, co), row_lens=(lens.data_ptr(), B), row_group=Gs[j],
+                      alg=(Mj, co, kalg))
+
+    def _conv_stack_bwd(self, ws):
+        """Weight gradients of the conv layers above the bottom one and the pre-activation gradient handed down to each
+        layer below (ends with ws['dEpre0'], which the bottom layer's dK = A^T . dEpre and the saliency path read)."""
+        s, sid, store = self.spec, ws['sid'], self.store
+        lays, lds = self.conv[sid], self.conv_ld[sid]
+        train = ws.get('fwd_train', True)
+        keep = 1.0 / (1.0 - s.ff_dropout) if (train and s.ff_dropout > 0) else 1.0
+        top = len(lays) - 1
+        for j in range(top, 0, -1):
+            ci, co, n = lays[j]
+            dEp = ws['dEpre'] if j == top else ws['cv'][j]['dEpre']
+            Mj = ws['M'] if j == top else ws['cv'][j]['M']
+            prev, ldp = ws['cv'][j - 1], lds[j - 1]
+            g = store.ptr(conv_seg(sid, j), store.g)
+            # dW of tap w = (columns w*ldp .. of the view)^T . dEpre: one batched K-major product, straight into the segment
+            self.gemm(prev['E'].data_ptr(), n * ldp, dEp.data_ptr(), lds[j], g, co, ci, co, Mj, splitk=True, tn=True,
+                      batch=(n, ldp, 0, ci * co), alg=(ci, co, Mj))
+            # bias gradient: the ones column of the layer below (index r8(in), 16-B aligned) against dEpre
+            self.gemm(prev['E'].data_ptr() + 2 * r8(ci), n * ldp, dEp.data_ptr(), lds[j], g + 4 * n * ci * co, co, 1, co, Mj,
+                      splitk=True, tn=True, alg=(1, co, Mj))
+            # d(pre-activation) of the layer below, through the view: [M_j][n*ldp] = dEpre . W (masked by E != 0, x 1/keep)
+            self.gemm(dEp.data_ptr(), lds[j], self.convBj[sid][j].data_ptr(), lds[j], prev['dEpre'].data_ptr(), n * ldp, Mj, n * ldp, lds[j],
+                      out_bf16=True, alpha=keep, mask_src=(prev['E'].data_ptr(), n * ldp), alg=(Mj, n * ci, co))
 
     def forward(self, ws, train=True, which=None, with_aux=True, pack_first=False, global_counts=False, pack_skip=None):
         """Teacher-forced forward incl. losses and d(logits); leaves everything backward needs in ws.
@@ -1318,6 +1444,7 @@ class Seq2SeqEngine:
         head = [n for n in store.order if n.startswith('proj') or n.startswith('dec.')]
         enc_names = lambda l: [n for n in store.order if n.startswith('enc%d.' % l)]
         aux_names = [n for n in store.order if n.startswith('aux')]
+        conv_names = [conv_seg(ws['sid'], j) for j in range(len(self.conv[ws['sid']]) - 1, -1, -1)]
         # the auxiliary head's backward (its own weight gradients + its share of dY[aux_layer]) only needs the forward
         # pass: side stream, under the decoder's BPTT; the layer above then ACCUMULATES its input gradient onto it
         stages.append((lambda train: self._bwd_head(ws, train), lambda train: self._bwd_aux(ws, train), rng_of(aux_names)))
@@ -1333,9 +1460,9 @@ class Seq2SeqEngine:
             # the bottom layer's dW_h runs next to its dW_x + conv gradient instead of behind them
             stages.append((lambda train: self._bwd_enc_weights(ws, 0, 0),
                            lambda train, part=None: (self._bwd_enc_weights(ws, 0, 1) if part in (None, 1) else None),
-                           rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
+                           rng_of(enc_names(0) + conv_names)))
         else:
-            stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + ['conv%s.W' % ws['sid']])))
+            stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + conv_names)))
         return stages
 
     def fork_side(self, fn):
@@ -1410,6 +1537,7 @@ class Seq2SeqEngine:
         weight-gradient GEMMs of the remaining stages)."""
         ws['have_dy'] = [False] * len(self.enc)
         ws['_aux_join'] = None
+        ws['fwd_train'] = train
         deferred = []
         held = []
         stages = self.backward_stages(ws)
@@ -1537,13 +1665,16 @@ class Seq2SeqEngine:
             return
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
         sid = ws['sid']
+        if len(self.conv[sid]) > 1:
+            assert self.tn, 'the conv stack uses the K-major weight-gradient products'
+            self._conv_stack_bwd(ws)            # upper conv layers; leaves the bottom layer's pre-activation gradient in ws['dEpre0']
         if ws.get('A_stale'):          # fused forward: the packed bf16 copy is made here, off the forward critical path
             lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), ws['B'], ws['T'], ws['C'], s.decimation,
                               ws['A'].data_ptr(), ws['Kc8'], st)
             ws['A_stale'] = False
         if self.tn:
-            self.gemm(ws['A'].data_ptr(), ws['Kc8'], ws['dEpre'].data_ptr(), self.F8, store.ptr('conv%s.W' % sid, store.g),
-                      s.enc_embed, ws['Kc'] + 1, s.enc_embed, M, splitk=True, tn=True)
+            self.gemm(ws['A'].data_ptr(), ws['Kc8'], ws['dEpre0'].data_ptr(), ws['ld0'], store.ptr('conv%s.W' % sid, store.g),
+                      ws['out0'], ws['Kc'] + 1, ws['out0'], ws['M0'], splitk=True, tn=True)
             return
         lib.e2t_transpose_bf16(ws['dEpre'].data_ptr(), self.F8, M, s.enc_embed, ws['dEpreT'].data_ptr(), Mk, st)
         lib.e2t_transpose_bf16(ws['A'].data_ptr(), ws['Kc8'], M, ws['Kc'], ws['AT'].data_ptr(), Mk, st)
@@ -1555,18 +1686,17 @@ class Seq2SeqEngine:
         """d(loss)/d(encoder_inputs) [B,T,C] fp32 after forward()+backward(): dA = dEpre . W_conv^T, then the
         im2row/time-reversal is undone (restore_and_get_saliencies, reference trainers.py:722-725)."""
         s, sid, dev = self.spec, ws['sid'], self.device
-        Kc, Kc8, M = ws['Kc'], ws['Kc8'], ws['M']
+        Kc, Kc8, M, out0, ld0 = ws['Kc'], ws['Kc8'], ws['M0'], ws['out0'], ws['ld0']      # the BOTTOM conv layer's sizes
         if sid not in self.convB:
-            self.convB[sid] = _bf(Kc, self.F8, device=dev)
+            self.convB[sid] = _bf(Kc, ld0, device=dev)
         src = getattr(self.store, self._packed or 'p')
-        lib.e2t_cast_pack(self.store.ptr('conv%s.W' % sid, src), s.enc_embed, 1, Kc, s.enc_embed, self.convB[sid].data_ptr(),
-                          self.F8, self.stream)
+        lib.e2t_cast_pack(self.store.ptr('conv%s.W' % sid, src), out0, 1, Kc, out0, self.convB[sid].data_ptr(), ld0, self.stream)
         if 'dA' not in ws:
             ws['dA'] = _f32(M, Kc8, device=dev)
             ws['dX'] = _f32(ws['B'], ws['T'], ws['C'], device=dev)
-        self.gemm(ws['dEpre'].data_ptr(), self.F8, self.convB[sid].data_ptr(), self.F8, ws['dA'].data_ptr(), Kc8, M, Kc, self.F8)
-        lib.e2t_conv_unpack_grad(ws['dA'].data_ptr(), Kc8, ws['lens'].data_ptr(), ws['B'], ws['T'], ws['C'], s.decimation,
-                                 ws['dX'].data_ptr(), self.stream)
+        self.gemm(ws['dEpre0'].data_ptr(), ld0, self.convB[sid].data_ptr(), ld0, ws['dA'].data_ptr(), Kc8, M, Kc, ld0)
+        lib.e2t_conv_unpack_grad_grouped(ws['dA'].data_ptr(), Kc8, ws['lens'].data_ptr(), ws['B'], ws['T'], ws['C'], ws['N0'], ws['G0'],
+                                         ws['dX'].data_ptr(), self.stream)
         return ws['dX']
 
     # ------------------------------------------------------------------ optimiser
@@ -1614,7 +1744,7 @@ class Seq2SeqEngine:
         store = self.store
         names = []
         for nm in store.order:
-            if nm.startswith('conv') and (sid is None or nm != 'conv%s.W' % sid):
+            if nm.startswith('conv') and (sid is None or not (nm == 'conv%s.W' % sid or re.fullmatch(r'conv%s\.W\d+' % re.escape(str(sid)), nm))):
                 continue
             if self.trainable is not None and nm not in self.trainable:
                 continue

@@ -24,7 +24,8 @@ class GemmEpilogue(C.Structure):
                 ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong), ('drop_step', C.c_void_p),
                 ('drop_stream', C.c_uint), ('drop_ld', C.c_int), ('last_col_out', C.c_void_p),
                 ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_size_t), ('batch', C.c_int),
-                ('a_batch_stride', C.c_longlong), ('b_batch_stride', C.c_longlong), ('c_batch_stride', C.c_longlong)]
+                ('a_batch_stride', C.c_longlong), ('b_batch_stride', C.c_longlong), ('c_batch_stride', C.c_longlong),
+                ('row_group', C.c_int)]
 
 
 class LstmDesc(C.Structure):
@@ -55,8 +56,10 @@ SIGNATURES = {
     'e2t_sum_i32': [_p, _i, _p, _p],
     'e2t_sum_f32': [_p, _i, _p, _f, _p, _p],
     'e2t_conv_pack': [_p, _p, _i, _i, _i, _i, _p, _i, _p],
+    'e2t_conv_pack_grouped': [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     'e2t_conv_fwd_fused': [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, C.POINTER(GemmEpilogue), _p],
     'e2t_conv_unpack_grad': [_p, _i, _p, _i, _i, _i, _i, _p, _p],
+    'e2t_conv_unpack_grad_grouped': [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p],
     'e2t_gather_rev_decim_f32': [_p, _p, _i, _i, _i, _i, _p, _p],
     'e2t_gather_rev_decim_i32': [_p, _p, _i, _i, _i, _p, _p],
     'e2t_decoder_tokens': [_p, _i, _i, _i, _p, _p, _p],

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 2
+#define E2T_ABI_VERSION 3
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -74,8 +74,14 @@ int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float*
  *      A [(T/N)*B][lda] bf16, row (t',b), column (w,c); columns N*C.. are zero except column N*C = 1.0 when lda > N*C
  *      (the ones column that makes A^T . dE = [dW; db] in e2t_gemm_tn_bf16)  ---- */
 int e2t_conv_pack(const float* x, const int32_t* lens, int B, int T, int C, int N, void* A, int lda, void* stream);
+/* same with the rows in GROUPED order for a stack of conv layers (total stride = product of the layers' strides,
+ * trainers.py:406-407): row m = (tg*B + b)*G + g holds step t' = tg*G + g, G = product of the strides of the layers above;
+ * S = ceil(T / (N*G)) * G rows per utterance.  The G steps a later layer folds into one are then adjacent rows, so that
+ * layer's im2row operand is a VIEW of this layer's output ([S/G*B][G*ld]) and its input gradient a view of dE. */
+int e2t_conv_pack_grouped(const float* x, const int32_t* lens, int B, int T, int C, int N, int G, void* A, int lda, void* stream);
 /* a12: scatter d/dA [S*B][ldda] fp32 back to d/dx [B][T][C] (restore_and_get_saliencies, trainers.py:722-725) */
 int e2t_conv_unpack_grad(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, float* dx, void* stream);
+int e2t_conv_unpack_grad_grouped(const float* dA, int ldda, const int32_t* lens, int B, int T, int C, int N, int G, float* dx, void* stream);
 
 /* ---- a8: _prepare_encoder_targets: reverse then [:, 0::N, :] (trainers.py:791-799) ---- */
 int e2t_gather_rev_decim_f32(const float* a, const int32_t* tlens, int B, int T, int K, int N, float* out, void* stream);
@@ -108,6 +114,8 @@ typedef struct e2t_gemm_epilogue {
                                       the respective array; bias / masks / row_lens are shared).  0 or 1: a single product.
                                       (The two directions of a recurrent weight gradient: twice the tiles, half the splits.) */
     long long a_batch_stride, b_batch_stride, c_batch_stride;
+    int row_group;                 /* 0 / 1: output rows are (step, utterance) time-major; G > 1: grouped order of e2t_conv_pack_grouped --
+                                      only the row_lens mask looks at it */
 } e2t_gemm_epilogue;
 int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep /* host pointer or NULL */, void* stream);

@@ -80,6 +80,13 @@ SPECS = {
                         vocab=50, aux_layer=1, aux_hidden=[24], aux_dim=5, ff_dropout=0.1, rnn_dropout=0.3,
                         aux_extra=[dict(layer=0, hidden=[12], dim=7, dist='categorical', scale=0.5),
                                    dict(layer=2, hidden=[], dim=3, dist='Gaussian', scale=0.25)]),
+    # a stack of three strided conv layers (strides 2 x 3 x 2 = the decimation factor; layer_sizes['encoder_embedding'] with
+    # three entries, trainers.py:406-407, 535-541): the lower layers' rows are kept in grouped order on the device
+    'conv_stack': dict(channels={401: 16}, decimation=12, conv_pre=[dict(out=20, stride=2), dict(out=12, stride=3)], enc_embed=24,
+                       enc_rnn=[32, 32], dec_embed=16, dec_rnn=64, vocab=50, aux_layer=1, aux_hidden=[24], aux_dim=5,
+                       ff_dropout=0.1, rnn_dropout=0.3),
+    'conv_stack_odd': dict(channels={401: 6}, decimation=6, conv_pre=[dict(out=7, stride=3)], enc_embed=5, enc_rnn=[4, 6], dec_embed=3,
+                           dec_rnn=12, vocab=11, aux_layer=0, aux_hidden=[6], aux_dim=2, ff_dropout=0.2, rnn_dropout=0.0),
     'cfg4_widths': dict(channels={401: 16}, decimation=4, enc_embed=40, enc_rnn=[1024], dec_embed=30, dec_rnn=2048,
                         vocab=90, aux_layer=None, ff_dropout=0.0, rnn_dropout=0.2),
 }
@@ -146,7 +153,7 @@ def test_smallest_shapes(B, T, L):
     assert not (diff & (margin > 5e-2)).any()
 
 
-@pytest.mark.parametrize('name', ['small_dropout', 'mid', 'no_aux_linear_conv', 'cfg5_frontend'])
+@pytest.mark.parametrize('name', ['small_dropout', 'mid', 'no_aux_linear_conv', 'cfg5_frontend', 'conv_stack', 'conv_stack_odd'])
 def test_input_gradient_matches_oracle(name):
     """Row a12 (restore_and_get_saliencies, trainers.py:703-732): d loss / d encoder_inputs, per sample ('sequences') and
     as the per-electrode RMS ('norms'), against oracle.input_gradient (itself pinned by torch autograd and finite
