@@ -76,7 +76,7 @@ class SequenceNetwork:
                  TEMPORALLY_CONVOLVE=None, EMA_decay=None, beam_width=None, assessment_epoch_interval=None,
                  tf_summaries_dir=None, N_epochs=None, temperature=None, N_cases=256, learning_rate=5e-4,
                  max_hyp_length=20, seed=0, assessment_GPU=0, checkpoint_path='./model.ckpt', inputs_to_occlude=None,
-                 process_group=None):
+                 process_group=None, encoder_strides=None):
         self._engine = None
         self._engine_key = None
         self._epoch = 0
@@ -111,11 +111,22 @@ class SequenceNetwork:
         kw['aux_extra'] = extra
         N = {int(s.decimation_factor) if self.TEMPORALLY_CONVOLVE else 1 for s in subjects}
         assert len(N) == 1, 'all subjects must share one decimation factor'
-        assert len(ls['encoder_embedding']) == 1, ('a multi-layer temporal-convolution front-end is not built: how the reference splits '
-                                                   'decimation_factor over its layers is not in its tree (DESIGN.md section 7)')
+        # several entries in layer_sizes['encoder_embedding'] = a stack of strided conv layers whose strides multiply to the
+        # decimation factor (trainers.py:406-407, 535-541).  How the reference divides the factor over the layers is in the absent
+        # `machine_learning` package, so the split is taken from `encoder_strides` (ctor argument / manifest key; a restored
+        # checkpoint supplies it from its weight shapes, update_net_from_saved_model) -- [BUILD-DEFINES] default when none is
+        # given: the bottom layer takes the whole factor, the layers above have stride (= width) 1
+        emb = list(ls['encoder_embedding'])
+        Ntot = next(iter(N))
+        if len(emb) > 1:
+            assert self.TEMPORALLY_CONVOLVE, 'a stack of embedding layers is a temporal-convolution stack'
+            strides = [int(x) for x in (self.encoder_strides or [Ntot] + [1] * (len(emb) - 1))]
+            assert len(strides) == len(emb) and int(np.prod(strides)) == Ntot, \
+                'encoder_strides %r must have one entry per embedding layer and multiply to the decimation factor %d' % (strides, Ntot)
+            kw['conv_pre'] = [dict(out=int(o), stride=int(n)) for o, n in zip(emb[:-1], strides[:-1])]
         assert len(ls['decoder_embedding']) == 1 and len(ls['decoder_rnn']) == 1, 'one decoder embedding / RNN layer'
         return NetSpec(channels={s.subnet_id: int(s.data_manifests['encoder_inputs'].num_features) for s in subjects},
-                       decimation=N.pop(), enc_embed=ls['encoder_embedding'][0], enc_rnn=list(ls['encoder_rnn']),
+                       decimation=N.pop(), enc_embed=emb[-1], enc_rnn=list(ls['encoder_rnn']),
                        dec_embed=ls['decoder_embedding'][0], dec_rnn=ls['decoder_rnn'][0],
                        dec_proj_hidden=list(ls.get('decoder_projection', [])), vocab=int(dms['decoder_targets'].num_features),
                        dec_scale=float(dms['decoder_targets'].penalty_scale), ff_dropout=float(self.FF_dropout),
@@ -482,7 +493,7 @@ class SequenceNetwork:
         out = {}
         for seg in eng.store.order:
             if seg.startswith('conv'):
-                out[seg] = 'seq2seq/subnet_%s/encoder_embedding' % seg[4:-2]
+                out[seg] = 'seq2seq/subnet_%s/encoder_embedding' % re.fullmatch(r'conv(.*)\.W\d*', seg).group(1)
             elif seg.startswith('enc'):
                 out[seg] = 'seq2seq/encoder_rnn_%s' % seg[3:].split('.')[0]
             elif seg.startswith('auxx'):

@@ -177,6 +177,8 @@ class MultiSubjectTrainer:
     def update_net_from_saved_model(self):
         self.net.layer_sizes, data_sizes, strides, EMA = self.recover_model_sizes()
         self.net.TEMPORALLY_CONVOLVE = len(next(iter(strides.values()), []))
+        if self.net.TEMPORALLY_CONVOLVE > 1:                  # a conv stack: the layers' strides are the widths of their rank-4 weights
+            self.net.encoder_strides = [int(x) for x in next(iter(strides.values()))]
         self.net.EMA_decay = 0.99 * EMA
         for subject in self.ecog_subjects:
             sid = str(subject.subnet_id)

@@ -49,8 +49,7 @@ MANIFEST_TEMPLATE = """
     encoder_1_projection:
     - 24
 {extra_proj}    encoder_embedding:
-    - 24
-    encoder_rnn:
+{emb}    encoder_rnn:
     - 32
     - 32
   mfcc_winlen: 0.02
@@ -68,9 +67,10 @@ MANIFEST_TEMPLATE = """
 """
 
 
-def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None, extra_aux=False):
+def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None, extra_aux=False, embedding=(24,)):
     """grids: {subject id: (rows, cols)} for participants whose electrode grids differ from `grid`; extra_aux: a second
-    auxiliary head ('encoder_0_targets', also on the audio sequence, one hidden layer of 12, penalty scale 0.25)."""
+    auxiliary head ('encoder_0_targets', also on the audio sequence, one hidden layer of 12, penalty scale 0.25); embedding:
+    layer_sizes['encoder_embedding'] (more than one entry = a stack of strided conv layers)."""
     root = str(root)
     os.makedirs(root, exist_ok=True)
     blocks = {}
@@ -97,5 +97,6 @@ def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4),
             f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=g[0], g1=g[1], rate=rate,
                                             extra_map='    encoder_0_targets: audio_sequence\n' if extra_aux else '',
                                             extra_scale='  encoder_0_targets_penalty_scale: 0.25\n' if extra_aux else '',
-                                            extra_proj='    encoder_0_projection:\n    - 12\n' if extra_aux else ''))
+                                            extra_proj='    encoder_0_projection:\n    - 12\n' if extra_aux else '',
+                                            emb=''.join('    - %d\n' % e for e in embedding)))
     return path

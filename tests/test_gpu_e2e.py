@@ -367,3 +367,37 @@ def test_fit_with_two_auxiliary_target_keys(small):
     assert names['seq2seq/encoder_0_projection_12_5_1/weights'] == [5, 12] and names['seq2seq/encoder_1_projection_24_5_1/weights'] == [5, 24]
     res = tr.assess_saved_model()
     assert np.isfinite(res['validation'].word_error_rate)
+
+
+def test_fit_with_a_stack_of_conv_layers(small):
+    """layer_sizes['encoder_embedding'] with two entries = two strided conv layers whose strides (4 x 3) multiply to the
+    decimation factor 12 (trainers.py:406-407, 535-541; the split is the `encoder_strides` argument): the fit learns, the
+    checkpoint holds both layers under the reference's names with rank-4 weights whose width is the stride, and a FRESH trainer
+    recovers sizes and strides from the checkpoint alone and reproduces the assessment."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    path = make_experiment(small, subject_ids=(401,), epochs=40, interval=20, embedding=(20, 24))
+    ck = str(small / 'ck3'); os.makedirs(ck)
+    kw = dict(checkpoint_dir=ck, VERBOSE=False, DG_kwargs={'max_samples': 420})
+    sn = {'N_cases': 32, 'learning_rate': 3e-3, 'FF_dropout': 0.05, 'RNN_dropout': 0.1, 'EMA_decay': 0.9}
+    tr = MultiSubjectTrainer(path, [401], SN_kwargs=dict(sn, encoder_strides=[4, 3]), **kw)
+    for s in tr.ecog_subjects:
+        s.write_tf_records_maybe()
+    a = tr.parallel_transfer_learn()
+    assert tr.net._engine.spec.conv_pre == [dict(out=20, stride=4)] and tr.net._engine.spec.enc_embed == 24
+    lo = a['training'].losses
+    assert lo[-1]['decoder'] < 0.6 * lo[0]['decoder'] and lo[-1]['aux'] < lo[0]['aux']
+    z = np.load(os.path.join(ck, 'model.ckpt-40.npz'))
+    assert z['seq2seq/subnet_401/encoder_embedding_16_20_0/weights'].shape == (1, 4, 16, 20)
+    assert z['seq2seq/subnet_401/encoder_embedding_20_24_1/weights'].shape == (1, 3, 20, 24)
+    assert z['seq2seq/subnet_401/encoder_embedding_20_24_1/biases'].shape == (24,)
+    res = tr.assess_saved_model()
+    tr2 = MultiSubjectTrainer(path, [401], SN_kwargs=sn, **kw)            # no encoder_strides: they come from the checkpoint
+    ls, ds, strides, ema = tr2.recover_model_sizes()
+    assert ls['encoder_embedding'] == [20, 24] and strides['401'] == [4, 3] and ds['401']['encoder_inputs'] == 16
+    res2 = tr2.assess_saved_model()
+    assert tr2.net.encoder_strides == [4, 3] and tr2.ecog_subjects[-1].decimation_factor == 12
+    assert res2['validation'].hypotheses == res['validation'].hypotheses and res2['validation'].accuracy == res['validation'].accuracy
+    sal = tr2.get_saliencies('decoder_saliency_map')
+    assert sal.shape == (16,) and np.isfinite(sal).all() and sal.max() > 0
+    act = tr2.get_internal_activations()
+    assert act['convolved_inputs'].shape[2] == 24
