@@ -222,13 +222,15 @@ def test_multi_subject_round_robin_follows_oracle():
     assert np.array_equal(snap[c401], P[c401].astype(np.float32)) and not np.array_equal(snap[c400], P[c400].astype(np.float32))
 
 
-def test_train_steps_follow_oracle():
-    """Three Adam+EMA steps with dropout: parameters track the oracle's trajectory."""
-    eng, ws, ospec, P, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=7)
+@pytest.mark.parametrize('name,use_graph', [('small_dropout', False), ('conv_stack', False), ('conv_stack', True), ('three_heads', False), ('three_heads', True)])
+def test_train_steps_follow_oracle(name, use_graph):
+    """Three Adam+EMA steps with dropout: parameters track the oracle's trajectory (eager and from the captured graph; with a
+    conv stack / several heads every extra parameter segment goes through gradients, Adam, EMA and the operand re-pack)."""
+    eng, ws, ospec, P, batch = build(SPECS[name], 19, 26, 6, seed=7)
     state = {}
     Po = {k: v.copy() for k, v in P.items()}
     for it in range(3):
-        eng.train_step(ws, use_graph=False)
+        eng.train_step(ws, use_graph=use_graph)
         # oracle: dropout key = seed + step counter (counter is incremented by the optimiser)
         _, cache = O.forward(Po, ospec, batch, train=True, seed=11 + it, emulate_bf16=True)
         G = O.backward(Po, cache)
@@ -238,7 +240,10 @@ def test_train_steps_follow_oracle():
     Ed = eng.store.export_tf('ema')
     for k in Po:
         # Adam normalises every coordinate to ~lr, so compare against the step size
-        assert np.abs(Pd[k] - Po[k]).max() < 3 * 5e-4 * 0.35, k
+        err = np.abs(Pd[k] - Po[k])
+        # (a coordinate whose gradient is within round-off of zero may take its first step -- of size lr whatever |g| -- in the
+        #  other direction: at most a handful of such coordinates, each off by no more than 2 lr)
+        assert (err > 3 * 5e-4 * 0.35).mean() < 2e-3 and err.max() < 2.1 * 5e-4, (k, float(err.max()), float((err > 3 * 5e-4 * 0.35).mean()))
         assert np.abs(Ed[k] - state['ema'][k]).max() < 1e-4, k
     moved = max(np.abs(Pd[k] - P[k]).max() for k in P)
     assert moved > 5e-4
