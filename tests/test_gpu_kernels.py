@@ -513,3 +513,56 @@ def test_gemm_tn_256_tile_instance(hl, M, N, K, nb):
         want = round_bf16(A[:, z * r8(M):z * r8(M) + M]).T @ round_bf16(Bm[:, z * r8(N):z * r8(N) + N])
         np.testing.assert_allclose(got[z][:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
         assert np.all(got[z][:, N:] == 7.0)
+
+
+@pytest.mark.parametrize('G', [1, 2, 3])
+def test_grouped_row_order_of_the_conv_stack(hl, G):
+    """e2t_conv_pack_grouped / e2t_conv_unpack_grad_grouped / e2t_gemm_epilogue.row_group: row m = (tg*B + b)*G + g holds step
+    t' = tg*G + g (the order in which a stack of strided conv layers keeps the rows of its lower layers, trainers.py:406-407).
+    The grouped im2row is the plain one with its rows permuted, the un-im2row inverts it, and the GEMM's row-length mask zeroes
+    the rows whose step lies beyond the utterance's decimated length."""
+    rng = np.random.default_rng(G)
+    B, T, N, C_ = 5, 29, 2, 8
+    X = np.abs(rng.standard_normal((B, T, C_))) + 0.1
+    lens = np.array([29, 1, 0, 13, 24])
+    for b in range(B):
+        X[b, lens[b]:] = 0
+    xt = torch.tensor(X, dtype=torch.float32, device='cuda')
+    lt = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    S1 = -(-T // N)                                   # plain: steps of this layer
+    S = -(-T // (N * G)) * G                          # grouped: a whole number of groups
+    K8 = r8(N * C_)
+    plain = torch.zeros((S1 * B, K8), dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_conv_pack(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, plain.data_ptr(), K8, st())
+    grp = torch.full((S * B, K8), 3.0, dtype=torch.bfloat16, device='cuda')
+    hl.lib.e2t_conv_pack_grouped(xt.data_ptr(), lt.data_ptr(), B, T, C_, N, G, grp.data_ptr(), K8, st())
+    torch.cuda.synchronize()
+    P_, Gr = host(plain), host(grp)
+    m = np.arange(S * B)
+    tp, b = (m // (B * G)) * G + m % G, (m // G) % B
+    want = np.zeros((S * B, K8))
+    ok = tp < S1
+    want[ok] = P_[tp[ok] * B + b[ok]]
+    np.testing.assert_array_equal(Gr, want)
+    # un-im2row of a gradient laid out in the grouped order == the plain one on the permuted rows
+    dA = rng.standard_normal((S * B, K8)).astype(np.float32)
+    dAp = np.zeros((S1 * B, K8), np.float32)
+    dAp[tp[ok] * B + b[ok]] = dA[ok]
+    d1 = torch.zeros(B, T, C_, dtype=torch.float32, device='cuda'); d2 = torch.zeros_like(d1)
+    a1, a2 = torch.tensor(dAp, device='cuda'), torch.tensor(dA, device='cuda')
+    hl.lib.e2t_conv_unpack_grad(a1.data_ptr(), K8, lt.data_ptr(), B, T, C_, N, d1.data_ptr(), st())
+    hl.lib.e2t_conv_unpack_grad_grouped(a2.data_ptr(), K8, lt.data_ptr(), B, T, C_, N, G, d2.data_ptr(), st())
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2) and float(d1.abs().max()) > 0
+    # row mask of the product in the grouped order
+    F = 16
+    W = rng.standard_normal((F, K8))
+    wt = dev_bf16(W)
+    ld_t = torch.tensor(-(-lens // N), dtype=torch.int32, device='cuda')
+    out = torch.full((S * B, F), 7.0, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue(); ep.alpha = 1.0
+    ep.row_lens, ep.rows_per_step, ep.row_group = ld_t.data_ptr(), B, G
+    hl.lib.e2t_gemm_nt_bf16(grp.data_ptr(), K8, wt.data_ptr(), K8, out.data_ptr(), F, S * B, F, K8, C.byref(ep), st())
+    torch.cuda.synchronize()
+    ref = Gr @ round_bf16(W).T * (tp < (-(-lens // N))[b])[:, None]
+    np.testing.assert_allclose(host(out), ref, rtol=1e-5, atol=1e-4)
