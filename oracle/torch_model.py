@@ -61,17 +61,24 @@ def torch_model(Pt, spec, batch, masks, x_leaf=None):
     lens_d = -(-lens // N)
     Xr = reverse_padded(X.transpose(0, 1), lens)                     # [T,B,C]
     Xr = F.pad(Xr, (0, 0, 0, 0, 0, S * N - T))
-    nm = O.conv_name(spec, sid)
-    W = Pt[nm + '/weights'][0]                                        # [N,C,F]
-    # independent formulation: conv1d over [B,C,T] with stride N
-    y = F.conv1d(Xr.permute(1, 2, 0), W.permute(2, 1, 0), Pt[nm + '/biases'], stride=N)  # [B,F,S]
-    E = y.permute(2, 0, 1)
-    if spec.conv_relu:
-        E = F.relu(E)
-    if masks.get('conv') is not None:
-        E = E * masks['conv']
+    # independent formulation of the temporal-convolution stack (one layer unless spec.conv_pre): F.conv1d over [B,C,T] with
+    # stride = width per layer; the decimated lengths follow by ceil-division layer by layer
+    cur, lens_j = Xr, lens
+    layers = O.conv_layers(spec, sid)
+    for j, (nm, ci, co, n) in enumerate(layers):
+        W = Pt[nm + '/weights'][0]                                    # [n,ci,co]
+        y = F.conv1d(cur.permute(1, 2, 0), W.permute(2, 1, 0), Pt[nm + '/biases'], stride=n)  # [B,co,Tj]
+        E = y.permute(2, 0, 1)
+        if spec.conv_relu:
+            E = F.relu(E)
+        mk = masks.get('conv' if j == len(layers) - 1 else 'conv_pre%d' % j)
+        if mk is not None:
+            E = E * mk
+        lens_j = -(-lens_j // n)
+        vj = (torch.arange(E.shape[0])[:, None] < lens_j[None]).to(E.dtype)
+        E = E * vj[..., None]
+        cur = E
     valid = (torch.arange(S)[:, None] < lens_d[None]).to(E.dtype)
-    E = E * valid[..., None]
     inp = E
     lens_c = torch.clamp(lens_d, min=1)
     taps = []
@@ -90,9 +97,15 @@ def torch_model(Pt, spec, batch, masks, x_leaf=None):
     c0 = torch.cat([cf, cb], -1)
     total = 0.0
     out = {}
-    if 'encoder_targets' in batch and spec.aux_layer is not None:
-        tg = torch.tensor(batch['encoder_targets'])
-        cat = spec.aux_dist == 'categorical'
+    for hd in O.aux_heads(spec):
+        if hd['key'] == 'encoder_targets':
+            tgn = batch.get('encoder_targets')
+        else:
+            tgn = (batch.get('encoder_targets_extra') or [None] * (hd['key'] + 1))[hd['key']]
+        if tgn is None or hd['scale'] == 0.0:
+            continue
+        tg = torch.tensor(np.asarray(tgn))
+        cat = hd['dist'] == 'categorical'
         tl = (tg != 0).sum(1) if cat else (tg.abs().amax(2) > 0).sum(1)
         tgm = tg.transpose(0, 1)
         if cat:
@@ -100,25 +113,26 @@ def torch_model(Pt, spec, batch, masks, x_leaf=None):
         tr = reverse_padded(tgm, tl)
         tr = F.pad(tr, (0, 0, 0, 0, 0, S * N - T))[0::N]
         av = (torch.arange(S)[:, None] * N < tl[None]).to(E.dtype)
-        sizes = [2 * spec.enc_rnn[spec.aux_layer]] + list(spec.aux_hidden) + [spec.aux_dim]
-        names = O.ff_names('encoder_%d_projection' % spec.aux_layer, sizes)
-        z = taps[spec.aux_layer]
+        sizes = [2 * spec.enc_rnn[hd['layer']]] + list(hd['hidden']) + [hd['dim']]
+        names = O.ff_names('encoder_%d_projection' % hd['layer'], sizes)
+        mkey = 'aux%d' if hd['name'] == 'aux' else ('auxx%d_' % hd['key']) + '%d'
+        z = taps[hd['layer']]
         for i, n_ in enumerate(names):
             last = i == len(names) - 1
             if last:
                 z = F.linear(z, Pt[n_ + '/weights'], Pt[n_ + '/biases'])
             else:
                 z = F.relu(z @ Pt[n_ + '/weights'] + Pt[n_ + '/biases'])
-                if masks.get('aux%d' % i) is not None:
-                    z = z * masks['aux%d' % i]
+                if masks.get(mkey % i) is not None:
+                    z = z * masks[mkey % i]
         nval = av.sum().clamp(min=1)
         if cat:
             ce = F.cross_entropy(z.reshape(S * B, -1), tr[..., 0].reshape(-1).long(), reduction='none')
             aux = (ce * av.reshape(-1)).sum() / nval
         else:
-            aux = (((z - tr) * av[..., None]) ** 2).sum() / (nval * spec.aux_dim)
-        out['aux'] = aux
-        total = total + spec.aux_scale * aux
+            aux = (((z - tr) * av[..., None]) ** 2).sum() / (nval * hd['dim'])
+        out[hd['name']] = aux
+        total = total + hd['scale'] * aux
     Yt = torch.tensor(np.asarray(batch['decoder_targets'])).long()
     L = Yt.shape[1]
     dl = (Yt != 0).sum(1)

@@ -34,9 +34,12 @@ def collect_masks(cache, spec):
     masks = {'conv': t(cache['mE']), 'demb': t(cache['dec']['mEm']), 'dout': t(cache['dec']['mH'])}
     for l, lay in enumerate(cache['enc']):
         masks['enc%d' % l] = t(lay['mY'])
-    if 'aux' in cache:
-        for i, m in enumerate(cache['aux']['ff']['masks']):
-            masks['aux%d' % i] = t(m)
+    for rec in cache.get('aux_heads', {}).values():
+        key = 'aux%d' if rec['head']['name'] == 'aux' else ('auxx%d_' % rec['head']['key']) + '%d'
+        for i, m in enumerate(rec['ff']['masks']):
+            masks[key % i] = t(m)
+    for j, cv in enumerate(cache['convs'][:-1]):
+        masks['conv_pre%d' % j] = t(cv['mE'])
     for i, m in enumerate(cache['dec']['pff']['masks']):
         masks['proj%d' % i] = t(m)
     return masks
@@ -50,6 +53,12 @@ CASES = [
     dict(dec_proj_hidden=[9], ff_dropout=0.3),
     dict(conv_relu=False, enc_rnn=[4], aux_layer=0, dec_rnn=8),
     dict(enc_rnn=[4, 6, 5], dec_rnn=10, aux_layer=2),
+    # a stack of strided conv layers (strides 2 x 3 x 1 = decimation 6)
+    dict(decimation=6, conv_pre=[dict(out=7, stride=2), dict(out=4, stride=3)], enc_embed=5, ff_dropout=0.2, rnn_dropout=0.1),
+    dict(decimation=4, conv_pre=[dict(out=3, stride=4)], enc_embed=5),
+    # several auxiliary heads (one per tapped layer): categorical on layer 0 next to the Gaussian one on layer 1
+    dict(aux_extra=[dict(layer=0, hidden=[5], dim=4, dist='categorical', scale=0.7)], ff_dropout=0.2, rnn_dropout=0.3),
+    dict(enc_rnn=[4, 6, 8], dec_rnn=16, aux_layer=1, aux_extra=[dict(layer=2, hidden=[], dim=3, scale=0.25), dict(layer=0, hidden=[6, 5], dim=2)]),
 ]
 
 
@@ -70,8 +79,9 @@ def test_oracle_matches_torch_autograd(kw, ragged):
     out = torch_model(Pt, spec, batch, collect_masks(cache, spec))
     out['total'].backward()
     assert abs(losses['decoder'] - out['decoder'].item()) < 1e-10
-    if 'aux' in out:
-        assert abs(losses['aux'] - out['aux'].item()) < 1e-10
+    for k in losses:
+        if k.startswith('aux'):
+            assert abs(losses[k] - out[k].item()) < 1e-10, k
     assert abs(losses['total'] - out['total'].item()) < 1e-10
     np.testing.assert_allclose(cache['dec']['logits'], out['logits'].detach().numpy(), atol=1e-10)
     for k in P:
@@ -84,7 +94,8 @@ def test_oracle_matches_torch_autograd(kw, ragged):
 
 
 
-@pytest.mark.parametrize('kw', [dict(), dict(ff_dropout=0.2, rnn_dropout=0.5), dict(conv_relu=False, enc_rnn=[4], aux_layer=0, dec_rnn=8)])
+@pytest.mark.parametrize('kw', [dict(), dict(ff_dropout=0.2, rnn_dropout=0.5), dict(conv_relu=False, enc_rnn=[4], aux_layer=0, dec_rnn=8),
+                                dict(decimation=6, conv_pre=[dict(out=7, stride=2), dict(out=4, stride=3)], enc_embed=5, ff_dropout=0.2)])
 def test_oracle_input_gradient_matches_torch_autograd(kw):
     """Row a12 (restore_and_get_saliencies, trainers.py:703-732): d loss / d encoder_inputs from the oracle's manual
     chain (conv back-projection, un-im2row, un-reverse) against autograd through the independent torch model.  Padding
