@@ -1339,15 +1339,29 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     auto prefetch = [&](int s) {                                                                     //  no generic->LDS casts in the loop)
         if (!tile_ok) return;
         const unsigned dst = pre_lds + (unsigned)(s % 3) * (E2T_BWD_PRE16 * 16);
-        const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
+        // (a wide workgroup covers TWO row tiles: with an odd number of them the second one of the last group does not
+        //  exist -- its lanes own nothing, but the DMA runs with full exec: clamp the tile so it reads inside the arrays.
+        //  Found by tests/test_gpu_fullsize_parity.py: cfg2's decoder at B = 16 read 200 KiB past the end of Gs.)
+        const int rtp = min(rt, RT - 1);
+        const size_t tile = native_tile(s, dir, rtp, ut, p.ndir, RT, p.UT);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dma16_to_lds(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, dst + r * 1024);
-        if (s > 0) dma16_to_lds(p.Cs + native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 256 + lane * 4, dst + 4 * 1024);
+        if (s > 0) dma16_to_lds(p.Cs + native_tile(s - 1, dir, rtp, ut, p.ndir, RT, p.UT) * 256 + lane * 4, dst + 4 * 1024);
         if (p.dY) {
             const int t = (s < len) ? (dir ? (len - 1 - s) : s) : 0;
             dma16_to_lds(p.dY + ((size_t)t * B + bc) * p.lddy + dir * p.H8 + u0c, dst + 5 * 1024);
         }
     };
+    // The rarely used per-utterance operands (initial cell state; gradients into the final state, consumed once per
+    // utterance at its own last step) are fetched ONCE, here: a compiler-visible global load inside the step loop makes
+    // hipcc put `s_waitcnt vmcnt(0)` on every path of the side work, which drains this wave's exchange stores, the row-major
+    // dG stores and the operand prefetch of two steps ahead EVERY step (seen in the ISA; side work 1.1 us per step).
+    float c0v[4] = {0.f, 0.f, 0.f, 0.f}, dhfin[4] = {0.f, 0.f, 0.f, 0.f}, dcfin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (own) {
+        if (p.c0) { const float4 c = *(const float4*)(p.c0 + su); c0v[0] = c.x; c0v[1] = c.y; c0v[2] = c.z; c0v[3] = c.w; }
+        if (p.dh_final) { const float4 v = *(const float4*)(p.dh_final + su); dhfin[0] = v.x; dhfin[1] = v.y; dhfin[2] = v.z; dhfin[3] = v.w; }
+        if (p.dc_final) { const float4 v = *(const float4*)(p.dc_final + su); dcfin[0] = v.x; dcfin[1] = v.y; dcfin[2] = v.z; dcfin[3] = v.w; }
+    }
     // factors of step s (see the cell backward below): f_add = dh_final + dy*mask, k1..k5, f; c_t is carried
     float ct[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
     float f_add[4], k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
@@ -1361,19 +1375,17 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             const float2* cs = (const float2*)(src + 4 * 64);
             const float2 a = cs[lane], c = cs[64 + lane];
             cp[0] = a.x; cp[1] = a.y; cp[2] = c.x; cp[3] = c.y;
-        } else if (p.c0) {
-            const float4 c = *(const float4*)(p.c0 + su);
-            cp[0] = c.x; cp[1] = c.y; cp[2] = c.z; cp[3] = c.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[r] = c0v[r];
         }
         if (s < len) {
             const int t = dir ? (len - 1 - s) : s;
             const size_t m = (size_t)t * B + b;
             float dhf[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f}, dsc4[4] = {1.f, 1.f, 1.f, 1.f};
             if (s == len - 1) {               // the utterance's last time step: gradients into the final state
-                if (p.dh_final) { const float4 v = *(const float4*)(p.dh_final + su); dhf[0] = v.x; dhf[1] = v.y; dhf[2] = v.z; dhf[3] = v.w; }
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.dc_final) v = *(const float4*)(p.dc_final + su);
-                dcc[0] = v.x; dcc[1] = v.y; dcc[2] = v.z; dcc[3] = v.w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dhf[r] = dhfin[r]; dcc[r] = dcfin[r]; }
             }
             if (p.dY) {
                 const uint4 raw = src[5 * 64 + lane];
@@ -1406,6 +1418,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         ct[0] = a.x; ct[1] = a.y; ct[2] = c.x; ct[3] = c.y;
     }
     dma_wait_all();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(c0v[r]), "+v"(dhfin[r]), "+v"(dcfin[r]));     // hipcc's wait for these loads HERE, not at their first use in the loop
     precompute(S - 1);
     if (S > 1) prefetch(S - 2);
     long long pts[8];
@@ -1482,8 +1496,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             if (own) {
                 float4 oh = make_float4(rec[0], rec[1], rec[2], rec[3]), oc = make_float4(dcc[0], dcc[1], dcc[2], dcc[3]);
                 if (len == 0) {
-                    oh = p.dh_final ? *(const float4*)(p.dh_final + su) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    oc = p.dc_final ? *(const float4*)(p.dc_final + su) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    oh = make_float4(dhfin[0], dhfin[1], dhfin[2], dhfin[3]);
+                    oc = make_float4(dcfin[0], dcfin[1], dcfin[2], dcfin[3]);
                 }
                 *(float4*)(p.dh0 + su) = oh; *(float4*)(p.dc0 + su) = oc;
             }

@@ -1,0 +1,138 @@
+"""Full-size parity leg: the REAL graphs of BASELINE.json's configurations -- cfg2 (256 electrodes x
+400 samples, 3 x biLSTM(400), decoder 800, V = 1806, B = 256: 8704-row GEMMs with split-K, S = 34 persistent sweeps, K = 3072
+conv) and cfg4 (H = 1024 x 4 layers, decoder 2048) -- compared tensor by tensor with CPU checkers:
+
+ * HIP path vs `oracle/torch_model.py` (the independent torch-CPU model, fp32, autograd) at the full batch.  The HIP path
+   multiplies bf16 operands, so the tolerance is the measured bf16-vs-exact band, stated per quantity:
+   losses 1e-2 relative, logits cosine >= 0.999, every gradient tensor cosine >= 0.995 and norm ratio within 3 %.
+ * HIP path vs the bf16-emulating NumPy oracle (`oracle/seq2seq.py`, same rounding points) at B = 16 of the SAME cfg2
+   graph, with the tolerances of tests/test_gpu_parity.py (losses 2e-4, gradients 5e-3 of the tensor's maximum).
+
+Dropout is off in all three (the torch model draws Bernoulli masks, not Philox; the Philox path is covered at small sizes by
+test_gpu_parity.py and, at full size, by determinism / linearity in test_gpu_fullsize.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import seq2seq as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ragged(batch, T, lo, seed=0):
+    rng = np.random.default_rng(seed)
+    B = batch['encoder_inputs'].shape[0]
+    lens = rng.integers(lo, T + 1, size=B)
+    lens[0] = T
+    for b in range(B):
+        batch['encoder_inputs'][b, lens[b]:] = 0
+        if 'encoder_targets' in batch:
+            batch['encoder_targets'][b, lens[b]:] = 0
+    return lens
+
+
+def _hip(kw, B, T, L, batch, P):
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=5)
+    eng.load_params(P)
+    ws = eng.workspace(401, B, T, L)
+    eng.set_batch(ws, batch)
+    eng.forward(ws, train=False)
+    eng.backward(ws, train=False)
+    torch.cuda.synchronize()
+    assert int(eng.sync_err[0].item()) == 0
+    losses = eng.losses(ws)
+    logits = ws['proj']['out'].float().cpu().numpy().reshape(L, B, -1)
+    return eng, ws, losses, logits, eng.store.export_tf('g')
+
+
+def _torch_reference(ospec, batch, P, dtype=torch.float32):
+    from oracle import torch_model as TM
+    Pt = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in P.items()}
+    b = dict(batch)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    b['encoder_inputs'] = np.asarray(batch['encoder_inputs'], dtype=npdt)
+    if 'encoder_targets' in b:
+        b['encoder_targets'] = np.asarray(batch['encoder_targets'], dtype=npdt)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    out = TM.torch_model(Pt, ospec, b, {})
+    out['total'].backward()
+    G = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape, npdt)) for k, v in Pt.items()}
+    losses = {k: float(v.detach()) for k, v in out.items() if k != 'logits'}
+    return losses, out['logits'].detach().numpy(), G
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def _biases_off_zero(P, seed):
+    """Random biases (the initialiser leaves them at zero: a transposed or mis-sliced bias gradient would go unseen)."""
+    rng = np.random.default_rng(seed)
+    for k in P:
+        if P[k].ndim == 1:
+            P[k] = 0.1 * rng.standard_normal(P[k].shape)
+    return P
+
+
+@pytest.mark.parametrize('name,B', [('cfg2', 256), ('cfg4', 64)])
+def test_full_graph_against_torch_cpu(name, B):
+    kw, _, T, L = bench.CONFIGS[name]
+    from ecog2txt_amd.engine import NetSpec
+    ospec = O.NetSpec(**NetSpec(**kw).as_dict())
+    P = _biases_off_zero(O.init_params(ospec, seed=3), 4)
+    batch = bench.synth_batch(kw, B, T, L, seed=7)
+    _ragged(batch, T, 240, seed=1)
+    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P)
+    want, wlogits, WG = _torch_reference(ospec, batch, P)
+    # losses: 1e-2 relative (bf16 operands against fp32)
+    for k in ('decoder', 'aux'):
+        if k in want:
+            assert abs(losses[k] - want[k]) <= 1e-2 * max(1.0, abs(want[k])), (k, losses, want)
+    # logits of the valid target positions
+    Y = np.asarray(batch['decoder_targets'])
+    valid = (Y != 0).T                                              # [L, B]
+    assert _cos(logits[valid], wlogits.reshape(L, B, -1)[valid]) >= 0.999
+    worst = []
+    for k in sorted(WG):
+        g, w = np.asarray(G[k], np.float64), np.asarray(WG[k], np.float64)
+        assert g.shape == w.shape, (k, g.shape, w.shape)
+        nw = np.linalg.norm(w)
+        if nw == 0.0:
+            assert np.abs(g).max() < 1e-6, k
+            continue
+        c, ratio = _cos(g, w), float(np.linalg.norm(g) / nw)
+        worst.append((c, ratio, k))
+        assert c >= 0.995, (k, c, ratio)
+        assert abs(ratio - 1.0) <= 3e-2, (k, c, ratio)
+    worst.sort()
+    print('\n%s B=%d: losses hip %s torch %s; worst gradient cosines: %s' % (
+        name, B, {k: round(v, 5) for k, v in losses.items() if k in want}, {k: round(v, 5) for k, v in want.items()},
+        ['%s cos %.5f ratio %.4f' % (k, c, r) for c, r, k in worst[:4]]))
+
+
+def test_cfg2_graph_against_bf16_emulating_oracle():
+    """The same cfg2 graph (3 x 400 bidirectional, decoder 800, V = 1806, T = 400 -> 34 steps, K = 3072 conv) at B = 16 against the
+    NumPy oracle with the device's rounding points: the tight tolerances of test_gpu_parity.py."""
+    from test_gpu_parity import check_grad, LOSS_RTOL
+    from ecog2txt_amd.engine import NetSpec
+    kw, _, T, L = bench.CONFIGS['cfg2']
+    B = 16
+    ospec = O.NetSpec(**NetSpec(**kw).as_dict())
+    P = _biases_off_zero(O.init_params(ospec, seed=5), 6)
+    batch = bench.synth_batch(kw, B, T, L, seed=9)
+    _ragged(batch, T, 200, seed=2)
+    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P)
+    want, cache = O.forward(P, ospec, batch, train=False, emulate_bf16=True)
+    for k in ('decoder', 'aux'):
+        assert abs(losses[k] - want[k]) <= LOSS_RTOL * max(1.0, abs(want[k])), (k, losses, want)
+    np.testing.assert_array_equal(ws['lens'].cpu().numpy(), cache['lens'])
+    np.testing.assert_allclose(logits, cache['dec']['logits'], atol=3e-2, rtol=1e-2)
+    WG = O.backward(P, cache)
+    for k in sorted(WG):
+        # 54 400 conv activations here (16 utterances x 34 steps x 100 units) against ~2 000 in the small cases: a few units sit
+        # on the ReLU knife edge, each moving one column (1 %) of the conv weight gradient
+        check_grad(k, G[k], WG[k], relu_outliers=4e-2)

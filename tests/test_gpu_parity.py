@@ -26,14 +26,29 @@ LOSS_RTOL = 2e-4
 GRAD_TOL = 5e-3
 
 
-def check_grad(name, got, want):
+def relu_class(name):
+    """Tensors whose gradient passes through a ReLU mask of their OWN layer (the conv front-end, hidden layers of the feed-forward
+    heads): a pre-activation within fp32 accumulation error of zero flips the mask of one sample and shifts that unit's weight
+    column and bias by one sample's contribution.  Everything else (LSTM kernels and biases, embeddings, linear output layers)
+    has no such knife edge and is held to the plain tolerance."""
+    return 'encoder_embedding' in name or ('_projection_' in name)
+
+
+def check_grad(name, got, want, relu_outliers=1e-2):
     scale = np.abs(want).max() + 1e-12
     err = np.abs(got - want) / scale
     outliers = (err > GRAD_TOL).mean()
     rel_l2 = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-12)
-    # one flipped unit moves a whole weight column / one bias entry
-    assert outliers <= max(1e-2, 1.0 / err.size) and err.max() < 5e-2, (name, float(err.max()), float(outliers))
-    assert rel_l2 < 2e-2, (name, float(rel_l2))
+    if relu_class(name):
+        # at most 1 % of the entries (one unit; three entries of a small bias vector) beyond 5e-3, none beyond 5e-2
+        # (relu_outliers: the share grows with the number of activations -- every flipped unit moves one weight column)
+        assert outliers <= max(relu_outliers, 3.0 / err.size) and err.max() < 5e-2, (name, float(err.max()), float(outliers))
+        assert rel_l2 < 2e-2, (name, float(rel_l2))
+    else:
+        # recurrent kernels, embeddings, linear layers: at most 0.1 % of the entries beyond 5e-3 (1-ulp bf16 flips amplified
+        # through BPTT), none beyond 2e-2
+        assert outliers <= max(1e-3, 1.0 / err.size) and err.max() < 2e-2, (name, float(err.max()), float(outliers))
+        assert rel_l2 < 1e-2, (name, float(rel_l2))
 
 
 def build(spec_kw, B, T, L, seed=0, ragged=True, engine_seed=11):
