@@ -490,83 +490,86 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         const bool active = s < len;
         const int t = dir ? (len - 1 - s) : s;
         u32x4 st[KB];
-        if (s == 0) {
-            // initial state from the row-major array: block 0 (forward), the all-zero slack block S+1 (backward);
-            // rows that are inactive or beyond B read block 0 (finite, result discarded)
-            size_t tau = 0, srb = bc;
-            if (active && dir == 1) { tau = (size_t)S + 1; srb = 0; }
-            const bf16_t* src = p.Yext + (tau * B + srb) * p.ldy + dir * p.H8 + fq * 8;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(st[kb]) : "v"(src), "i"(kb * 64) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));         // uses stay behind the wait
-        } else {
-            // No flags: every bf16 in the exchange buffer carries a 1-bit stamp in bit 14 (free: |h| <= 1 keeps the
-            // exponent below 128).  Buffer (s-1)&1 is rewritten every other step, so its stamp toggles with (s-1)>>1;
-            // the consumer simply loads and retries until every value it needs shows the expected stamp.
-            const bf16_t* src = pa.hx + ((((size_t)((s - 1) & 1) * p.ndir + dir) * (RB * 4) + rt) * KB * 64 + lane) * 8;
-            const bool tag1 = ((((s - 1) >> 1) & 1) ^ ((s - 1) & 1 ? base[1] : base[0])) != 0;      // wave-uniform
-            const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
-            int spins = 0;
-            for (;;) {
-                // NOTHING may sit between the issue and the wait, and the loads stay inline (not in a lambda): a copy of a
-                // load destination taken while the load is in flight is garbage -- hipcc makes such copies when it parks
-                // registers in AGPRs or gives a by-reference capture a home (seen: stale stamps, timeout).  Moving the
-                // Philox mask in front of the MFMAs was measured too: +0.2 us on the MFMA phase, more retries, slower.
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)     // the immediate offset field is 13-bit signed: one base per 4 k-blocks
-                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));     // uses stay behind the wait
-                bool fresh;
-                if (tag1) {                                              // all stamps must be set
-                    unsigned m = 0xFFFFFFFFu;
-#pragma unroll
-                    for (int kb = 0; kb < KB - 1; ++kb) m &= st[kb][0] & st[kb][1] & st[kb][2] & st[kb][3];
-                    const unsigned l = st[KB - 1][0] & st[KB - 1][1] & st[KB - 1][2] & st[KB - 1][3];
-                    m &= chk_last ? l : 0xFFFFFFFFu;
-                    fresh = (m & 0x40004000u) == 0x40004000u;
-                } else {                                                 // all stamps must be clear
-                    unsigned m = 0u;
-#pragma unroll
-                    for (int kb = 0; kb < KB - 1; ++kb) m |= st[kb][0] | st[kb][1] | st[kb][2] | st[kb][3];
-                    const unsigned l = st[KB - 1][0] | st[KB - 1][1] | st[KB - 1][2] | st[KB - 1][3];
-                    m |= chk_last ? l : 0u;
-                    fresh = (m & 0x40004000u) == 0u;
-                }
-                // rows that are inactive at this step (or beyond B) may hold anything: their results are discarded
-                if (__all(fresh || !active)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
-                if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            if (tag1) {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) st[kb] &= 0xBFFFBFFFu;   // strip the stamps before the MFMAs
-            }
-        }
-        PSTAMP(2);
-        if (s + 2 < S) gx_load(s + 2);
-
         f32x4 acc[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pp = 0; pp < npr; ++pp) {                           // k-block pairs; parity = the K half of the step kernel
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp][g], *(bf16x8*)&st[2 * pp], acc[pp & 1][g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp + 1][g], *(bf16x8*)&st[2 * pp + 1], acc[pp & 1][g], 0, 0, 0);
-        }
-        if (KB & 1) {                                                // odd tail k-block: the half that owns pair index npr
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[npr & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[KB - 1][g], *(bf16x8*)&st[KB - 1], acc[npr & 1][g], 0, 0, 0);
+        {
+            if (s == 0) {
+                // initial state from the row-major array: block 0 (forward), the all-zero slack block S+1 (backward);
+                // rows that are inactive or beyond B read block 0 (finite, result discarded)
+                size_t tau = 0, srb = bc;
+                if (active && dir == 1) { tau = (size_t)S + 1; srb = 0; }
+                const bf16_t* src = p.Yext + (tau * B + srb) * p.ldy + dir * p.H8 + fq * 8;
+    #pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(st[kb]) : "v"(src), "i"(kb * 64) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    #pragma unroll
+                for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));         // uses stay behind the wait
+            } else {
+                // No flags: every bf16 in the exchange buffer carries a 1-bit stamp in bit 14 (free: |h| <= 1 keeps the
+                // exponent below 128).  Buffer (s-1)&1 is rewritten every other step, so its stamp toggles with (s-1)>>1;
+                // the consumer simply loads and retries until every value it needs shows the expected stamp.
+                const bf16_t* src = pa.hx + ((((size_t)((s - 1) & 1) * p.ndir + dir) * (RB * 4) + rt) * KB * 64 + lane) * 8;
+                const bool tag1 = ((((s - 1) >> 1) & 1) ^ ((s - 1) & 1 ? base[1] : base[0])) != 0;      // wave-uniform
+                const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
+                int spins = 0;
+                for (;;) {
+                    // NOTHING may sit between the issue and the wait, and the loads stay inline (not in a lambda): a copy of a
+                    // load destination taken while the load is in flight is garbage -- hipcc makes such copies when it parks
+                    // registers in AGPRs or gives a by-reference capture a home (seen: stale stamps, timeout).  Moving the
+                    // Philox mask in front of the MFMAs was measured too: +0.2 us on the MFMA phase, more retries, slower.
+    #pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)     // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    #pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));     // uses stay behind the wait
+                    bool fresh;
+                    if (tag1) {                                              // all stamps must be set
+                        unsigned m = 0xFFFFFFFFu;
+    #pragma unroll
+                        for (int kb = 0; kb < KB - 1; ++kb) m &= st[kb][0] & st[kb][1] & st[kb][2] & st[kb][3];
+                        const unsigned l = st[KB - 1][0] & st[KB - 1][1] & st[KB - 1][2] & st[KB - 1][3];
+                        m &= chk_last ? l : 0xFFFFFFFFu;
+                        fresh = (m & 0x40004000u) == 0x40004000u;
+                    } else {                                                 // all stamps must be clear
+                        unsigned m = 0u;
+    #pragma unroll
+                        for (int kb = 0; kb < KB - 1; ++kb) m |= st[kb][0] | st[kb][1] | st[kb][2] | st[kb][3];
+                        const unsigned l = st[KB - 1][0] | st[KB - 1][1] | st[KB - 1][2] | st[KB - 1][3];
+                        m |= chk_last ? l : 0u;
+                        fresh = (m & 0x40004000u) == 0u;
+                    }
+                    // rows that are inactive at this step (or beyond B) may hold anything: their results are discarded
+                    if (__all(fresh || !active)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
+                    if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if (p.dbg && s == S / 2) pts[1] = spins;
+                if (tag1) {
+    #pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) st[kb] &= 0xBFFFBFFFu;   // strip the stamps before the MFMAs
+                }
+            }
+            PSTAMP(2);
+            if (s + 2 < S) gx_load(s + 2);
+
+    #pragma unroll
+            for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) acc[h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int pp = 0; pp < npr; ++pp) {                           // k-block pairs; parity = the K half of the step kernel
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp][g], *(bf16x8*)&st[2 * pp], acc[pp & 1][g], 0, 0, 0);
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp + 1][g], *(bf16x8*)&st[2 * pp + 1], acc[pp & 1][g], 0, 0, 0);
+            }
+            if (KB & 1) {                                                // odd tail k-block: the half that owns pair index npr
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) acc[npr & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[KB - 1][g], *(bf16x8*)&st[KB - 1], acc[npr & 1][g], 0, 0, 0);
+            }
         }
         PSTAMP(3);
 
@@ -1352,16 +1355,18 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             dma16_to_lds(p.dY + ((size_t)t * B + bc) * p.lddy + dir * p.H8 + u0c, dst + 5 * 1024);
         }
     };
-    // The rarely used per-utterance operands (initial cell state; gradients into the final state, consumed once per
-    // utterance at its own last step) are fetched ONCE, here: a compiler-visible global load inside the step loop makes
-    // hipcc put `s_waitcnt vmcnt(0)` on every path of the side work, which drains this wave's exchange stores, the row-major
-    // dG stores and the operand prefetch of two steps ahead EVERY step (seen in the ISA; side work 1.1 us per step).
-    float c0v[4] = {0.f, 0.f, 0.f, 0.f}, dhfin[4] = {0.f, 0.f, 0.f, 0.f}, dcfin[4] = {0.f, 0.f, 0.f, 0.f};
-    if (own) {
-        if (p.c0) { const float4 c = *(const float4*)(p.c0 + su); c0v[0] = c.x; c0v[1] = c.y; c0v[2] = c.z; c0v[3] = c.w; }
-        if (p.dh_final) { const float4 v = *(const float4*)(p.dh_final + su); dhfin[0] = v.x; dhfin[1] = v.y; dhfin[2] = v.z; dhfin[3] = v.w; }
-        if (p.dc_final) { const float4 v = *(const float4*)(p.dc_final + su); dcfin[0] = v.x; dcfin[1] = v.y; dcfin[2] = v.z; dcfin[3] = v.w; }
-    }
+    // The rarely used per-utterance operands (gradients into the final state, consumed once per utterance at its own last
+    // step; the initial cell state, at step 0) must not be compiler-visible global loads inside the step loop: hipcc then puts
+    // `s_waitcnt vmcnt(0)` on every path of the side work, which drains this wave's exchange stores, the row-major dG stores and
+    // the operand prefetch of two steps ahead EVERY step (seen in the ISA; side work 1.1 -> 0.8 us per step).  They are
+    // fetched where they are needed by a load that waits for itself (one asm statement, invisible to hipcc's wait insertion):
+    // a drain only at the steps that do consume them.  (Registers are not the place: 12 more push the kernel past the 368 that
+    // let a 128 x 128 K-major GEMM workgroup share the CU; nor is LDS: 8 KiB more and the two no longer fit 160 KiB together.)
+    auto ld4_now = [](const float* q) {
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");
+        return v;
+    };
     // factors of step s (see the cell backward below): f_add = dh_final + dy*mask, k1..k5, f; c_t is carried
     float ct[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
     float f_add[4], k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
@@ -1375,17 +1380,19 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             const float2* cs = (const float2*)(src + 4 * 64);
             const float2 a = cs[lane], c = cs[64 + lane];
             cp[0] = a.x; cp[1] = a.y; cp[2] = c.x; cp[3] = c.y;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cp[r] = c0v[r];
+        } else if (p.c0) {
+            const f32x4 c = ld4_now(p.c0 + su);
+            cp[0] = c[0]; cp[1] = c[1]; cp[2] = c[2]; cp[3] = c[3];
         }
         if (s < len) {
             const int t = dir ? (len - 1 - s) : s;
             const size_t m = (size_t)t * B + b;
             float dhf[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f}, dsc4[4] = {1.f, 1.f, 1.f, 1.f};
             if (s == len - 1) {               // the utterance's last time step: gradients into the final state
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { dhf[r] = dhfin[r]; dcc[r] = dcfin[r]; }
+                if (p.dh_final) { const f32x4 v = ld4_now(p.dh_final + su); dhf[0] = v[0]; dhf[1] = v[1]; dhf[2] = v[2]; dhf[3] = v[3]; }
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.dc_final) v = ld4_now(p.dc_final + su);
+                dcc[0] = v[0]; dcc[1] = v[1]; dcc[2] = v[2]; dcc[3] = v[3];
             }
             if (p.dY) {
                 const uint4 raw = src[5 * 64 + lane];
@@ -1419,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
     }
     dma_wait_all();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(c0v[r]), "+v"(dhfin[r]), "+v"(dcfin[r]));     // hipcc's wait for these loads HERE, not at their first use in the loop
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ct[r]));     // hipcc's wait for the prologue's loads HERE, not at a first use inside the loop
     precompute(S - 1);
     if (S > 1) prefetch(S - 2);
     long long pts[8];
@@ -1496,8 +1503,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             if (own) {
                 float4 oh = make_float4(rec[0], rec[1], rec[2], rec[3]), oc = make_float4(dcc[0], dcc[1], dcc[2], dcc[3]);
                 if (len == 0) {
-                    oh = make_float4(dhfin[0], dhfin[1], dhfin[2], dhfin[3]);
-                    oc = make_float4(dcfin[0], dcfin[1], dcfin[2], dcfin[3]);
+                    oh = make_float4(0.f, 0.f, 0.f, 0.f); oc = oh;
+                    if (p.dh_final) { const f32x4 v = ld4_now(p.dh_final + su); oh = make_float4(v[0], v[1], v[2], v[3]); }
+                    if (p.dc_final) { const f32x4 v = ld4_now(p.dc_final + su); oc = make_float4(v[0], v[1], v[2], v[3]); }
                 }
                 *(float4*)(p.dh0 + su) = oh; *(float4*)(p.dc0 + su) = oc;
             }
@@ -1746,7 +1754,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
         return E2T_ERR_ARG;
     }
     pa.fstride = wide ? 128 : 32;
-    const size_t lds = (size_t)(4 * 3 * E2T_BWD_PRE16 + 16 * 64) * 16;
+    const size_t lds = (size_t)(4 * 3 * E2T_BWD_PRE16 + 16 * 64) * 16;        // prefetch rings, K-quarter partials
 #define E2T_PERSIST_CASE(K, W) case K: hipLaunchKernelGGL((k_lstm_seq_bwd_persist<K, W>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
     if (!wide) {
         switch (KQ) {

@@ -57,6 +57,9 @@ if lay.persistent_ok(B, eng.num_cus):
         print('  whole kernel per wave: min %.1f med %.1f max %.1f us; prologue+step0: med %.1f max %.1f us' % (tot.min(), np.median(tot), tot.max(), np.median(first), first.max()))
         t = raw[:nw * 8].reshape(-1, 8)[:, :7]
         t = t[t[:, 0] > 0]
+        spins = t[:, 1].copy()
+        print('  retries of the state loads at that step: mean %.2f, share of waves with >= 1: %.2f, max %d' % (spins.mean(), (spins > 0).mean(), spins.max()))
+        t[:, 1] = t[:, 0]
         rel = (t - t[:, :1]) / 100.0
         names = ['step top', '(unused)', 'state landed (incl. retries)', 'mma done', 'h stored', '(unused)', 'side work issued']
         print('  persistent step %d, %d waves; time since step top (us):' % (S // 2, len(t)))
