@@ -29,6 +29,7 @@
 #include "common.h"
 #include "ecog2txt_hip.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define BK 64
 
@@ -154,8 +155,8 @@ constexpr int gemm_wgs_per_cu(int bm, int bn, int kt, int ns) {
 // pays is fewer bytes and fewer instructions per flop: the locality order of the grid and the scalar-base DMA form below.
 // DBG (diagnostics, scripts/gemm_loop_probe.py): 1 = no operand loads after the prologue, 2 = loads and barriers only (no
 // fragment reads, no MFMA), 3 = fragment reads without MFMAs -- wrong results by design, timing only
-template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64, int NS = 2, int DBG = 0>
-__global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void k_gemm_nt(GemmArgs p_in) {
+template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT, int NS, int DBG>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* workgroup index within this product's launch */) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE = (BM + BN) * (KT / 8);  // 16-B units per stage: [A: BM rows | B: BN rows][KT/8 chunks]
     static_assert(KT == 64 || (TN && KT == 32), "a 32-deep stage exists for the K-major form only");
@@ -176,7 +177,6 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void
     int ksplit, tm, tn, zprod;
     {
         const int W = nwg * p_in.splits * p_in.batch;
-        const int L = blockIdx.x;
         const int q = W >> 3, r = W & 7, xcd = L & 7, idx = L >> 3;
         int w = p_in.order ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : L;
         zprod = w / (nwg * p_in.splits);
@@ -466,10 +466,42 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void
     }
 }
 
+template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64, int NS = 2, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void k_gemm_nt(GemmArgs p_in) {
+    gemm_body<BM, BN, WM, WN, RICH, TN, KT, NS, DBG>(p_in, blockIdx.x);
+}
+
+// Several K-major products in ONE launch (the weight gradients of a backward stage: dW_x and dW_h of a layer; projection,
+// embedding-side and recurrent kernel of the decoder).  Launched one by one every product pays its own ramp-up, its own last
+// partly filled round of workgroups (split counts had to keep a launch inside the 512 resident slots: 175 tiles x 2 = 350 of
+// 512) and its own dependent launch gap; here the workgroups of all products form one list that the dispatcher deals out as
+// slots free up, so the K splits can be chosen for TWO OR MORE full rounds (e2t_gemm_tn_group_bf16) and a product's tail is
+// filled by the next product's head.  Product i owns workgroups [first[i], first[i+1]) (multiples of 8, so that the
+// XCD-locality order inside a product still sees workgroup L on XCD L % 8; the few padding workgroups exit at once).
+#define E2T_GEMM_GROUP_MAX 8
+struct GemmGroupArgs { int n; int first[E2T_GEMM_GROUP_MAX + 1]; int count[E2T_GEMM_GROUP_MAX]; GemmArgs p[E2T_GEMM_GROUP_MAX]; };
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_group(GemmGroupArgs g) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < E2T_GEMM_GROUP_MAX; ++j) if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
+    const int L = (int)blockIdx.x - g.first[i];
+    if (L >= g.count[i]) return;
+    gemm_body<128, 128, 2, 2, true, true, 64, 2, 0>(g.p[i], L);
+}
+
 // C[m][n] (+)= epilogue(sum_s slab[s][m][n]) in fixed split order (deterministic); 4 consecutive columns per thread so
 // the dropout mask is the GEMM kernel's (one Philox counter per aligned group of 4)
-__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) {
-    const GemmArgs p = gemm_batch_view(p_in, blockIdx.y);
+__device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z);
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) { splitk_reduce_body(p_in, blockIdx.y); }
+// the reductions of a grouped launch: blockIdx.y = product, blockIdx.z = batch member
+__global__ __launch_bounds__(256) void k_splitk_reduce_group(GemmGroupArgs g) {
+    if ((int)blockIdx.y >= g.n) return;
+    const GemmArgs& p = g.p[blockIdx.y];
+    if (p.splits <= 1 || (int)blockIdx.z >= p.batch) return;
+    splitk_reduce_body(p, blockIdx.z);
+}
+__device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z) {
+    const GemmArgs p = gemm_batch_view(p_in, z);
     const int N4 = (p.N + 3) >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)p.M * N4) return;
@@ -976,20 +1008,21 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     return pl;
 }
 
-static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                       int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
+// validated kernel arguments of one product (splits / slab are filled in by the caller from its plan)
+static int gemm_make_args(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                          int M, int N, int K, const e2t_gemm_epilogue* ep, GemmArgs& p) {
     E2T_CHECK_ARG(A && B && C);
     E2T_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
     E2T_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0);
     if (tn) E2T_CHECK_ARG(lda >= (M + 7) / 8 * 8 && ldb >= (N + 7) / 8 * 8);      // K-major operands [K][M], [K][N]
     else E2T_CHECK_ARG(K % 8 == 0 && lda >= K && ldb >= K);
     E2T_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0);
-    if (M == 0 || N == 0) return E2T_OK;
-    GemmArgs p{};
+    p = GemmArgs{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = 1.0f;
     p.splits = 1;
+    p.batch = 1;
     if (ep) {
         p.bias = ep->bias;
         p.mask_src = (const bf16_t*)ep->relu_bwd_src; p.ld_mask = ep->ld_relu_bwd_src;
@@ -1000,17 +1033,24 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : N;
         p.last_col_out = ep->last_col_out;
         E2T_CHECK_ARG(!((p.flags & E2T_GEMM_OUT_BF16) && (p.flags & E2T_GEMM_ACCUMULATE)));
+        if (ep->batch > 1) { p.batch = ep->batch; p.a_bs = ep->a_batch_stride; p.b_bs = ep->b_batch_stride; p.c_bs = ep->c_batch_stride; }
     }
     E2T_CHECK_ARG(ldc >= (p.last_col_out ? N - 1 : N));
+    p.order = gemm_order();
+    return E2T_OK;
+}
+
+static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                       int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
+    GemmArgs p;
+    if (int rc = gemm_make_args(tn, A, lda, B, ldb, C, ldc, M, N, K, ep, p)) return rc;
+    if (M == 0 || N == 0) return E2T_OK;
     const GemmPlan pl = gemm_plan(tn, M, N, K, ep);
     const bool big = pl.tile == 256;
     const int BM = pl.tile, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int batch = pl.batch;
-    if (batch > 1) { p.a_bs = ep->a_batch_stride; p.b_bs = ep->b_batch_stride; p.c_bs = ep->c_batch_stride; }
     if (pl.splits > 1 || pl.want_split) { p.splits = pl.splits; p.slab = (float*)ep->splitk_ws; }
-    p.batch = batch;
-    p.order = gemm_order();
     const dim3 grid((unsigned)(ntm * ntn * p.splits * batch));
     const hipStream_t st = (hipStream_t)stream;
     // every instance asks for its LDS explicitly (above the 64-KiB default for most of them)
@@ -1050,6 +1090,81 @@ extern "C" int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
 extern "C" int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                                 int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
     return gemm_launch(true, A, lda, B, ldb, C, ldc, M, N, K, ep, stream);
+}
+
+// Several K-major products in one launch (k_gemm_tn_group).  The K splits are chosen for the GROUP: all products are cut into
+// work items of about the same K depth, `depth` K tiles, the depth that minimises (rounds of 512 resident workgroups) x (time
+// of an item); slabs of all products share the workspace of the first product's epilogue.
+extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* stream) {
+    E2T_CHECK_ARG(n >= 1 && n <= E2T_GEMM_GROUP_MAX && calls);
+    GemmGroupArgs g{};
+    int tiles[E2T_GEMM_GROUP_MAX], kt[E2T_GEMM_GROUP_MAX];
+    int m = 0;
+    const e2t_gemm_epilogue* ep0 = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const e2t_gemm_call& c = calls[i];
+        E2T_CHECK_ARG(c.ep);
+        GemmArgs p;
+        if (int rc = gemm_make_args(true, c.A, c.lda, c.B, c.ldb, c.C, c.ldc, c.M, c.N, c.K, c.ep, p)) return rc;
+        if (c.M == 0 || c.N == 0) continue;
+        if (!ep0) ep0 = c.ep;
+        tiles[m] = ((c.M + 127) / 128) * ((c.N + 127) / 128) * p.batch;
+        kt[m] = (c.K + BK - 1) / BK;
+        g.p[m++] = p;
+    }
+    if (m == 0) return E2T_OK;
+    E2T_CHECK_ARG(ep0->splitk_ws && ep0->splitk_ws_bytes > 0);
+    // item depth: candidates from "no split at all" down to 16 K tiles (a workgroup's fixed cost -- DMA fill, slab store, its
+    // share of the reduction -- is worth ~8 of them); cost model: an item of d K tiles takes d + 5 tile times, a round of 512
+    // resident workgroups as long as its longest item
+    int kmax = 0;
+    for (int i = 0; i < m; ++i) kmax = std::max(kmax, kt[i]);
+    static const int forced_depth = [] { const char* e = getenv("E2T_GEMM_GROUP_DEPTH"); return e ? atoi(e) : 0; }();      // (diagnostics)
+    int best_d = kmax; double best_c = 1e30;
+    for (int d = kmax; d >= std::min(16, kmax); --d) {
+        long items = 0; size_t bytes = 0; int longest = 0;
+        for (int i = 0; i < m; ++i) {
+            const int sp = (kt[i] + d - 1) / d;
+            items += (long)tiles[i] * sp;
+            longest = std::max(longest, (kt[i] + sp - 1) / sp);
+            if (sp > 1) bytes += (size_t)sp * g.p[i].M * g.p[i].N * g.p[i].batch * sizeof(float);
+        }
+        if (bytes > ep0->splitk_ws_bytes) continue;
+        const double rounds = (double)((items + 511) / 512);
+        // the last round is as expensive as a full one unless it is nearly empty; splitting costs a reduction pass
+        const double c = rounds * (longest + 5.0) + (items > 0 && bytes > 0 ? 6.0 : 0.0);
+        if (c < best_c - 1e-9) { best_c = c; best_d = d; }
+    }
+    if (forced_depth > 0) best_d = std::min(kmax, forced_depth);
+    size_t off = 0;
+    int first = 0;
+    bool any_split = false;
+    unsigned max_red = 0; int max_batch = 1;
+    for (int i = 0; i < m; ++i) {
+        GemmArgs& p = g.p[i];
+        int sp = (kt[i] + best_d - 1) / best_d;
+        const size_t need = (size_t)sp * p.M * p.N * p.batch * sizeof(float);
+        if (sp > 1 && off + need > ep0->splitk_ws_bytes) sp = 1;
+        p.splits = sp;
+        if (sp > 1) {
+            p.slab = (float*)((char*)ep0->splitk_ws + off);
+            off += (need + 255) / 256 * 256;
+            any_split = true;
+            max_red = std::max(max_red, (unsigned)(((size_t)p.M * ((p.N + 3) / 4) + 255) / 256));
+            max_batch = std::max(max_batch, p.batch);
+        }
+        g.first[i] = first;
+        g.count[i] = tiles[i] * sp;
+        first += (g.count[i] + 7) / 8 * 8;
+    }
+    g.first[m] = first;
+    g.n = m;
+    static const hipError_t rc_ = hipFuncSetAttribute((const void*)k_gemm_tn_group, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(128, 128, 64, 2));
+    if (rc_ != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(rc_)); return E2T_ERR_HIP; }
+    hipLaunchKernelGGL(k_gemm_tn_group, dim3((unsigned)first), dim3(256), gemm_lds_bytes(128, 128, 64, 2), (hipStream_t)stream, g);
+    if (any_split) hipLaunchKernelGGL(k_splitk_reduce_group, dim3(max_red, (unsigned)m, (unsigned)max_batch), dim3(256), 0, (hipStream_t)stream, g);
+    E2T_LAUNCH_CHECK();
+    return E2T_OK;
 }
 
 extern "C" int e2t_gemm_plan(int tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int* tile, int* splits) {

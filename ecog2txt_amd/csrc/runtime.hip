@@ -23,6 +23,7 @@ extern "C" int e2t_sizeof(int which) {
         case 2: return (int)sizeof(e2t_pack_desc);
         case 3: return (int)sizeof(e2t_adam_hyper);
         case 4: return (int)sizeof(e2t_dropout);
+        case 5: return (int)sizeof(e2t_gemm_call);
         default: return -1;
     }
 }

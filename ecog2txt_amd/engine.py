@@ -676,6 +676,8 @@ class _Lstm:
         nd, Hh = self.ndir, self.H
         dense = all(k0 == r0 for (r0, n, k0) in self.in_blocks) and self.in_ld > self.D
         if e.tn and dense and self.ones_col_set:
+            # (inside Seq2SeqEngine.gemm_group() both products -- and the caller's other K-major products of the stage --
+            #  leave in one grouped launch)
             if part in (None, 0):
                 e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
                        self.D + 1, self.N4, M, splitk=True, tn=True)
@@ -778,6 +780,9 @@ class Seq2SeqEngine:
         self._pack_ops, self._pack_sub = None, {}
         self._img_early = None        # 'all' after a full pack of the masters, else the ranges the last replay re-packed itself
         self._gemm_log = None         # a list while bench.py records the step's products (instance, shape, flops)
+        self._in_group = False
+        self._group = None            # a list while gemm_group() collects a stage's K-major weight-gradient products
+        self.group_gemms = os.environ.get('E2T_GROUP_GEMMS', '1') != '0'   # (diagnostics: 0 = one launch per product)
         mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
         self.persistent = mode != '0'
         self.persistent_fwd, self.persistent_bwd = mode in ('1', 'fwd'), mode in ('1', 'bwd')
@@ -860,6 +865,10 @@ class Seq2SeqEngine:
             ep.row_lens, ep.rows_per_step = row_lens
             ep.row_group = row_group
         ep.flags = flags
+        if self._group is not None and tn and splitk:
+            # inside `with self.gemm_group():` -- the K-major weight-gradient products of a stage leave in ONE launch
+            self._group.append((A, lda, B, ldb, Cp, ldc, M, N, K, ep, alg or (M, N, K), batch[0] if batch is not None else 1))
+            return
         if self._gemm_log is not None:
             tile, splits = C.c_int(0), C.c_int(0)
             lib.e2t_gemm_plan(int(tn), M, N, K, C.byref(ep), C.byref(tile), C.byref(splits))
@@ -872,8 +881,52 @@ class Seq2SeqEngine:
         (lib.e2t_gemm_tn_bf16 if tn else lib.e2t_gemm_nt_bf16)(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
 
     def gemm_replay(self, rec):
-        """Re-issue a logged product (same operands, same epilogue) on the current stream."""
+        """Re-issue a logged launch (same operands, same epilogue) on the current stream."""
+        if rec.get('group') is not None:
+            lib.e2t_gemm_tn_group_bf16(len(rec['group']), rec['group'], self.stream)
+            return
         (lib.e2t_gemm_tn_bf16 if rec['tn'] else lib.e2t_gemm_nt_bf16)(*rec['call'], C.byref(rec['ep']), self.stream)
+
+    def gemm_group(self):
+        """Context manager: the K-major split-K products (weight gradients) issued inside it are collected and launched as
+        ONE grouped kernel (+ one grouped reduction) on exit -- e2t_gemm_tn_group_bf16: their workgroups share the chip's
+        rounds instead of each product paying its own ramp-up, partly filled last round and launch gap."""
+        eng = self
+
+        class _G:
+            def __enter__(self_g):
+                assert not eng._in_group
+                eng._in_group = True
+                eng._group = [] if eng.group_gemms else None
+                return self_g
+
+            def __exit__(self_g, et, ev, tb):
+                items, eng._group = eng._group, None
+                eng._in_group = False
+                if et is not None or not items:
+                    return False
+                eng._launch_group(items)
+                return False
+        return _G()
+
+    def _launch_group(self, items):
+        for k in range(0, len(items), 8):
+            part = items[k:k + 8]
+            calls = (H.GemmCall * len(part))()
+            keep = []
+            for c, it in zip(calls, part):
+                A, lda, B, ldb, Cp, ldc, M, N, K, ep = it[:10]
+                c.A, c.lda, c.B, c.ldb, c.C, c.ldc, c.M, c.N, c.K = A, lda, B, ldb, Cp, ldc, M, N, K
+                c.ep = C.pointer(ep)
+                keep.append(ep)
+            if self._gemm_log is not None:
+                fl = sum(2 * it[10][0] * it[10][1] * it[10][2] * it[11] for it in part)
+                self._gemm_log.append(dict(inst='tn128g', M=part[0][6], N=part[0][7], K=part[0][8], batch=len(part), splits=0,
+                                           flops=fl, out_bytes=sum(4 * it[10][0] * it[10][1] * it[11] for it in part),
+                                           in_bytes=sum(2 * (it[10][0] + it[10][1]) * it[10][2] * it[11] for it in part),
+                                           side=self._on_side, group=calls, keep=keep, tn=True,
+                                           desc=' + '.join('%dx%dx%d%s' % (it[10][0], it[10][1], it[10][2], ('x%d' % it[11]) if it[11] > 1 else '') for it in part)))
+            lib.e2t_gemm_tn_group_bf16(len(part), calls, self.stream)
 
     def _dropout(self, rate, stream):
         d = H.Dropout()
@@ -1592,14 +1645,20 @@ class Seq2SeqEngine:
         """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them.
         part 0 / 1: the two halves that run on the two side lanes (None: everything)."""
         s, store = self.spec, self.store
-        if part in (None, 0):
+        if part is None:
+            # projection, decoder input kernel and decoder recurrent kernel: one grouped launch (K = L*B rows each)
+            with self.gemm_group():
+                self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
+                self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
+        if part == 0:
             self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
+        if part in (None, 0):
             # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
             self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
             dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
             lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
                               store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)
-        if part in (None, 1):
+        if part == 1:
             self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
 
     def _bwd_enc_rec(self, ws, l, train):
@@ -1641,8 +1700,9 @@ class Seq2SeqEngine:
         if ws['use_aux']:
             l = s.aux_layer
             lay, lw = self.enc[l], ws['enc'][l]
-            self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train,
-                         d_in_drop=lay.out_drop(train))
+            with self.gemm_group():          # (the head's weight gradients leave together, behind its input-gradient chain)
+                self.aux.bwd(ws['aux'], lw['Ydrop'].data_ptr(), ws['dP'], ws['dY'][l].data_ptr(), lay.ldy, ws['have_dy'][l], train,
+                             d_in_drop=lay.out_drop(train))
             ws['have_dy'][l] = True
         for ax, hx, wx in zip(self.aux_x, s.aux_extra, ws['auxx']):
             if not wx.get('use'):
@@ -1656,6 +1716,11 @@ class Seq2SeqEngine:
     def _bwd_enc_weights(self, ws, l, part=None):
         """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end).
         part 0: dW_x (+ conv), part 1: dW_h -- the halves for the two side lanes; None: everything."""
+        if part is None and not self._in_group:
+            # every K-major product of the stage (dW_x, dW_h; for the bottom layer also the conv kernels) in one grouped launch
+            with self.gemm_group():
+                self._bwd_enc_weights(ws, l, None)
+            return
         s, store = self.spec, self.store
         M, Mk = ws['M'], ws['Mk']
         st = self.stream

@@ -28,6 +28,11 @@ class GemmEpilogue(C.Structure):
                 ('row_group', C.c_int)]
 
 
+class GemmCall(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('B', C.c_void_p), ('ldb', C.c_int), ('C', C.c_void_p), ('ldc', C.c_int),
+                ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('ep', C.POINTER(GemmEpilogue))]
+
+
 class LstmDesc(C.Structure):
     _fields_ = [('S', C.c_int), ('B', C.c_int), ('H', C.c_int), ('ndir', C.c_int), ('ldy', C.c_int),
                 ('forget_bias', C.c_float), ('drop_rate', C.c_float), ('drop_seed', C.c_ulonglong),
@@ -65,6 +70,7 @@ SIGNATURES = {
     'e2t_decoder_tokens': [_p, _i, _i, _i, _p, _p, _p],
     'e2t_gemm_nt_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     'e2t_gemm_tn_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    'e2t_gemm_tn_group_bf16': [_i, C.POINTER(GemmCall), _p],
     'e2t_gemm_plan': [_i, _i, _i, _i, C.POINTER(GemmEpilogue), C.POINTER(_i), C.POINTER(_i)],
     'e2t_transpose_bf16': [_p, _i, _i, _i, _p, _i, _p],
     'e2t_cast_pack': [_p, _l, _l, _i, _i, _p, _i, _p],

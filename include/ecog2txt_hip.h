@@ -34,11 +34,11 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 3
+#define E2T_ABI_VERSION 4
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
- * which = 0 e2t_gemm_epilogue, 1 e2t_lstm_desc, 2 e2t_pack_desc, 3 e2t_adam_hyper, 4 e2t_dropout; -1 for any other value */
+ * which = 0 e2t_gemm_epilogue, 1 e2t_lstm_desc, 2 e2t_pack_desc, 3 e2t_adam_hyper, 4 e2t_dropout, 5 e2t_gemm_call; -1 for any other value */
 int e2t_sizeof(int which);
 const char* e2t_last_error(void);          /* thread-local, host pointer */
 /* number of compute units / XCDs of `device`, 0 if no device is usable */
@@ -125,6 +125,16 @@ int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
  * gathered from the K-major LDS tile with the transposing read ds_read_b64_tr_b16. */
 int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep, void* stream);
+/* Several K-major products in ONE launch: the weight gradients of a backward stage (dW_x and dW_h of a layer; projection and
+ * decoder kernels of the head), trainers.py:318 (fit) with the kernel shapes of :527-541.  Same results as n calls of
+ * e2t_gemm_tn_bf16 with E2T_GEMM_SPLITK (the slabs are summed in fixed order); the K splits are chosen for the group as a whole,
+ * so that the workgroups of all products fill whole rounds of the chip.  n <= 8; every call carries its own epilogue (ep != NULL;
+ * the split-K workspace of the FIRST call's epilogue serves the whole group). */
+typedef struct e2t_gemm_call {
+    const void* A; int lda; const void* B; int ldb; void* C; int ldc; int M, N, K;
+    const e2t_gemm_epilogue* ep;
+} e2t_gemm_call;
+int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls /* host array */, void* stream);
 /* which instance e2t_gemm_{nt,tn}_bf16 would run this product on: *tile = 128 or 256 (square tiles), *splits = K splits
  * (1: none).  For profiling tools that attribute time to kernel instances (bench.py). */
 int e2t_gemm_plan(int tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int* tile, int* splits);

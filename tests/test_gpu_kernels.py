@@ -146,6 +146,54 @@ def test_gemm_batched_products_in_one_launch(hl, split):
     assert np.all(out[M * r8(N):c_stride] == 7.0)
 
 
+@pytest.mark.parametrize('ws_floats', [8 * 1024 * 1024, 600 * 1024, 1024])
+def test_gemm_tn_group_one_launch_for_several_products(hl, ws_floats):
+    """e2t_gemm_tn_group_bf16: several K-major products (different shapes, one of them batched, one with its last column
+    diverted, ragged edges) in ONE launch equal the products computed one by one -- with the K splits the library picks for
+    the group, with a workspace that only admits shallow splits, and with one too small for any split."""
+    rng = np.random.default_rng(17)
+    wsb = torch.zeros(ws_floats, dtype=torch.float32, device='cuda')
+    shapes = [(801, 400, 2300, 1), (72, 136, 1100, 2), (130, 70, 2000, 1), (37, 9, 70, 1), (256, 384, 4096, 1)]
+    calls = (hl.GemmCall * len(shapes))()
+    keep, checks = [], []
+    for i, (M, N, K, nb) in enumerate(shapes):
+        lda, ldb = nb * r8(M) + 8, nb * r8(N)
+        A = rng.standard_normal((K + 16, lda)); Bm = rng.standard_normal((K, ldb))
+        a, b = dev_bf16(A), dev_bf16(Bm)
+        ep = hl.GemmEpilogue(); ep.alpha = 1.0; ep.flags = hl.GEMM_SPLITK
+        ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        a_stride, b_stride, c_stride = 5 * lda + r8(M), r8(N), M * r8(N) + 40
+        if nb > 1:
+            ep.batch, ep.a_batch_stride, ep.b_batch_stride, ep.c_batch_stride = nb, a_stride, b_stride, c_stride
+        c = torch.full((nb * (M * r8(N) + 40),), 7.0, dtype=torch.float32, device='cuda')
+        lc = None
+        if i == 2:                   # last column of the product -> its own vector (the bias gradient of a transposed kernel)
+            lc = torch.full((M,), 7.0, dtype=torch.float32, device='cuda')
+            ep.last_col_out = lc.data_ptr()
+        calls[i].A, calls[i].lda, calls[i].B, calls[i].ldb = a.data_ptr(), lda, b.data_ptr(), ldb
+        calls[i].C, calls[i].ldc, calls[i].M, calls[i].N, calls[i].K = c.data_ptr(), r8(N), M, N, K
+        calls[i].ep = C.pointer(ep)
+        keep.append((a, b, ep))
+        checks.append((A, Bm, c, lc, M, N, K, nb, a_stride, b_stride, c_stride))
+    hl.lib.e2t_gemm_tn_group_bf16(len(shapes), calls, st())
+    torch.cuda.synchronize()
+    for (A, Bm, c, lc, M, N, K, nb, a_stride, b_stride, c_stride) in checks:
+        out = host(c)
+        Ar, Br = round_bf16(A), round_bf16(Bm)
+        for z in range(nb):
+            if nb > 1:
+                want = Ar[5 * z:5 * z + K, z * r8(M):z * r8(M) + M].T @ Br[:, z * r8(N):z * r8(N) + N]
+            else:
+                want = Ar[:K, :M].T @ Br[:, :N]
+            got = out[z * c_stride:z * c_stride + M * r8(N)].reshape(M, r8(N))
+            if lc is not None:
+                np.testing.assert_allclose(host(lc), want[:, N - 1], rtol=1e-5, atol=1e-4 * np.sqrt(K))
+                np.testing.assert_allclose(got[:, :N - 1], want[:, :N - 1], rtol=1e-5, atol=1e-4 * np.sqrt(K))
+            else:
+                np.testing.assert_allclose(got[:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+            assert np.all(got[:, N:] == 7.0)
+
+
 def test_gemm_splitk_runs_the_full_epilogue(hl):
     """Few output tiles + long K: the library splits K on its own when a workspace is offered, and the reduction
     applies the same bias / ReLU / dropout / row mask / bf16 epilogue (same Philox mask) as the direct store."""
