@@ -1114,26 +1114,24 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
     }
     if (m == 0) return E2T_OK;
     E2T_CHECK_ARG(ep0->splitk_ws && ep0->splitk_ws_bytes > 0);
-    // item depth: candidates from "no split at all" down to 16 K tiles (a workgroup's fixed cost -- DMA fill, slab store, its
-    // share of the reduction -- is worth ~8 of them); cost model: an item of d K tiles takes d + 5 tile times, a round of 512
-    // resident workgroups as long as its longest item
+    // Item depth = the LARGEST K depth that still yields about a round of workgroups (>= 300 of the 512 resident slots), never
+    // below 16 K tiles.  Measured on the train step (E2T_GEMM_GROUP_DEPTH sweep, cfg2): depth 16 / 23: 1.87 / 1.91 ms, 34: 1.765,
+    // 46: 1.75, 68: 1.742, no split at all: 1.75 -- beside the persistent BPTT the products are not short of workgroups, and
+    // every extra split is slab traffic plus a longer reduction; only a group with few tiles (the bottom layer's, at the tail of
+    // the step on an otherwise idle chip) needs the splits to fill it.
     int kmax = 0;
     for (int i = 0; i < m; ++i) kmax = std::max(kmax, kt[i]);
     static const int forced_depth = [] { const char* e = getenv("E2T_GEMM_GROUP_DEPTH"); return e ? atoi(e) : 0; }();      // (diagnostics)
-    int best_d = kmax; double best_c = 1e30;
+    int best_d = std::min(16, kmax);
     for (int d = kmax; d >= std::min(16, kmax); --d) {
-        long items = 0; size_t bytes = 0; int longest = 0;
+        long items = 0; size_t bytes = 0;
         for (int i = 0; i < m; ++i) {
             const int sp = (kt[i] + d - 1) / d;
             items += (long)tiles[i] * sp;
-            longest = std::max(longest, (kt[i] + sp - 1) / sp);
-            if (sp > 1) bytes += (size_t)sp * g.p[i].M * g.p[i].N * g.p[i].batch * sizeof(float);
+            if (sp > 1) bytes += ((size_t)sp * g.p[i].M * g.p[i].N * g.p[i].batch * sizeof(float) + 255) / 256 * 256;
         }
         if (bytes > ep0->splitk_ws_bytes) continue;
-        const double rounds = (double)((items + 511) / 512);
-        // the last round is as expensive as a full one unless it is nearly empty; splitting costs a reduction pass
-        const double c = rounds * (longest + 5.0) + (items > 0 && bytes > 0 ? 6.0 : 0.0);
-        if (c < best_c - 1e-9) { best_c = c; best_d = d; }
+        if (items >= 300 || d == std::min(16, kmax)) { best_d = d; break; }
     }
     if (forced_depth > 0) best_d = std::min(kmax, forced_depth);
     size_t off = 0;
