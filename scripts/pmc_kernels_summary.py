@@ -4,6 +4,8 @@ FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950: 128-B request
 import csv, json, sys, collections
 d, tag = sys.argv[1], sys.argv[2]
 def short(name):
+    if 'k_gemm_tn_group' in name: return 'tn128g'
+    if 'k_splitk_reduce_group' in name: return 'k_splitk_reduce_group'
     if 'k_gemm_nt<128, 128, 2, 2, true, true' in name: return 'tn128'
     if 'k_gemm_nt<128, 128, 2, 2, true, false' in name: return 'nt128'
     if 'k_gemm_nt<256, 256, 2, 4, false, true' in name: return 'tn256'
@@ -59,6 +61,6 @@ for k, c in acc.items():
 note = ('rocprofv3 --kernel-trace --pmc <one counter set per pass> over scripts/roofline_kernels.py (scripts/pmc_round.sh): per-launch averages, '
         'kernels launched in isolation on one stream; SQ_* in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs); FETCH_SIZE x2.')
 json.dump(dict(_note=note, **out), open('profiles/%s_pmc_kernels.json' % tag, 'w'), indent=1)
-json.dump(dict(_note=note, **{k: v for k, v in out.items() if k in ('tn128', 'nt128', 'nt256', 'k_splitk_reduce')}), open('profiles/%s_pmc_gemm.json' % tag, 'w'), indent=1)
+json.dump(dict(_note=note, **{k: v for k, v in out.items() if k in ('tn128g', 'tn128', 'tn256', 'nt128', 'nt256', 'k_splitk_reduce', 'k_splitk_reduce_group')}), open('profiles/%s_pmc_gemm.json' % tag, 'w'), indent=1)
 for k, v in out.items():
     print(k, v)
