@@ -46,7 +46,11 @@ void load_rccl() {
 }
 int need_rccl() {
     std::call_once(g_rccl_once, load_rccl);
-    if (!g_rccl.ok) { e2t_set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing"); return E2T_ERR_HIP; }
+    if (!g_rccl.ok) {
+        const char* why = dlerror();             // (the call clears the state: read it once)
+        e2t_set_error("librccl could not be loaded (%s)", why ? why : "symbols missing");
+        return E2T_ERR_HIP;
+    }
     return E2T_OK;
 }
 }  // namespace
@@ -89,8 +93,18 @@ extern "C" int e2t_comm_init(e2t_comm** out, int rank, int nranks, const void* i
     memcpy(&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
     if (r != ncclSuccess) { e2t_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString(r)); delete c; return E2T_ERR_HIP; }
-    E2T_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < E2T_NEVENTS; ++i) E2T_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    // (a failure below must not leak the communicator, the stream or the events made so far)
+    hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    int nev = 0;
+    for (; he == hipSuccess && nev < E2T_NEVENTS; ++nev) he = hipEventCreateWithFlags(&c->ev[nev], hipEventDisableTiming);
+    if (he != hipSuccess) {
+        e2t_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(he));
+        for (int i = 0; i + 1 < nev; ++i) (void)hipEventDestroy(c->ev[i]);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        (void)g_rccl.CommDestroy(c->comm);
+        delete c;
+        return E2T_ERR_HIP;
+    }
     *out = c;
     return E2T_OK;
 }
@@ -115,10 +129,12 @@ static int order_after(e2t_comm* c, void* after_stream) {
     E2T_HIP(hipStreamWaitEvent(c->stream, e, 0));
     return E2T_OK;
 }
+// a ticket is the RUNNING index of its event (not the ring slot), so that e2t_comm_wait can tell a ticket whose slot has been
+// reused since -- two events are taken per collective, i.e. after 32 later collectives -- from a live one
 static int ticket(e2t_comm* c, int* out) {
-    const unsigned t = c->next++ % E2T_NEVENTS;
-    E2T_HIP(hipEventRecord(c->ev[t], c->stream));
-    if (out) *out = (int)t;
+    const unsigned t = c->next++;
+    E2T_HIP(hipEventRecord(c->ev[t % E2T_NEVENTS], c->stream));
+    if (out) *out = (int)(t & 0x7FFFFFFFu);
     return E2T_OK;
 }
 
@@ -144,12 +160,17 @@ extern "C" int e2t_comm_broadcast(e2t_comm* c, void* buf, size_t bytes, int root
 }
 
 extern "C" int e2t_comm_wait(e2t_comm* c, int ticket_id, void* stream) {
-    E2T_CHECK_ARG(c && ticket_id < E2T_NEVENTS);
+    E2T_CHECK_ARG(c);
     if (ticket_id < 0) {                                   // everything issued so far
         int t;
         if (int rc = ticket(c, &t)) return rc;
         ticket_id = t;
     }
-    E2T_HIP(hipStreamWaitEvent((hipStream_t)stream, c->ev[ticket_id], 0));
+    const unsigned age = ((c->next & 0x7FFFFFFFu) - (unsigned)ticket_id) & 0x7FFFFFFFu;      // events taken since, this one included
+    if (age == 0 || age > E2T_NEVENTS) {
+        e2t_set_error("e2t_comm_wait: ticket %d is stale (its event was reused: at most %d collectives may be outstanding)", ticket_id, E2T_NEVENTS / 2);
+        return E2T_ERR_ARG;
+    }
+    E2T_HIP(hipStreamWaitEvent((hipStream_t)stream, c->ev[(unsigned)ticket_id % E2T_NEVENTS], 0));
     return E2T_OK;
 }

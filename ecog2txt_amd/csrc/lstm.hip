@@ -1542,6 +1542,13 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
 #pragma unroll
                 for (int i = 0; i < 8; ++i) big |= x[i];
                 if (__any((big & 0x40004000u) != 0u)) {
+                    // |x| >= 2 somewhere in this wave's publish.  Finite values saturate in the exchange copy (counted in err[8]:
+                    // the host warns); a NaN or an infinity must not be turned into a finite gradient -- it invalidates the step
+                    // like a timed-out wait does (err[0]: the optimiser kernels skip their update, check_sync() raises)
+                    unsigned nonfinite = 0u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) nonfinite |= (unsigned)((x[i] & 0x7F80u) == 0x7F80u) | (unsigned)((x[i] & 0x7F800000u) == 0x7F800000u);
+                    if (__any(nonfinite != 0u)) { if (lane == 0) atomicCAS((int*)pa.err, 0, 7); }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[i] = (x[i] | (((x[i] & 0x40004000u) >> 14) * 0x3FFFu)) & 0xBFFFBFFFu;
                     if (lane == 0) atomicAdd(pa.err + 8, 1);     // visible to the host: recurrent gate gradients were clipped

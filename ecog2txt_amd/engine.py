@@ -2009,6 +2009,9 @@ class Seq2SeqEngine:
                 for k in ('hx', 'dgx', 'counters', 'flagsb', 'flagsbb', 'dgxb'):
                     if k in lw:
                         lw[k].zero_()
+        if info[0] == 7:
+            raise RuntimeError('persistent BPTT: a recurrent gate gradient was NaN or infinite (results of this step are invalid, '
+                               'the weights were not updated) %r' % (info,))
         raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid, the '
                            'weights were not updated; E2T_PERSISTENT=0 selects the launch-per-step kernels) %r' % (info,))
 

@@ -118,10 +118,9 @@ class RcclSync:
         self.rank, self.world = rank, world
         self.sum_of_global_means = sum_of_global_means
         comm = C.c_void_p()
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
-        # CUs reserved for the exchange: the persistent recurrences of cfg2 occupy 200 (forward) / 224 (BPTT) of the 256 CUs
-        # for a whole layer sweep, one workgroup each; RCCL's channel kernels (one workgroup per channel) get the other 32
-        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0 -- the host driver only supports dmabuf IPC -- and NCCL_MAX_NCHANNELS=32 -- the CUs the
+        #  persistent recurrences leave to RCCL's channel kernels -- are defaulted at package import, ecog2txt_amd/__init__.py:
+        #  the HSA runtime reads its variable when it initialises, long before a communicator is made)
         lib.e2t_comm_init(C.byref(comm), rank, world, unique_id, int(device))
         self.comm = comm
         self.pending_ranges = []
@@ -180,6 +179,10 @@ class RcclSync:
             self.comm = None
 
 
+_BOOTSTRAPS = 0
+_OWN_STORE = {}
+
+
 def share_from_rank0(payload, rank, world, group=None, port_offset=1, key='e2t_rccl_uid'):
     """Hand rank 0's bytes to every rank -- bootstrap only.  Through an existing torch.distributed group if there is one;
     else through the launcher's own store when torch.distributed.run hosts one on MASTER_PORT (the workers connect as
@@ -195,11 +198,21 @@ def share_from_rank0(payload, rank, world, group=None, port_offset=1, key='e2t_r
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500'))
     timeout = datetime.timedelta(seconds=300)
+    # every bootstrap of a job gets its own key: the ranks call this function the same number of times (once per communicator,
+    # and SequenceNetwork makes a new one whenever the subject set changes), so a per-process counter agrees across ranks -- with
+    # one key for all of them a worker that reaches `get` before rank 0's `set` would read the PREVIOUS unique id
+    global _BOOTSTRAPS
+    _BOOTSTRAPS += 1
     if os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True':
         store = dist.TCPStore(addr, port, world, is_master=False, timeout=timeout, wait_for_workers=False)
-        key = '%s/%s/%s' % (key, os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
+        key = '%s/%s/%s/%d' % (key, os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), _BOOTSTRAPS)
     else:
-        store = dist.TCPStore(addr, port + port_offset, world, is_master=(rank == 0), timeout=timeout)
+        store = _OWN_STORE.get((addr, port + port_offset))
+        if store is None:
+            # kept for the life of the process: rank 0 hosts the server, and a slow worker's `get` must still find it
+            store = dist.TCPStore(addr, port + port_offset, world, is_master=(rank == 0), timeout=timeout)
+            _OWN_STORE[(addr, port + port_offset)] = store
+        key = '%s/%d' % (key, _BOOTSTRAPS)
     if rank == 0:
         store.set(key, payload)
     return store.get(key)

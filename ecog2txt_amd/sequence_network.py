@@ -331,9 +331,14 @@ class SequenceNetwork:
         return res
 
     def _get_sync(self, eng):
-        """The gradient exchange of this process layout (None for one process); made once per engine."""
+        """The gradient exchange of this process layout (None for one process); made once per engine.  A new engine (the
+        subject set changed: sequential_transfer_learn fits one subject at a time) gets a new exchange; the previous
+        communicator is destroyed first."""
         if getattr(self, '_sync_for', None) is not eng:
             from .parallel import make_sync
+            old = getattr(self, '_sync', None)
+            if old is not None and hasattr(old, 'close'):
+                old.close()
             self._sync = make_sync(eng.store.g, self.process_group)
             self._sync_for = eng
         return self._sync
@@ -515,6 +520,10 @@ class SequenceNetwork:
         import torch
         sync = getattr(self, '_sync', None)
         if (sync.rank if sync is not None else int(os.environ.get('RANK', '0'))) != 0:
+            # the other ranks wait until rank 0 has the files in place: the next fit(_restore_epoch=...) / restore_and_assess
+            # restores on EVERY rank and must not meet a missing or half-written checkpoint
+            if sync is not None:
+                sync.barrier()
             return
         # float32, as the reference's TF1 Saver stores (and restores into) its variables: a DT_DOUBLE entry would be
         # rejected by the reference on restore
@@ -524,12 +533,17 @@ class SequenceNetwork:
         arrays['__adam_v'] = eng.store.v.cpu().numpy()
         arrays['__step'] = eng.step_t.cpu().numpy()
         os.makedirs(os.path.dirname(self.checkpoint_path) or '.', exist_ok=True)
-        np.savez(self._ckpt(epoch) + '.npz', **arrays)
+        # written under temporary names and moved into place (os.replace is atomic): a reader never sees a partial file
+        tmp = self._ckpt(epoch) + '.tmp%d' % os.getpid()
+        np.savez(tmp + '.npz', **arrays)
+        os.replace(tmp + '.npz', self._ckpt(epoch) + '.npz')
         # the same variables (weights + EMA shadows, reference naming grammar) as a TensorFlow V2 checkpoint:
         # `model.ckpt-<epoch>.index` is what the trainer's restore_epoch scan looks for (trainers.py:235-252), and the
         # pair is readable by TF's own checkpoint reader (recover_model_sizes, trainers.py:444-554)
         from . import tf_checkpoint
         tf_checkpoint.write_checkpoint(self._ckpt(epoch), {k: v for k, v in arrays.items() if not k.startswith('__')})
+        if sync is not None:
+            sync.barrier()
 
     def _restore(self, eng, epoch, reuse_vars_scope):
         import torch

@@ -337,6 +337,9 @@ def write_checkpoint(prefix, arrays):
     items = []
     offset = 0
     os.makedirs(os.path.dirname(prefix) or '.', exist_ok=True)
+    # both files are written under temporary names and moved into place, the data shard first and the `.index` -- the file a
+    # restore scans for (trainers.py:235-252) -- last: a reader that finds the index finds a complete checkpoint
+    final_prefix, prefix = prefix, prefix + '.tmp%d' % os.getpid()
     with open(_shard_name(prefix, 0, 1), 'wb') as f:
         for name in sorted(arrays, key=lambda s: s.encode('utf-8')):
             a = np.asarray(arrays[name], order='C')              # (ascontiguousarray would turn a scalar into shape (1,))
@@ -355,3 +358,5 @@ def write_checkpoint(prefix, arrays):
             offset += len(raw)
     header = _varint((1 << 3) | 0) + _varint(1) + _ld(3, _varint((1 << 3) | 0) + _varint(1))     # num_shards 1, version.producer 1
     write_table(prefix + '.index', [(b'', header)] + items)
+    os.replace(_shard_name(prefix, 0, 1), _shard_name(final_prefix, 0, 1))
+    os.replace(prefix + '.index', final_prefix + '.index')

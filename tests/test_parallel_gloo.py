@@ -198,8 +198,14 @@ def test_unique_id_bootstrap_through_the_launchers_store(tmp_path):
         "sys.path.insert(0, %r)\n"
         "from ecog2txt_amd import parallel\n"
         "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "import time\n"
         "got = parallel.share_from_rank0(bytes(range(128)) if rank == 0 else None, rank, world)\n"
         "assert got == bytes(range(128)), got\n"
+        "# a SECOND bootstrap in the same job (a new communicator after the subject set changed): rank 0 is late (it is still\n"
+        "# writing a checkpoint, say) -- the early rank must wait for the new id, not read the first one again\n"
+        "if rank == 0: time.sleep(1.5)\n"
+        "got2 = parallel.share_from_rank0(bytes(range(1, 129)) if rank == 0 else None, rank, world)\n"
+        "assert got2 == bytes(range(1, 129)), got2\n"
         "print('rank', rank, 'ok', flush=True)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
     def free_port():
