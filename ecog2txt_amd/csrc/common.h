@@ -122,6 +122,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Diagnostic switches.  The PRODUCT library reads no environment variables on its compute paths: every E2T_* knob that
+// selects a kernel variant or hands a debug buffer to a kernel exists only in the diagnostics build (build.sh with
+// E2T_DEBUG=1 -> libecog2txt_hip_dbg.so, used by scripts/: -DE2T_DEBUG); here it folds to its default at compile time.
+#ifdef E2T_DEBUG
+#include <stdlib.h>
+static inline int e2t_dbg_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline const char* e2t_dbg_str(const char* name) { return getenv(name); }
+static inline void* e2t_dbg_ptr(const char* name) { const char* e = getenv(name); return e ? (void*)strtoull(e, nullptr, 0) : nullptr; }
+#else
+static inline constexpr int e2t_dbg_int(const char*, int dflt) { return dflt; }
+static inline constexpr const char* e2t_dbg_str(const char*) { return nullptr; }
+static inline constexpr void* e2t_dbg_ptr(const char*) { return nullptr; }
+#endif
+
 // host-side status plumbing -------------------------------------------------
 #define E2T_OK 0
 #define E2T_ERR_ARG 1

@@ -890,7 +890,7 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
     struct ConvCfg { int ks, ns, splits, ub, ws; };
     static const ConvCfg cfg = [] {
         ConvCfg r{64, 2, 0, 64, 4};
-        const char* e = getenv("E2T_CONV_FWD");
+        const char* e = e2t_dbg_str("E2T_CONV_FWD");
         if (!e) return r;
         if (e[0] == 'w' && e[1] == 's') { int d = 0, sp = 0; const int got = sscanf(e + 2, "%dx%d", &d, &sp); if (got >= 1 && (d == 4 || d == 6)) r.ws = d; if (got >= 2) r.splits = sp; return r; }
         int k = 0, n = 0, sp = 0, u = 0;
@@ -944,13 +944,13 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
 
 struct GemmPlan { int tile, splits, batch; bool want_split; };
 static int gemm_order() {
-    static const int o = [] { const char* e = getenv("E2T_GEMM_ORDER"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    static const int o = e2t_dbg_int("E2T_GEMM_ORDER", 1) == 0 ? 0 : 1;
     return o;
 }
 // Which instance a product runs on, and its split count (shared by the launcher and e2t_gemm_plan).
 static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue* ep) {
     // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
-    static const int forced = [] { const char* e = getenv("E2T_GEMM_TILE"); return e ? atoi(e) : 0; }();      // (thread-safe init)
+    static const int forced = e2t_dbg_int("E2T_GEMM_TILE", 0);
     // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
     // product has too few 128x128 tiles to fill the chip and a long K loop (conv front-end, input gradients of narrow
     // layers).  Partial slabs go to the caller's workspace; k_splitk_reduce sums them and applies the epilogue.
@@ -964,10 +964,10 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     bool big = !tn && !want_split && !rich && t256 >= 192 && K >= 64;
     // K-major products with both output dimensions large (cfg4's weight gradients: 2049 x 8192, 1024 x 4096 x 2): 256 x 256 tiles
     // halve the bytes staged per flop; E2T_TN256=0 keeps the 128 x 128 instance
-    static const bool tn256_ok = [] { const char* e = getenv("E2T_TN256"); return !(e && atoi(e) == 0); }();
+    static const bool tn256_ok = e2t_dbg_int("E2T_TN256", 1) != 0;
     const int nbatch = (ep && ep->batch > 1) ? ep->batch : 1;
-    static const int tn256_min = [] { const char* e = getenv("E2T_TN256_MIN"); return e ? atoi(e) : 1024; }();        // (diagnostics)
-    static const int tn256_tiles = [] { const char* e = getenv("E2T_TN256_TILES"); return e ? atoi(e) : 64; }();
+    static const int tn256_min = e2t_dbg_int("E2T_TN256_MIN", 1024);
+    static const int tn256_tiles = e2t_dbg_int("E2T_TN256_TILES", 64);
     const bool big_tn = tn && tn256_ok && !rich && have_ws && M >= tn256_min && N >= tn256_min && t256 * nbatch >= tn256_tiles && forced != 128;
     if (big_tn) big = true;
     if (forced == 128) big = false;
@@ -999,7 +999,7 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
         // (measured, E2T_GEMM_SPLITS sweep, dW_x 801 x 3200 x 8704 = 175 tiles: 1 split 114 us, 2: 92, 3: 105, 4: 94; batched
         //  dW_h 104 tiles: 1: 109, 2: 67, 3: 63, 4: 56 -- a workgroup ALONE on a CU is not faster than one of two: a K tile
         //  costs ~0.8 us of LDS-DMA issue + wait + barrier either way, so filling both slots of every CU is what counts)
-        { static const int forced_s = [] { const char* e = getenv("E2T_GEMM_SPLITS"); return e ? atoi(e) : 0; }(); if (forced_s > 0) s = forced_s; }
+        { static const int forced_s = e2t_dbg_int("E2T_GEMM_SPLITS", 0); if (forced_s > 0) s = forced_s; }
         const size_t per = (size_t)M * N * sizeof(float) * pl.batch;
         if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
         if (s < 1) s = 1;
@@ -1063,7 +1063,7 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, RICH_, TN_, KT_, NS_, D_>), grid, dim3(64 * WM_ * WN_), lds_, st, p); \
     } while (0)
     // E2T_GEMM_DBG=1|2|3 selects the timing-only forms of the 128 x 128 instances (scripts/gemm_loop_probe.py)
-    static const int dbg = [] { const char* e = getenv("E2T_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = e2t_dbg_int("E2T_GEMM_DBG", 0);
     if (tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 1);
     else if (tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 2);
     else if (tn && !big && dbg == 3) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 3);
@@ -1121,7 +1121,7 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
     // the step on an otherwise idle chip) needs the splits to fill it.
     int kmax = 0;
     for (int i = 0; i < m; ++i) kmax = std::max(kmax, kt[i]);
-    static const int forced_depth = [] { const char* e = getenv("E2T_GEMM_GROUP_DEPTH"); return e ? atoi(e) : 0; }();      // (diagnostics)
+    static const int forced_depth = e2t_dbg_int("E2T_GEMM_GROUP_DEPTH", 0);
     int best_d = std::min(16, kmax);
     for (int d = kmax; d >= std::min(16, kmax); --d) {
         long items = 0; size_t bytes = 0;

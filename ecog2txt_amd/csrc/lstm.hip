@@ -640,237 +640,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
 #undef PSTAMP
 }
 
-// ---------------------------------------------------------------------------
-// Persistent forward recurrence with the state SHARED through LDS (H <= 416): workgroup = 16 utterances (one row tile)
-// x 64 units x direction; wave w owns unit tile ug*4 + w with the weights, lane <-> cell map, K halves, saves and stamped
-// exchange of k_lstm_seq_fwd_persist (results are bit-identical) -- but the row tile's state is pulled once per
-// workgroup instead of once per unit tile: every wave loads a quarter of the k-blocks and the four share them through
-// LDS.  L2 -> CU traffic per step falls from (#unit tiles = 25) x state to (#unit groups = 7) x state (10.6 -> 3.0 MB at
-// cfg2), and a wave issues 3-4 stamped loads per step instead of 13.
-// ---------------------------------------------------------------------------
-template <int KB>
-__global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_shared(LstmPersistArgs pa) {
-    const LstmFwdArgs& p = pa.a;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int B = p.B, H = p.H, S = p.S;
-    const int RB = (B + 63) >> 6, RT = (B + 15) >> 4;
-    const int UG = (p.UT + 3) >> 2;
-    const int ncl = RT * p.ndir;
-    const int cl = blockIdx.x % ncl, ug = blockIdx.x / ncl;      // cluster-major ids: cluster c sits on XCD c % 8
-    if (ug >= UG) return;
-    const int rt = cl % RT, dir = cl / RT;
-    const int ut = ug * 4 + wave;                                // this wave's unit tile (may not exist in the last group)
-    const bool tile_ok = ut < p.UT;
-    const int utc = tile_ok ? ut : p.UT - 1;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int NH = p.ndir * H;
-    const int b = rt * 16 + frow;
-    const int bc = min(b, B - 1);
-    const int len = (b < B) ? p.lens[b] : 0;
-    const int u0 = ut * 16 + fq * 4;                              // this lane's 4 consecutive units (H % 4 == 0)
-    const bool own = (b < B) && tile_ok && (u0 < H);
-    const unsigned long long key = p.drop.seed + ((p.drop.rate > 0.f && p.drop.step) ? (unsigned long long)(*p.drop.step) : 0ull);
-    constexpr int npr = KB >> 1;
-
-    // ---- once: W_h fragments of (dir, ut): [gate][k-block] ----
-    bf16x8 W[KB][4];
-    {
-        const uint4* wsrc = (const uint4*)p.WhF + ((size_t)(dir * 4) * p.UT + utc) * KB * 64 + lane;
-        const size_t wgs = (size_t)p.UT * KB * 64;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { const uint4 v = wsrc[g * wgs + (size_t)kb * 64]; W[kb][g] = *(const bf16x8*)&v; }
-    }
-    float cst[4] = {0.f, 0.f, 0.f, 0.f};                          // c of this lane's 4 cells, carried in registers
-    if (own && len > 0 && p.c0) { const float4 c = *(const float4*)(p.c0 + (size_t)b * NH + dir * H + u0); cst[0] = c.x; cst[1] = c.y; cst[2] = c.z; cst[3] = c.w; }
-    // Gx of the lane's 4 units at its utterance's time index: 64 contiguous bytes.  Prefetched TWO steps ahead by
-    // LDS-DMA into a wave-private ring of three buffers ([buffer][r][lane] float4) -- no registers are involved, so the
-    // compiler cannot pull the wait for it into the critical path.  It is issued right after a step's state has landed
-    // (VMEM returns in order: issued in front of the state loads it would be waited for with them) and is covered by the
-    // state waits of the two following steps, which is enough for an HBM miss (long sequences: Gx no longer fits the
-    // 256-MB infinity cache; one step ahead cost 4.5 instead of 3.0 us per step at S = 167).
-    uint4* gxl = lstm_smem + (size_t)wave * (3 * 4 * 64);
-    auto gx_load = [&](int s) {
-        const bool act = own && s < len;
-        const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
-        const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s % 3) * 4 + r) * 64));
-    };
-    gx_load(0);
-    if (S > 1) gx_load(1);
-    // Stamp convention (see the state loads below).  Every slot of an exchange buffer ends a launch on the same stamp
-    // (all producers make the same number of writes); the new launch starts on the opposite one, so leftovers -- of the
-    // previous launch or of the initial fill -- never look fresh, and no flag, counter or reset pass is needed.  The
-    // leftover stamps (bit q = buffer q) live in one word per cluster behind the buffers; the cluster's first workgroup
-    // updates it when it is done -- a cluster cannot finish before all its members have started and read the word.
-    // (Reading the leftover from the wave's own slot instead fails for waves that own none but still check others' rows.)
-    const size_t hx_slot = ((((size_t)p.ndir * 0 + dir) * (RB * 4) + rt) * KB + (ut >> 1)) * 512 + (((ut & 1) * 2 + (fq >> 1)) * 16 + frow) * 8 + (fq & 1) * 4;
-    const size_t hx_buf = (size_t)p.ndir * (RB * 4) * KB * 512;          // elements per step-parity buffer
-    unsigned* hxw = (unsigned*)(pa.hx + 2 * hx_buf) + cl;
-    const unsigned left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hxw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const unsigned base[2] = {(left & 1u) ^ 1u, ((left >> 1) & 1u) ^ 1u};
-    long long pts[8];
-    const long long t_entry = p.dbg ? wall_clock64() : 0;
-#define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)      // 100 MHz, chip-wide
-
-    for (int s = 0; s < S; ++s) {
-        PSTAMP(0);
-        // ---- h_{t-1} fragments of this lane's utterance (MFMA B operand: k = kb*32 + fq*8 .. +8) ----
-        const bool active = s < len;
-        const int t = dir ? (len - 1 - s) : s;
-        // The state of the workgroup's 16 utterances is pulled ONCE: wave w loads k-blocks w, w+4, ... (checks and strips
-        // their stamps in registers, as the narrow kernel does for all of them), parks them in LDS, and after one barrier
-        // every wave reads all KB fragments from there.  Double-buffered by step parity: a wave may write step s+1's image
-        // while a slower one still reads step s's; the barrier of step s+1 keeps it from reaching step s+2's write early.
-        constexpr int KW = (KB + 3) / 4;
-        u32x4 ldv[KW];
-        uint4* simg = lstm_smem + 4 * 3 * 4 * 64 + (s & 1) * (KB * 64);
-        if (s == 0) {
-            // initial state from the row-major array: block 0 (forward), the all-zero slack block S+1 (backward);
-            // rows that are inactive or beyond B read block 0 (finite, result discarded)
-            size_t tau = 0, srb = bc;
-            if (active && dir == 1) { tau = (size_t)S + 1; srb = 0; }
-            const bf16_t* src = p.Yext + (tau * B + srb) * p.ldy + dir * p.H8 + fq * 8 + wave * 32;
-#pragma unroll
-            for (int i = 0; i < KW; ++i)
-                if (wave + 4 * i < KB)
-                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ldv[i]) : "v"(src), "i"(i * 256) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < KW; ++i) asm volatile("" : "+v"(ldv[i]));            // uses stay behind the wait
-        } else {
-            const bf16_t* src = pa.hx + (((((size_t)((s - 1) & 1) * p.ndir + dir) * (RB * 4) + rt) * KB + wave) * 64 + lane) * 8;
-            const bool tag1 = ((((s - 1) >> 1) & 1) ^ ((s - 1) & 1 ? base[1] : base[0])) != 0;      // wave-uniform
-            const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
-            int spins = 0;
-            for (;;) {
-                // (nothing between the issue and the wait: see k_lstm_seq_fwd_persist)
-#pragma unroll
-                for (int i = 0; i < KW; ++i)
-                    if (wave + 4 * i < KB)
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ldv[i]) : "v"(src + (size_t)i * 2048) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < KW; ++i) asm volatile("" : "+v"(ldv[i]));
-                unsigned ma = 0xFFFFFFFFu, mo = 0u;
-#pragma unroll
-                for (int i = 0; i < KW; ++i) {
-                    const int kb = wave + 4 * i;
-                    const bool chk = kb < KB && (kb < KB - 1 || chk_last);
-                    const unsigned a_ = ldv[i][0] & ldv[i][1] & ldv[i][2] & ldv[i][3], o_ = ldv[i][0] | ldv[i][1] | ldv[i][2] | ldv[i][3];
-                    ma &= chk ? a_ : 0xFFFFFFFFu; mo |= chk ? o_ : 0u;
-                }
-                const bool fresh = tag1 ? ((ma & 0x40004000u) == 0x40004000u) : ((mo & 0x40004000u) == 0u);
-                // rows that are inactive at this step (or beyond B) may hold anything: their results are discarded
-                if (__all(fresh || !active)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
-                if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            if (tag1) {
-#pragma unroll
-                for (int i = 0; i < KW; ++i) ldv[i] &= 0xBFFFBFFFu;      // strip the stamps before the MFMAs
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < KW; ++i)
-            if (wave + 4 * i < KB) simg[(wave + 4 * i) * 64 + lane] = make_uint4(ldv[i][0], ldv[i][1], ldv[i][2], ldv[i][3]);
-        __syncthreads();
-        u32x4 st[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) { const uint4 v = simg[kb * 64 + lane]; st[kb] = (u32x4){v.x, v.y, v.z, v.w}; }
-        PSTAMP(2);
-        if (s + 2 < S) gx_load(s + 2);
-
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pp = 0; pp < npr; ++pp) {                           // k-block pairs; parity = the K half of the step kernel
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp][g], *(bf16x8*)&st[2 * pp], acc[pp & 1][g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[pp & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * pp + 1][g], *(bf16x8*)&st[2 * pp + 1], acc[pp & 1][g], 0, 0, 0);
-        }
-        if (KB & 1) {                                                // odd tail k-block: the half that owns pair index npr
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[npr & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[KB - 1][g], *(bf16x8*)&st[KB - 1], acc[npr & 1][g], 0, 0, 0);
-        }
-        PSTAMP(3);
-
-        // ---- lane-local cell update for (utterance b, units u0..u0+3): critical part ----
-        float gi[4], gj[4], gf[4], go[4], hv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint4 graw = gxl[((s % 3) * 4 + r) * 64 + lane];
-            const float gxv[4] = {__uint_as_float(graw.x), __uint_as_float(graw.y), __uint_as_float(graw.z), __uint_as_float(graw.w)};
-            gi[r] = fsigmoid((acc[0][0][r] + acc[1][0][r]) + gxv[0]);
-            gj[r] = ftanh((acc[0][1][r] + acc[1][1][r]) + gxv[1]);
-            gf[r] = fsigmoid((acc[0][2][r] + acc[1][2][r]) + gxv[2] + p.forget_bias);
-            go[r] = fsigmoid((acc[0][3][r] + acc[1][3][r]) + gxv[3]);
-            const float cv = fmaf(gf[r], cst[r], gi[r] * gj[r]);
-            hv[r] = go[r] * ftanh(cv);
-            if (active) cst[r] = cv;
-        }
-        unsigned long long hb = 0ull;
-        if (active) hb = (unsigned long long)f2bf(hv[0]) | ((unsigned long long)f2bf(hv[1]) << 16) | ((unsigned long long)f2bf(hv[2]) << 32) | ((unsigned long long)f2bf(hv[3]) << 48);
-        if (own && s + 1 < S) {
-            // write-through store into the exchange buffer: unit u0 sits in k-block ut/2, k-group (ut&1)*2 + fq/2,
-            // half (fq&1) of the 16-B lane slot.  EVERY owned slot is rewritten EVERY step (padded positions: zeros),
-            // so all stamps of a buffer move together.
-            unsigned long long* hp = (unsigned long long*)(pa.hx + (s & 1) * hx_buf + hx_slot);
-            const unsigned long long stamp = ((((s >> 1) & 1) ^ (s & 1 ? base[1] : base[0])) != 0) ? 0x4000400040004000ull : 0ull;
-            __hip_atomic_store(hp, hb | stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        PSTAMP(4);
-        PSTAMP(5);
-        // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
-        if (own) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
-            const size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
-            *(unsigned long long*)(p.Yext + (blk * B + b) * p.ldy + dir * p.H8 + u0) = hb;
-        }
-        if (own) {
-            if (active) {
-                const size_t m = (size_t)t * B + b;
-                const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi[r], gj[r], gf[r], go[r]);
-                ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
-                ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
-                if (p.Ydrop) {
-                    float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
-                    nt_store_bf4(p.Ydrop + m * p.ldy + dir * p.H8 + u0, f2bf(hv[0] * dsc4[0]), f2bf(hv[1] * dsc4[1]), f2bf(hv[2] * dsc4[2]), f2bf(hv[3] * dsc4[3]));
-                }
-            } else if (p.Ydrop) {
-                *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
-            }
-        }
-        PSTAMP(6);
-        if (p.dbg && s == S / 2 && lane == 0)
-            for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
-        if (p.dbg && s == 0 && lane == 0) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = wall_clock64() - t_entry;   // prologue + step 0
-    }
-    if (ug == 0 && threadIdx.x == 0) {
-        // stamps the buffers are left with: buffer q was written at steps q, q+2, ... <= S-2 with stamps base, !base, ...
-        unsigned nl = left;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int nwr = (S - 1 > q) ? (S - q) / 2 : 0;
-            if (nwr > 0) nl = (nl & ~(1u << q)) | ((((unsigned)(nwr - 1) & 1u) ^ base[q]) << q);
-        }
-        __hip_atomic_store(hxw, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (p.dbg && lane == 0) p.dbg[(size_t)(gridDim.x * 4) * 8 + (size_t)blockIdx.x * 4 + wave] = wall_clock64() - t_entry;
-#undef PSTAMP
-}
-
+// (A variant with the row tile's state pulled once per workgroup and shared through LDS -- 16 utterances x 64 units, L2 -> CU
+// traffic 10.6 -> 3.0 MB per step -- was built, bit-identical, and measured SLOWER: 3.20 vs 2.89 us per step; the step is bound
+// by the hand-off latency, and the LDS hop + barrier add more than the lighter load burst saves.  Removed in round 3;
+// DESIGN.md keeps the numbers.)
 
 // ---------------------------------------------------------------------------
 // Persistent forward recurrence, WIDE layers (14 <= KB <= 26 k-blocks, i.e. 417 <= H <= 832: the decoder).
@@ -1603,7 +1376,7 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
-    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     const StepGeom G = step_geom(p.KB, 4, 4 * 256 + 1024);
@@ -1636,7 +1409,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     pa.hx = (bf16_t*)hx; pa.err = err;
-    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
     if (p.KB > 13 && p.KB <= 26 && d->H % 8 == 0) {
         // wide layer: 32 x 32 workgroups, K halves in the accumulation order of k_lstm_step_fwd (its LDS chunk geometry)
         LstmPersistWideArgs pw{};
@@ -1658,24 +1431,6 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
         const size_t ldsw = (size_t)(4 * 3 * 4 * 64 + 2 * 4 * 4 * 64) * 16;
 #define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist_wide<K>, dim3(nwgw), dim3(256), ldsw, (hipStream_t)stream, pw); break;
         switch (KH) { E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10) E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13) }
-#undef E2T_PERSIST_CASE
-        E2T_LAUNCH_CHECK();
-        return E2T_OK;
-    }
-    // state shared through LDS (16 utterances x 64 units per workgroup): E2T_FWD_SHARED=1.  Measured at cfg2 (B = 256,
-    // H = 400, S = 34): 3.20 us per step against 2.89 for the 64 x 16 tiling -- the L2 -> CU traffic falls 3.6x, but the step
-    // is bound by the hand-off LATENCY, and the LDS hop + barrier add more (state phase 0.80 vs 0.68 us, MFMA phase 0.72 vs
-    // 0.60) than the lighter load burst saves.  Kept (bit-identical, tested) as the variant for chips with fewer CUs.
-    const bool want_shared = [] { const char* e = getenv("E2T_FWD_SHARED"); return e && atoi(e) == 1; }();      // (read per call)
-    const int nwg_sh = ((d->B + 15) / 16) * d->ndir * ((p.UT + 3) / 4);
-    if (want_shared && p.KB <= 13 && d->H % 8 == 0 && nwg_sh <= num_cus) {
-        const size_t lds_sh = (size_t)(4 * 3 * 4 * 64 + 2 * p.KB * 64) * 16;
-#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist_shared<K>, dim3(nwg_sh), dim3(256), lds_sh, (hipStream_t)stream, pa); break;
-        switch (p.KB) {
-            E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)
-            E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10)
-            E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13)
-        }
 #undef E2T_PERSIST_CASE
         E2T_LAUNCH_CHECK();
         return E2T_OK;
@@ -1747,7 +1502,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     p.lddg = lddg; p.lddy = lddy;
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
     pa.dgx = (bf16_t*)dgx; pa.flags = flags; pa.err = err;
     const int RT = (d->B + 15) / 16;
     const int kq = (p.KB4 + 3) / 4;

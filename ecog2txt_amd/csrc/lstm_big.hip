@@ -377,9 +377,9 @@ extern "C" int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const float* Gx, con
     p.S = d->S; p.B = d->B; p.H = d->H; p.ndir = d->ndir; p.ldy = d->ldy; p.UT = d->H / 16; p.KB = d->H / 32;
     p.forget_bias = d->forget_bias;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    { const char* e = getenv("E2T_BIG_SPREAD_FWD"); p.spread = e ? atoi(e) : 1; if (p.spread != 2 && p.spread != 4 && p.spread != 8) p.spread = 1; }
+    p.spread = e2t_dbg_int("E2T_BIG_SPREAD_FWD", 1); if (p.spread != 2 && p.spread != 4 && p.spread != 8) p.spread = 1;
     step_fwd_halves(p.KB, p.kbl, p.nkb);
-    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
     const int KH = std::max(p.nkb[0], p.nkb[1]);
     const int nwg = ((d->B + 63) / 64) * d->ndir * (d->H / 32);
     if (KH > 16 || nwg > num_cus) {
@@ -670,8 +670,8 @@ extern "C" int e2t_lstm_seq_bwd_big(const e2t_lstm_desc* d, const void* WhB, voi
     p.dh_final = dh_final; p.dc_final = dc_final; p.dgx = (bf16_t*)dgx; p.flags = flags; p.err = err;
     p.S = d->S; p.B = d->B; p.H = d->H; p.ndir = d->ndir; p.lddg = lddg; p.lddy = lddy; p.UT = d->H / 16; p.KB4 = d->H / 8;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    { const char* e = getenv("E2T_LSTM_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
-    { const char* e = getenv("E2T_BIG_SPREAD_BWD"); p.spread = e ? atoi(e) : 1; if (p.spread != 2 && p.spread != 4 && p.spread != 8) p.spread = 1; }
+    p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
+    p.spread = e2t_dbg_int("E2T_BIG_SPREAD_BWD", 1); if (p.spread != 2 && p.spread != 4 && p.spread != 8) p.spread = 1;
     const int KQ = d->H / 32;
     const int nwg = ((d->B + 63) / 64) * d->ndir * (d->H / 32);
     if (nwg > num_cus) {

@@ -27,685 +27,9 @@ import torch
 
 from . import hip_lib as H
 from .hip_lib import lib
-
-PAD_ID, EOS_ID, OOV_ID = 0, 1, 2          # trainers.py:191-196
-
-STREAM_CONV, STREAM_ENC, STREAM_DEC_EMB, STREAM_DEC_OUT, STREAM_AUX = 1, 10, 20, 21, 30
-STREAM_CONV_PRE = 40      # + index of a conv layer in front of the one that feeds the encoder
-
-
-@contextlib.contextmanager
-def capture(graph):
-    """torch.cuda.graph(graph) with the cyclic garbage collector out of the way: a collection that runs DURING a stream
-    capture may destroy device objects of unrelated, dead Python objects (another engine's CUDAGraphs, events) -- HIP
-    refuses that while capturing and the destructor aborts the process.  (Seen: an exception's traceback kept a dead
-    engine alive in a reference cycle until the next capture.)"""
-    gc.collect()
-    was = gc.isenabled()
-    gc.disable()
-    kw = {}
-    if os.environ.get('E2T_CAPTURE_PRIO'):      # diagnostics: capture on a high-priority stream (do kernel nodes inherit it?)
-        kw['stream'] = torch.cuda.Stream(priority=int(os.environ['E2T_CAPTURE_PRIO']))
-    try:
-        with torch.cuda.graph(graph, **kw):
-            yield
-    finally:
-        if was:
-            gc.enable()
-
-
-def rk(x):
-    """Leading dimension of anything that serves as a GEMM K dimension: a multiple of the 64-wide K tile, zero
-    padded, so that k_gemm_nt never takes its register-staged K-tail path (measured: 98 -> 75 us on the encoder
-    input projection, scripts/bench_gemm_variants.py)."""
-    return (x + 63) // 64 * 64
-
-
-def r8(x):
-    return (x + 7) // 8 * 8
-
-
-def ceil_div(a, b):
-    return -(-a // b)
-
-
-@dataclass
-class NetSpec:
-    """Network sizes; field-for-field the manifest's layer_sizes & co.
-    (mocha-1_word_sequence.yaml:5-14, 56-69)."""
-    channels: Dict[object, int]
-    decimation: int = 12
-    enc_embed: int = 100
-    enc_rnn: List[int] = field(default_factory=lambda: [400, 400, 400])
-    dec_embed: int = 150
-    dec_rnn: int = 800
-    dec_proj_hidden: List[int] = field(default_factory=list)
-    vocab: int = 1806
-    aux_layer: Optional[int] = 1
-    aux_hidden: List[int] = field(default_factory=lambda: [225])
-    aux_dim: int = 13
-    aux_dist: str = 'Gaussian'
-    aux_scale: float = 1.0
-    # further auxiliary heads (one per additional 'encoder_<k>_targets' data key, trainers.py:94-102): dicts with layer,
-    # hidden, dim, dist, scale -- a simple path on the main stream; the first head keeps the overlapped schedule
-    aux_extra: List[dict] = field(default_factory=list)
-    dec_scale: float = 1.0
-    ff_dropout: float = 0.1
-    rnn_dropout: float = 0.5
-    forget_bias: float = 1.0
-    conv_relu: bool = True
-    # conv layers in front of the one that feeds the encoder (dicts with out, stride; the strides of the whole stack
-    # multiply to `decimation`, trainers.py:406-407; [BUILD-DEFINES] the split is given explicitly -- oracle/seq2seq.py)
-    conv_pre: List[dict] = field(default_factory=list)
-
-    def as_dict(self):
-        return asdict(self)
-
-
-def conv_stack(spec, Cc):
-    """[(in width, out width, stride)] of a subject's temporal-convolution stack, bottom up (oracle.conv_layers)."""
-    outs = [int(p['out']) for p in spec.conv_pre] + [spec.enc_embed]
-    strides = [int(p['stride']) for p in spec.conv_pre]
-    last = spec.decimation // int(np.prod(strides)) if strides else spec.decimation
-    assert last >= 1 and last * int(np.prod(strides or [1])) == spec.decimation, 'the conv strides must multiply to the decimation factor'
-    return list(zip([Cc] + outs[:-1], outs, strides + [last]))
-
-
-def conv_seg(sid, j):
-    """Parameter segment of conv layer j of subject sid ([stride*in + 1][out], bias last): the bottom layer keeps the
-    single-layer name."""
-    return 'conv%s.W' % sid if j == 0 else 'conv%s.W%d' % (sid, j)
-
-
-def conv_tf_name(sid, j, ci, co):
-    return 'seq2seq/subnet_%s/encoder_embedding_%d_%d_%d' % (sid, ci, co, j)
-
-
-def _tf2int(w, Hh):
-    """TF gate-major columns [..., 4H] (i|j|f|o) -> unit-major interleaved (u*4+g)."""
-    return w.reshape(w.shape[:-1] + (4, Hh)).swapaxes(-1, -2).reshape(w.shape)
-
-
-def _int2tf(w, Hh):
-    return w.reshape(w.shape[:-1] + (Hh, 4)).swapaxes(-1, -2).reshape(w.shape)
-
-
-class ParamStore:
-    """Flat fp32 master / grad / Adam / EMA buffers with named segments.
-
-    Segment order = order in which backward produces the gradients (vocab
-    projection first, per-subject conv last) so that contiguous ranges are the
-    all-reduce buckets of the data-parallel path."""
-
-    def __init__(self, spec, device):
-        self.spec, self.device = spec, device
-        self.segs = {}
-        self.order = []
-        off = 0
-
-        def add(name, *shape):
-            nonlocal off
-            n = int(np.prod(shape))
-            self.segs[name] = (off, tuple(shape))
-            self.order.append(name)
-            off += r8(n) if True else n        # keep every segment 32-B aligned
-
-        # decoder projection stack (last layer stored transposed, trainers.py:513-520)
-        sizes = [spec.dec_rnn] + list(spec.dec_proj_hidden) + [spec.vocab]
-        for i in range(len(sizes) - 2, -1, -1):
-            if i == len(sizes) - 2:
-                add('proj%d.WT' % i, sizes[i + 1], sizes[i]); add('proj%d.b' % i, sizes[i + 1])
-            else:
-                add('proj%d.W' % i, sizes[i] + 1, sizes[i + 1])
-        add('dec.Wx', spec.dec_embed + 1, 4 * spec.dec_rnn)
-        add('dec.Wh', 1, spec.dec_rnn, 4 * spec.dec_rnn)
-        add('dec.emb', spec.vocab, spec.dec_embed)
-        for l in range(len(spec.enc_rnn) - 1, -1, -1):
-            Hh = spec.enc_rnn[l]
-            if spec.aux_layer == l:
-                asz = [2 * Hh] + list(spec.aux_hidden) + [spec.aux_dim]
-                for i in range(len(asz) - 2, -1, -1):
-                    if i == len(asz) - 2:
-                        add('aux%d.WT' % i, asz[i + 1], asz[i]); add('aux%d.b' % i, asz[i + 1])
-                    else:
-                        add('aux%d.W' % i, asz[i] + 1, asz[i + 1])
-            for j, hx in enumerate(spec.aux_extra):
-                if hx['layer'] == l:
-                    asz = [2 * Hh] + list(hx.get('hidden', [])) + [hx['dim']]
-                    for i in range(len(asz) - 2, -1, -1):
-                        if i == len(asz) - 2:
-                            add('auxx%d_%d.WT' % (j, i), asz[i + 1], asz[i]); add('auxx%d_%d.b' % (j, i), asz[i + 1])
-                        else:
-                            add('auxx%d_%d.W' % (j, i), asz[i] + 1, asz[i + 1])
-            D = spec.enc_embed if l == 0 else 2 * spec.enc_rnn[l - 1]
-            add('enc%d.Wx' % l, D + 1, 2 * 4 * Hh)
-            add('enc%d.Wh' % l, 2, Hh, 4 * Hh)
-        self.shared_end = off
-        for sid, Cc in spec.channels.items():
-            lays = conv_stack(spec, Cc)
-            for j in range(len(lays) - 1, -1, -1):          # top conv layer first: the order backward produces them in
-                ci, co, n = lays[j]
-                add(conv_seg(sid, j), n * ci + 1, co)
-        self.n = off
-        z = lambda: torch.zeros(self.n, dtype=torch.float32, device=device)
-        self.p, self.g, self.m, self.v, self.ema = z(), z(), z(), z(), z()
-
-    def view(self, name, buf=None):
-        off, shape = self.segs[name]
-        buf = self.p if buf is None else buf
-        return buf[off:off + int(np.prod(shape))].view(*shape)
-
-    def ptr(self, name, buf=None, elem_off=0):
-        off, _ = self.segs[name]
-        buf = self.p if buf is None else buf
-        return buf.data_ptr() + 4 * (off + elem_off)
-
-    def seg_range(self, name):
-        off, shape = self.segs[name]
-        return off, off + r8(int(np.prod(shape)))
-
-    # ---- TF-layout names (checkpoint grammar, trainers.py:444-554) -------------
-    def tf_names(self):
-        s = self.spec
-        out = []
-        for sid, Cc in s.channels.items():
-            out.append('seq2seq/subnet_%s/encoder_embedding_%d_%d_0' % (sid, Cc, s.enc_embed))
-        return out
-
-    def import_tf(self, P, bufs=('p', 'ema')):
-        """Load a dict of TF-layout arrays (oracle.init_params naming) into the masters."""
-        s = self.spec
-        N = s.decimation
-        for bn in bufs:
-            buf = getattr(self, bn)
-
-            def put(name, arr):
-                self.view(name, buf).copy_(torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32))
-            for sid, Cc in s.channels.items():
-                for j, (ci, co, n) in enumerate(conv_stack(s, Cc)):
-                    nm = conv_tf_name(sid, j, ci, co)
-                    put(conv_seg(sid, j), np.concatenate([P[nm + '/weights'].reshape(n * ci, co), P[nm + '/biases'][None]], 0))
-            for l, Hh in enumerate(s.enc_rnn):
-                D = s.enc_embed if l == 0 else 2 * s.enc_rnn[l - 1]
-                wx, wh = [], []
-                for d in ('fw', 'bw'):
-                    K = P['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, d)]
-                    b = P['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, d)]
-                    wx.append(np.concatenate([_tf2int(K[:D], Hh), _tf2int(b[None], Hh)], 0))
-                    wh.append(_tf2int(K[D:], Hh))
-                put('enc%d.Wx' % l, np.concatenate(wx, 1))
-                put('enc%d.Wh' % l, np.stack(wh, 0))
-            self._ff_io(P, 'aux', 'encoder_%s_projection' % s.aux_layer,
-                        None if s.aux_layer is None else [2 * s.enc_rnn[s.aux_layer]] + list(s.aux_hidden) + [s.aux_dim], put)
-            for j, hx in enumerate(s.aux_extra):
-                self._ff_io(P, 'auxx%d_' % j, 'encoder_%s_projection' % hx['layer'],
-                            [2 * s.enc_rnn[hx['layer']]] + list(hx.get('hidden', [])) + [hx['dim']], put)
-            put('dec.emb', P['seq2seq/decoder_embedding_%d_%d_0/weights' % (s.vocab, s.dec_embed)])
-            K = P['seq2seq/decoder_rnn/cell_0/kernel']
-            b = P['seq2seq/decoder_rnn/cell_0/bias']
-            put('dec.Wx', np.concatenate([_tf2int(K[:s.dec_embed], s.dec_rnn), _tf2int(b[None], s.dec_rnn)], 0))
-            put('dec.Wh', _tf2int(K[s.dec_embed:], s.dec_rnn)[None])
-            self._ff_io(P, 'proj', 'decoder_projection', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab], put)
-
-    def _ff_io(self, P, prefix, tfprefix, sizes, put):
-        if sizes is None:
-            return
-        for i in range(len(sizes) - 1):
-            nm = 'seq2seq/%s_%d_%d_%d' % (tfprefix, sizes[i], sizes[i + 1], i)
-            if i == len(sizes) - 2:
-                put('%s%d.WT' % (prefix, i), P[nm + '/weights'])
-                put('%s%d.b' % (prefix, i), P[nm + '/biases'])
-            else:
-                put('%s%d.W' % (prefix, i), np.concatenate([P[nm + '/weights'], P[nm + '/biases'][None]], 0))
-
-    def export_tf(self, which='p'):
-        """Inverse of import_tf: dict of TF-layout float64 numpy arrays."""
-        s = self.spec
-        N = s.decimation
-        buf = getattr(self, which)
-        host = buf.detach().cpu().numpy().astype(np.float64)
-
-        def get(name):
-            off, shape = self.segs[name]
-            return host[off:off + int(np.prod(shape))].reshape(shape)
-        out = {}
-        for sid, Cc in s.channels.items():
-            for j, (ci, co, n) in enumerate(conv_stack(s, Cc)):
-                nm = conv_tf_name(sid, j, ci, co)
-                w = get(conv_seg(sid, j))
-                out[nm + '/weights'] = w[:-1].reshape(1, n, ci, co).copy()
-                out[nm + '/biases'] = w[-1].copy()
-        for l, Hh in enumerate(s.enc_rnn):
-            D = s.enc_embed if l == 0 else 2 * s.enc_rnn[l - 1]
-            wx, wh = get('enc%d.Wx' % l), get('enc%d.Wh' % l)
-            for d, dn in enumerate(('fw', 'bw')):
-                blk = wx[:, d * 4 * Hh:(d + 1) * 4 * Hh]
-                out['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, dn)] = np.concatenate(
-                    [_int2tf(blk[:D], Hh), _int2tf(wh[d], Hh)], 0)
-                out['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, dn)] = _int2tf(blk[D:D + 1], Hh)[0]
-        if s.aux_layer is not None:
-            self._ff_out(out, get, 'aux', 'encoder_%s_projection' % s.aux_layer,
-                         [2 * s.enc_rnn[s.aux_layer]] + list(s.aux_hidden) + [s.aux_dim])
-        for j, hx in enumerate(s.aux_extra):
-            self._ff_out(out, get, 'auxx%d_' % j, 'encoder_%s_projection' % hx['layer'],
-                         [2 * s.enc_rnn[hx['layer']]] + list(hx.get('hidden', [])) + [hx['dim']])
-        out['seq2seq/decoder_embedding_%d_%d_0/weights' % (s.vocab, s.dec_embed)] = get('dec.emb').copy()
-        wx, wh = get('dec.Wx'), get('dec.Wh')
-        out['seq2seq/decoder_rnn/cell_0/kernel'] = np.concatenate(
-            [_int2tf(wx[:s.dec_embed], s.dec_rnn), _int2tf(wh[0], s.dec_rnn)], 0)
-        out['seq2seq/decoder_rnn/cell_0/bias'] = _int2tf(wx[s.dec_embed:], s.dec_rnn)[0]
-        self._ff_out(out, get, 'proj', 'decoder_projection', [s.dec_rnn] + list(s.dec_proj_hidden) + [s.vocab])
-        return out
-
-    def _ff_out(self, out, get, prefix, tfprefix, sizes):
-        for i in range(len(sizes) - 1):
-            nm = 'seq2seq/%s_%d_%d_%d' % (tfprefix, sizes[i], sizes[i + 1], i)
-            if i == len(sizes) - 2:
-                out[nm + '/weights'] = get('%s%d.WT' % (prefix, i)).copy()
-                out[nm + '/biases'] = get('%s%d.b' % (prefix, i)).copy()
-            else:
-                w = get('%s%d.W' % (prefix, i))
-                out[nm + '/weights'] = w[:-1].copy()
-                out[nm + '/biases'] = w[-1].copy()
-
-
-def _bf(*shape, device):
-    return torch.zeros(*shape, dtype=torch.bfloat16, device=device)
-
-
-def _f32(*shape, device):
-    return torch.zeros(*shape, dtype=torch.float32, device=device)
-
-
-def _i32(*shape, device):
-    return torch.zeros(*shape, dtype=torch.int32, device=device)
-
-
-class _FFStack:
-    """hidden ReLU(+FF dropout) layers then a linear layer stored transposed."""
-
-    def __init__(self, eng, prefix, sizes, in_blocks, in_ld, stream0):
-        # in_blocks: [(src_row0, n, dst_k0)] maps dense input features onto the padded K layout
-        self.eng, self.prefix, self.sizes, self.in_blocks, self.in_ld, self.stream0 = eng, prefix, sizes, in_blocks, in_ld, stream0
-        dev = eng.device
-        self.nl = len(sizes) - 1
-        self.WT, self.WB = [], []
-        for i in range(self.nl):
-            kin = in_ld if i == 0 else rk(sizes[i])
-            self.WT.append(_bf(sizes[i + 1], kin, device=dev))          # B operand of the forward GEMM
-            self.WB.append(_bf(kin, rk(sizes[i + 1]), device=dev))      # B operand of the input-gradient GEMM
-
-    def pack_ops(self, ops, src):
-        st = self.eng.store
-        for i in range(self.nl):
-            last = i == self.nl - 1
-            fin, fout = self.sizes[i], self.sizes[i + 1]
-            blocks = self.in_blocks if i == 0 else [(0, fin, 0)]
-            name = '%s%d.%s' % (self.prefix, i, 'WT' if last else 'W')
-            for (r0, n, k0) in blocks:
-                if last:      # master [out][in]
-                    ops.append(('cast', st.ptr(name, src, r0), fin, 1, fout, n, self.WT[i], k0, 0))
-                    ops.append(('cast', st.ptr(name, src, r0), 1, fin, n, fout, self.WB[i], 0, k0))
-                else:         # master [in+1][out]
-                    ops.append(('cast', st.ptr(name, src, r0 * fout), 1, fout, fout, n, self.WT[i], k0, 0))
-                    ops.append(('cast', st.ptr(name, src, r0 * fout), fout, 1, n, fout, self.WB[i], 0, k0))
-
-    def bias_ptr(self, i, src):
-        st = self.eng.store
-        if i == self.nl - 1:
-            return st.ptr('%s%d.b' % (self.prefix, i), src)
-        return st.ptr('%s%d.W' % (self.prefix, i), src, self.sizes[i] * self.sizes[i + 1])
-
-    def alloc(self, M):
-        dev = self.eng.device
-        Mk = rk(M)
-        ws = dict(M=M, Mk=Mk, act=[], actT=[], dT=[], dpre=[])
-        for i in range(self.nl):
-            fin = self.sizes[i]
-            if i > 0:
-                ws['act'].append(_bf(M, rk(fin), device=dev))            # hidden activation i-1
-                if rk(fin) > fin:
-                    ws['act'][-1][:, fin] = 1.0                          # ones column for the TN weight gradient (no kernel writes it)
-                ws['dpre'].append(_bf(M, rk(fin), device=dev))
-            t = _bf(fin + 1, Mk, device=dev)
-            t[fin, :M] = 1.0                                             # ones row => bias gradient for free
-            ws['actT'].append(t)
-            ws['dT'].append(_bf(self.sizes[i + 1], Mk, device=dev))
-        ws['out'] = _f32(M, self.sizes[-1], device=dev)
-        return ws
-
-    def fwd(self, ws, x_ptr, src, train):
-        e = self.eng
-        M = ws['M']
-        cur, ld = x_ptr, self.in_ld
-        for i in range(self.nl):
-            last = i == self.nl - 1
-            fout = self.sizes[i + 1]
-            kin = self.in_ld if i == 0 else rk(self.sizes[i])
-            if last:
-                e.gemm(cur, ld, self.WT[i].data_ptr(), kin, ws['out'].data_ptr(), fout, M, fout, kin,
-                       bias=self.bias_ptr(i, src))
-            else:
-                o = ws['act'][i]
-                e.gemm(cur, ld, self.WT[i].data_ptr(), kin, o.data_ptr(), rk(fout), M, fout, kin,
-                       bias=self.bias_ptr(i, src), relu=True, out_bf16=True,
-                       drop=(e.spec.ff_dropout if train else 0.0, self.stream0 + i, fout))
-                cur, ld = o.data_ptr(), rk(fout)
-        return ws['out']
-
-    def bwd_dx(self, ws, d_out, d_in_ptr, d_in_ld, accumulate, train, d_in_drop=None):
-        """Input-gradient chain (the critical path): d_out bf16 [M][rk(out)] -> hidden pre-activation gradients
-        (ws['dpre'], masked by ReLU/dropout in the GEMM epilogue) -> fp32 gradient of the stack's input."""
-        e = self.eng
-        M = ws['M']
-        d, ldd = d_out.data_ptr(), rk(self.sizes[-1])
-        keep = 1.0 / (1.0 - e.spec.ff_dropout) if (train and e.spec.ff_dropout > 0) else 1.0
-        for i in range(self.nl - 1, -1, -1):
-            fin, fout = self.sizes[i], self.sizes[i + 1]
-            kin = self.in_ld if i == 0 else rk(fin)
-            if i > 0:
-                dp = ws['dpre'][i - 1]
-                e.gemm(d, ldd, self.WB[i].data_ptr(), rk(fout), dp.data_ptr(), rk(fin), M, fin, rk(fout),
-                       out_bf16=True, alpha=keep, mask_src=(ws['act'][i - 1].data_ptr(), rk(fin)))
-                d, ldd = dp.data_ptr(), rk(fin)
-            else:
-                e.gemm(d, ldd, self.WB[0].data_ptr(), rk(fout), d_in_ptr, d_in_ld, M, kin, rk(fout),
-                       accumulate=accumulate, drop=d_in_drop)
-
-    def bwd_dw(self, ws, x_ptr, d_out):
-        """Weight (+ bias) gradients from the layer inputs and the gradients bwd_dx left in ws['dpre']: K = M rows of
-        K-major operands -> TN GEMM where the input carries its ones column (x[:, fin] == 1), else operand transposes
-        + NT GEMM.  Nothing downstream depends on it: the engine queues it on the side stream."""
-        e = self.eng
-        st = e.store
-        M, Mk = ws['M'], ws['Mk']
-        for i in range(self.nl - 1, -1, -1):
-            last = i == self.nl - 1
-            fin, fout = self.sizes[i], self.sizes[i + 1]
-            d, ldd = (d_out.data_ptr(), rk(fout)) if last else (ws['dpre'][i].data_ptr(), rk(fout))
-            xp, xld = (x_ptr, self.in_ld) if i == 0 else (ws['act'][i - 1].data_ptr(), rk(fin))
-            blocks = self.in_blocks if i == 0 else [(0, fin, 0)]
-            dense = all(k0 == r0 for (r0, n, k0) in blocks) and xld > fin
-            if e.tn and dense and (self.ones_col_set if i == 0 else True):
-                if last:      # dW^T = d^T . [x | 1]  [out][in + 1]; the last column is the bias gradient
-                    e.gemm(d, ldd, xp, xld, st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin + 1, M, splitk=True,
-                           last_col_out=st.ptr('%s%d.b' % (self.prefix, i), st.g), tn=True)
-                else:         # [dW; db] = [x | 1]^T . d  [in + 1][out]
-                    e.gemm(xp, xld, d, ldd, st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, M, splitk=True, tn=True)
-                continue
-            # transposes (K-contiguous operands for the NT weight-gradient GEMM)
-            lib.e2t_transpose_bf16(d, ldd, M, fout, ws['dT'][i].data_ptr(), Mk, e.stream)
-            for (r0, n, k0) in blocks:
-                lib.e2t_transpose_bf16(xp + 2 * k0, xld, M, n, ws['actT'][i].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
-            if last:
-                # dW^T = d^T . x  [out][in]; the ones row of actT makes column `in` the bias gradient
-                e.gemm(ws['dT'][i].data_ptr(), Mk, ws['actT'][i].data_ptr(), Mk,
-                       st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin + 1, Mk, splitk=True,
-                       last_col_out=st.ptr('%s%d.b' % (self.prefix, i), st.g))
-            else:
-                e.gemm(ws['actT'][i].data_ptr(), Mk, ws['dT'][i].data_ptr(), Mk,
-                       st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, Mk, splitk=True)
-
-    def bwd(self, ws, x_ptr, d_out, d_in_ptr, d_in_ld, accumulate, train, d_in_drop=None):
-        """d_out: bf16 [M][rk(out)] gradient of the final linear output.  Writes weight grads
-        into the store and the input gradient (fp32) into d_in_ptr (d_in_drop: dropout mask of the input, applied in
-        the GEMM epilogue)."""
-        self.bwd_dx(ws, d_out, d_in_ptr, d_in_ld, accumulate, train, d_in_drop)
-        self.bwd_dw(ws, x_ptr, d_out)
-
-
-class _Lstm:
-    """One (bi)directional LSTM layer: operand images + launch helpers."""
-
-    def __init__(self, eng, name, ndir, D, in_blocks, in_ld, Hh, stream):
-        self.eng, self.name, self.ndir, self.D, self.in_blocks, self.in_ld, self.H, self.stream = \
-            eng, name, ndir, D, in_blocks, in_ld, Hh, stream
-        dev = eng.device
-        self.H8 = r8(Hh)
-        self.ldy = rk(ndir * self.H8 + 1)      # (+1: always room for the ones column of the consumers' TN weight-gradient GEMMs)
-        self.N4 = ndir * 4 * Hh
-        self.UT, self.KB, self.KB4 = ceil_div(Hh, 16), ceil_div(self.H8, 32), ceil_div(4 * Hh, 32)
-        self.WxT = _bf(self.N4, in_ld, device=dev)
-        self.WxB = _bf(in_ld, rk(self.N4), device=dev)
-        self.WhF = _bf(ndir, 4, self.UT, self.KB, 64, 8, device=dev)
-        self.WhB = _bf(ndir, self.UT, self.KB4, 64, 8, device=dev)
-        # large hidden sizes (cfg4: H = 1024): the waves of a workgroup hold different weights and share the state through
-        # LDS (csrc/lstm_big.hip); operand = fragment image over ALL gate columns of the gate-interleaved master
-        self.big = bool(H.load().e2t_lstm_big_ok(Hh)) and self.KB > 26
-        self.WhG = _bf(ndir, 4 * Hh // 16, Hh // 32, 64, 8, device=dev) if self.big else None
-
-    def pack_ops(self, ops, src):
-        st = self.eng.store
-        N4, Hh = self.N4, self.H
-        for (r0, n, k0) in self.in_blocks:
-            ops.append(('cast', st.ptr(self.name + '.Wx', src, r0 * N4), 1, N4, N4, n, self.WxT, k0, 0))
-            ops.append(('cast', st.ptr(self.name + '.Wx', src, r0 * N4), N4, 1, n, N4, self.WxB, 0, k0))
-        for d in range(self.ndir):
-            base = d * Hh * 4 * Hh
-            if (4 * Hh) % 4 == 0 and self.WhF[d].is_contiguous():
-                ops.append(('frag4', st.ptr(self.name + '.Wh', src, base), 4, 4 * Hh, Hh, Hh, self.WhF[d, 0]))
-            else:
-                for g in range(4):
-                    ops.append(('frag', st.ptr(self.name + '.Wh', src, base + g), 4, 4 * Hh, Hh, Hh, self.WhF[d, g]))
-            ops.append(('frag', st.ptr(self.name + '.Wh', src, base), 4 * Hh, 1, Hh, 4 * Hh, self.WhB[d]))
-            if self.big:
-                ops.append(('frag', st.ptr(self.name + '.Wh', src, base), 1, 4 * Hh, 4 * Hh, Hh, self.WhG[d]))
-
-    def bias_ptr(self, src):
-        return self.eng.store.ptr(self.name + '.Wx', src, self.D * self.N4)
-
-    def persistent_ok(self, B, num_cus):
-        """One workgroup per CU for the whole layer and the W_h fragments fit the waves' registers (mirrors the checks
-        in e2t_lstm_seq_fwd_persistent): 64-utterance x 16-unit workgroups up to H = 416, 32 x 32 up to H = 832."""
-        if self.H % 8 != 0:
-            return False
-        if self.big:
-            return ceil_div(B, 64) * self.ndir * (self.H // 32) <= num_cus
-        if self.KB <= 13:        # 16 x 64 tiling with the state shared through LDS, or 64 x 16 (csrc/lstm.hip picks)
-            return (ceil_div(B, 16) * self.ndir * ceil_div(self.UT, 4) <= num_cus
-                    or ceil_div(B, 64) * self.ndir * self.UT <= num_cus)
-        return self.KB <= 26 and ceil_div(B, 32) * self.ndir * ceil_div(self.UT, 2) <= num_cus
-
-    def persistent_bwd_ok(self, B, num_cus):
-        """Mirrors the checks in e2t_lstm_seq_bwd_persistent: 16-utterance x 64-unit workgroups up to H = 416,
-        32 x 32 up to H = 800, one per CU."""
-        if self.big:
-            return self.H % 128 == 0 and ceil_div(B, 64) * self.ndir * (self.H // 32) <= num_cus
-        kq = H.load().e2t_bwd_persist_kq(self.H)
-        if kq == 0 or self.H % 8 != 0:
-            return False
-        RT = ceil_div(B, 16)
-        nwg = RT * self.ndir * ceil_div(self.UT, 4) if kq <= 13 else ceil_div(RT, 2) * self.ndir * ceil_div(self.UT, 2)
-        return nwg <= num_cus
-
-    def alloc(self, S, B):
-        dev = self.eng.device
-        M, Mk = S * B, rk(S * B)
-        nd, Hh = self.ndir, self.H
-        ws = dict(S=S, B=B, M=M, Mk=Mk)
-        ws['Gx'] = _f32(M, self.N4, device=dev)
-        ws['Yext'] = _bf((S + 3) * B, self.ldy, device=dev)       # block 0 = initial state, S+1.. = zero slack
-        ws['Ydrop'] = _bf(M, self.ldy, device=dev)
-        if self.ldy > nd * self.H8:
-            ws['Ydrop'][:, nd * self.H8] = 1.0        # ones column for the dW_x of the layer above (no kernel writes it)
-        RT, UT = ceil_div(B, 16), ceil_div(Hh, 16)
-        ws['Cs'] = _f32(S, nd, RT, UT, 2, 64, 2, device=dev)       # lane-native per-step saves (lstm.hip)
-        ws['Gs'] = _f32(S, nd, RT, UT, 4, 64, 4, device=dev)
-        ws['dG'] = _bf(M + B, rk(self.N4), device=dev)              # block S = zero slack (rows without successor)
-        ws['dGT'] = _bf(self.N4, Mk, device=dev)
-        ws['YT'] = _bf(nd, Hh, Mk, device=dev)
-        ws['xT'] = _bf(self.D + 1, Mk, device=dev)
-        ws['xT'][self.D, :M] = 1.0
-        ws['dc_carry'] = _f32(B, nd * Hh, device=dev)
-        kq = H.load().e2t_bwd_persist_kq(Hh)
-        if kq:      # persistent BPTT: per-cluster stamp state and the in-launch dG exchange (include/ecog2txt_hip.h)
-            RT = ceil_div(B, 16)
-            nflag = RT * nd * 32 if kq <= 13 else ceil_div(RT, 2) * nd * 128
-            ws['counters'] = torch.zeros(nflag + 1, dtype=torch.int32, device=dev)
-            ws['dgx'] = _bf(2, nd, RT if kq <= 13 else 2 * ceil_div(RT, 2), 4 * kq, 64, 8, device=dev)
-        ws['hx'] = _bf(2 * nd * 4 * ceil_div(B, 64) * self.KB * 64 * 8 + 512, device=dev)     # in-launch h exchange (persistent recurrence)
-        if self.big:
-            ws['flagsb'] = torch.zeros(ceil_div(B, 64) * nd * 128, dtype=torch.int32, device=dev)
-            ws['flagsbb'] = torch.zeros(ceil_div(B, 64) * nd * 128, dtype=torch.int32, device=dev)
-            ws['dgxb'] = _bf(2 * nd * 4 * ceil_div(B, 64) * (Hh // 8) * 512, device=dev)       # in-launch dG exchange (big BPTT)
-        return ws
-
-    def desc(self, ws, train):
-        e = self.eng
-        d = H.LstmDesc()
-        d.S, d.B, d.H, d.ndir, d.ldy = ws['S'], ws['B'], self.H, self.ndir, self.ldy
-        d.forget_bias = e.spec.forget_bias
-        d.drop_rate = e.spec.rnn_dropout if train else 0.0
-        d.drop_seed, d.drop_step, d.drop_stream = e.seed, e.step_t.data_ptr(), self.stream
-        return d
-
-    def out_drop(self, train):
-        """(rate, stream, logical ld) of the dropout on this layer's output sequence, for a GEMM epilogue that produces a
-        gradient with respect to it: every producer of dY masks its own contribution (the mask is linear), so BPTT does
-        not spend a Philox evaluation per step and cell on the critical loop.  None: BPTT masks dY itself (no dropout, or
-        the padded column layout differs from the logical one)."""
-        rate = self.eng.spec.rnn_dropout if train else 0.0
-        if rate > 0 and self.H8 == self.H:
-            return (rate, self.stream, self.ndir * self.H)
-        return None
-
-    def fwd_gx(self, ws, x_ptr, src):
-        """Input projection of all time steps (no recurrence in it: may run ahead on another stream)."""
-        self.eng.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, ws['M'], self.N4,
-                      self.in_ld, bias=self.bias_ptr(src), alg=(ws['M'], self.N4, self.D))
-
-    def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None, gx_done=False, after_gx=None):
-        e = self.eng
-        M = ws['M']
-        if steps is None:
-            if not gx_done:
-                self.fwd_gx(ws, x_ptr, src)
-            if after_gx is not None:
-                after_gx()
-            steps = (0, ws['S'])
-        if e.persistent_fwd and steps == (0, ws['S']) and self.persistent_ok(ws['B'], e.num_cus):
-            # whole sequence in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_fwd_persist)
-            d = self.desc(ws, train)
-            if self.big:        # csrc/lstm_big.hip: k_lstm_seq_fwd_big
-                lib.e2t_lstm_seq_fwd_big(C.byref(d), ws['Gx'].data_ptr(), self.WhG.data_ptr(), ws['Yext'].data_ptr(),
-                                         ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
-                                         c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(),
-                                         ws['flagsb'].data_ptr(), e.sync_err.data_ptr(), e.num_cus, e.stream)
-                return
-            lib.e2t_lstm_seq_fwd_persistent(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
-                                            ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
-                                            c0.data_ptr() if c0 is not None else None, ws['hx'].data_ptr(),
-                                            e.sync_err.data_ptr(), e.num_cus, e.stream)
-            return
-
-        def launch(rb0, nrb, stream):
-            d = self.desc(ws, train)
-            d.rb_begin, d.rb_count = rb0, nrb
-            lib.e2t_lstm_seq_fwd(C.byref(d), ws['Gx'].data_ptr(), self.WhF.data_ptr(), ws['Yext'].data_ptr(),
-                                 ws['Ydrop'].data_ptr(), ws['Cs'].data_ptr(), ws['Gs'].data_ptr(), lens.data_ptr(),
-                                 c0.data_ptr() if c0 is not None else None, steps[0], steps[1], stream)
-        if steps[1] - steps[0] > 1:
-            e.run_chains(ws['B'], launch)
-        else:
-            launch(0, 0, e.stream)
-
-    def bwd_rec(self, ws, x_ptr, lens, dY_ptr, lddy, train, d_in_ptr, d_in_ld, c0=None, dh_final=None, dc_final=None,
-                dh0=None, dc0=None, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False, before_d_in=None,
-                dy_masked=False, d_in_drop=None):
-        """BPTT + input gradient (the critical path of the backward pass).  d_in_bf16_mask=(src_ptr, ld): emit the input
-        gradient as bf16 masked by src != 0 (conv ReLU/dropout backward fused into the epilogue).  d_in_ptr=None: BPTT
-        only (bwd_d_in() later, e.g. on another stream); before_d_in() runs between the two (a stream join)."""
-        e = self.eng
-        st = e.store
-        M, Mk, S, B = ws['M'], ws['Mk'], ws['S'], ws['B']
-        nd, Hh = self.ndir, self.H
-        p = lambda t: t.data_ptr() if t is not None else None
-
-        def launch(rb0, nrb, stream):
-            d = self.desc(ws, train)
-            if dy_masked:
-                d.drop_rate = 0.0                 # the producers of dY applied the output dropout mask (out_drop)
-            d.rb_begin, d.rb_count = rb0, nrb
-            lib.e2t_lstm_seq_bwd(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
-                                 ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
-                                 ws['dc_carry'].data_ptr(), p(dh0), p(dc0), stream)
-        if e.persistent_bwd and self.big and dh0 is None and self.persistent_bwd_ok(B, e.num_cus):
-            d = self.desc(ws, train)            # csrc/lstm_big.hip: k_lstm_seq_bwd_big
-            if dy_masked:
-                d.drop_rate = 0.0
-            lib.e2t_lstm_seq_bwd_big(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
-                                     ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final), p(dc_final),
-                                     ws['dgxb'].data_ptr(), ws['flagsbb'].data_ptr(), e.sync_err.data_ptr(), e.num_cus, e.stream)
-        elif e.persistent_bwd and not self.big and self.persistent_bwd_ok(B, e.num_cus):
-            # whole BPTT sweep in one weight-stationary launch (csrc/lstm.hip: k_lstm_seq_bwd_persist)
-            d = self.desc(ws, train)
-            if dy_masked:
-                d.drop_rate = 0.0
-            lib.e2t_lstm_seq_bwd_persistent(C.byref(d), self.WhB.data_ptr(), ws['dG'].data_ptr(), rk(self.N4), dY_ptr, lddy,
-                                            ws['Gs'].data_ptr(), ws['Cs'].data_ptr(), lens.data_ptr(), p(c0), p(dh_final),
-                                            p(dc_final), p(dh0), p(dc0), ws['dgx'].data_ptr(), ws['counters'].data_ptr(),
-                                            e.sync_err.data_ptr(), e.num_cus, e.stream)
-        else:
-            e.run_chains(B, launch)
-        if before_d_in is not None:
-            before_d_in()
-        if d_in_ptr is not None:
-            self.bwd_d_in(ws, d_in_ptr, d_in_ld, d_in_bf16_mask, d_in_alpha, d_in_accumulate, d_in_drop)
-
-    def bwd_d_in(self, ws, d_in_ptr, d_in_ld, d_in_bf16_mask=None, d_in_alpha=1.0, d_in_accumulate=False, d_in_drop=None):
-        """Input gradient dG . W_x of the dG that bwd_rec left in ws."""
-        e = self.eng
-        M = ws['M']
-        if d_in_bf16_mask is not None:
-            e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
-                   rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask, alg=(M, self.D, self.N4))
-        else:
-            e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                   rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop, alg=(M, self.D, self.N4))
-
-    def bwd_weights(self, ws, x_ptr, part=None):
-        """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the
-        engine runs it on a side stream under the next layer's BPTT.  Both products have K = S*B rows of activations
-        (x, h_{t-1}) and of their gradients (dG) exactly as the layers wrote them -- K-major -- so they go to the TN
-        GEMM directly; the bias gradient comes from a ones column kept at x[:, D] (the forward GEMM's weight image is
-        zero there).  Layouts the TN form cannot take (input features not dense, no room for the ones column) fall
-        back to operand transposes + NT GEMM."""
-        e = self.eng
-        st = e.store
-        M, Mk, B = ws['M'], ws['Mk'], ws['B']
-        nd, Hh = self.ndir, self.H
-        dense = all(k0 == r0 for (r0, n, k0) in self.in_blocks) and self.in_ld > self.D
-        if e.tn and dense and self.ones_col_set:
-            # (inside Seq2SeqEngine.gemm_group() both products -- and the caller's other K-major products of the stage --
-            #  leave in one grouped launch)
-            if part in (None, 0):
-                e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
-                       self.D + 1, self.N4, M, splitk=True, tn=True)
-            # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction).  Both directions in ONE
-            # batched launch: twice the tiles, so half the K splits (slabs, workgroup start-ups) for the same fill
-            if part in (None, 1):
-                e.gemm(ws['Yext'].data_ptr(), self.ldy, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wh', st.g), 4 * Hh,
-                       Hh, 4 * Hh, M, splitk=True, tn=True,
-                       batch=(nd, 2 * B * self.ldy + self.H8, 4 * Hh, Hh * 4 * Hh) if nd > 1 else None)
-            return
-        if part == 1:
-            return              # (the transposing fallback shares buffers between its products: everything runs as part 0)
-        lib.e2t_transpose_bf16(ws['dG'].data_ptr(), rk(self.N4), M, self.N4, ws['dGT'].data_ptr(), Mk, e.stream)
-        for (r0, n, k0) in self.in_blocks:
-            lib.e2t_transpose_bf16(x_ptr + 2 * k0, self.in_ld, M, n, ws['xT'].data_ptr() + 2 * r0 * Mk, Mk, e.stream)
-        e.gemm(ws['xT'].data_ptr(), Mk, ws['dGT'].data_ptr(), Mk, st.ptr(self.name + '.Wx', st.g), self.N4,
-               self.D + 1, self.N4, Mk, splitk=True)
-        for dd in range(nd):
-            # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction)
-            row_off = (2 * B if dd == 1 else 0) * self.ldy
-            lib.e2t_transpose_bf16(ws['Yext'].data_ptr() + 2 * (row_off + dd * self.H8), self.ldy, M, Hh,
-                                   ws['YT'][dd].data_ptr(), Mk, e.stream)
-            e.gemm(ws['YT'][dd].data_ptr(), Mk, ws['dGT'].data_ptr() + 2 * dd * 4 * Hh * Mk, Mk,
-                   st.ptr(self.name + '.Wh', st.g, dd * Hh * 4 * Hh), 4 * Hh, Hh, 4 * Hh, Mk, splitk=True)
-
-    def bwd(self, ws, x_ptr, *args, **kw):
-        self.bwd_rec(ws, x_ptr, *args, **kw)
-        self.bwd_weights(ws, x_ptr)
+from .params import *       # noqa: F401,F403  (NetSpec, ParamStore, layout helpers, stream ids: re-exported)
+from .params import _tf2int, _int2tf   # noqa: F401
+from .layers import _FFStack, _Lstm, _bf, _f32, _i32   # noqa: F401
 
 
 class Seq2SeqEngine:
@@ -795,12 +119,10 @@ class Seq2SeqEngine:
         self.splitk_ws = _f32(16 * 1024 * 1024, device=dev)          # 64 MiB of split-K partial slabs
         self.splitk_ws_side = _f32(16 * 1024 * 1024, device=dev)     # ... of the side stream (weight-gradient branch)
         self._on_side = False
-        self._ws_override = None      # split-K workspace of the second side lane while it is being enqueued
-        self._wstream2, self.splitk_ws_side2 = None, None
-        self.par_gemms = os.environ.get('E2T_PAR_GEMMS', '0') != '0'     # weight gradients on TWO side streams (dW_x | dW_h): measured slower (2.02 vs 1.87 ms), off
         self._wstream = None
+        # E2T_OVERLAP=0: everything on one stream (diagnostics).  (Measured and dropped in rounds 1-2, DESIGN.md: weight gradients
+        # on TWO side streams, the BPTT chain alone on the chip with all weight gradients behind it, per-stage joins.)
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
-        self._ovl = os.environ.get('E2T_OVERLAP', '1')          # diagnostics: 'auxf' / 'stage' / 'defer' subsets
         # front-end in ONE pass over x (e2t_conv_fwd_fused: reversal + im2row + bf16 rounding in the DMA path of the product, the
         # packed copy for the backward pass emitted on the way): 'auto' = when the input batch is HBM-sized (>= 256 MiB: cfg5
         # 894 -> 483 us inference / 729 us training; at cfg2's 105 MB the two-kernel path is as fast), '1' / '0' force it
@@ -853,7 +175,7 @@ class Seq2SeqEngine:
         if splitk:
             flags |= H.GEMM_SPLITK
         # the workspace is always offered: the library also splits K on its own when a product has too few tiles
-        wsb = self._ws_override if self._ws_override is not None else (self.splitk_ws_side if self._on_side else self.splitk_ws)
+        wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
         ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
@@ -1032,14 +354,6 @@ class Seq2SeqEngine:
             ops.append(('cast', st.ptr('dec.emb', base), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
             self.dec.pack_ops(ops, base)
             self.proj.pack_ops(ops, base)
-            if os.environ.get('E2T_PACK_ONLY'):          # diagnostics (scripts/bench_pack.py): a subset of the images
-                want = os.environ['E2T_PACK_ONLY']
-                def kind_of(op):
-                    if op[0] != 'cast':
-                        return 'frag4' if op[0] == 'frag4' else 'fragK'
-                    return 'tr' if (op[2] == 1 and op[3] != 1) else 'cast'
-                ops = [op for op in ops if kind_of(op) == want]
-                head = [op for op in head if kind_of(op) == want]
             self._pack_ops = (head, ops)
             self._pack_table = [self._pack_descs(t, base) for t in (head, ops) if t]
         for i, (dev, n, nblk) in enumerate(self._pack_table):
@@ -1387,7 +701,7 @@ class Seq2SeqEngine:
             self.dec.fwd_gx(ws['dec'], ws['e'].data_ptr(), src)
             if ws['use_aux']:
                 aux_targets()
-        ahead = self.overlap and self._ovl in ('1', 'auxf', 'tail')
+        ahead = self.overlap
         joins = []
         pend = {}
         ev0 = self.fork_point() if ahead else None
@@ -1504,18 +818,12 @@ class Seq2SeqEngine:
         for l in range(nl - 1, -1, -1):
             if l < nl - 1:
                 names = enc_names(l + 1)
-                side = (lambda train, l=l, part=None: self._bwd_enc_weights(ws, l + 1, part))
+                side = (lambda train, l=l: self._bwd_enc_weights(ws, l + 1))
             else:       # the head's own weight gradients queue up first, under the top layer's BPTT
                 names = head
-                side = (lambda train, part=None: self._bwd_head_weights(ws, train, part))
+                side = (lambda train: self._bwd_head_weights(ws, train))
             stages.append((lambda train, l=l: self._bwd_enc_rec(ws, l, train), side, rng_of(names)))
-        if self.par_gemms:
-            # the bottom layer's dW_h runs next to its dW_x + conv gradient instead of behind them
-            stages.append((lambda train: self._bwd_enc_weights(ws, 0, 0),
-                           lambda train, part=None: (self._bwd_enc_weights(ws, 0, 1) if part in (None, 1) else None),
-                           rng_of(enc_names(0) + conv_names)))
-        else:
-            stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + conv_names)))
+        stages.append((lambda train: self._bwd_enc_weights(ws, 0), None, rng_of(enc_names(0) + conv_names)))
         return stages
 
     def fork_side(self, fn):
@@ -1546,26 +854,19 @@ class Seq2SeqEngine:
         ev.record(torch.cuda.current_stream(self.device))
         return ev
 
-    def run_side(self, ev, fn, lane=0):
+    def run_side(self, ev, fn):
         """fn() on the side stream, ordered after fork_point() event ev.  Returns the event to pass to join_side().
-        lane 1: a second side stream with its own split-K workspace -- independent weight-gradient products (dW_x | dW_h
-        of a layer) then run side by side and fill each other's ramp-up / ramp-down bubbles instead of queueing in
-        stream order.  (Both lanes fork from the MAIN branch: a fork off a forked stream crashes hipGraphInstantiate.)"""
+        (A fork off a forked stream crashes hipGraphInstantiate: side work always forks from the MAIN branch.)"""
         if self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
-        if lane == 1 and self._wstream2 is None:
-            self._wstream2 = torch.cuda.Stream(device=self.device)
-            self.splitk_ws_side2 = _f32(16 * 1024 * 1024, device=self.device)
-        stream = self._wstream2 if lane == 1 else self._wstream
+        stream = self._wstream
         stream.wait_event(ev)
         with torch.cuda.stream(stream):
             self._on_side = True
-            self._ws_override = self.splitk_ws_side2 if lane == 1 else None
             try:
                 fn()
             finally:
                 self._on_side = False
-                self._ws_override = None
             join = torch.cuda.Event()
             join.record(stream)
         return join
@@ -1575,7 +876,7 @@ class Seq2SeqEngine:
 
     def run_stage(self, main, side, train):
         """main on the current stream, side (if any) on the side stream, joined at the end."""
-        if side is None or not self.overlap or self._ovl == 'auxf':
+        if side is None or not self.overlap:
             if side is not None:
                 side(train)
             main(train)
@@ -1592,32 +893,19 @@ class Seq2SeqEngine:
         ws['_aux_join'] = None
         ws['fwd_train'] = train
         deferred = []
-        held = []
         stages = self.backward_stages(ws)
         for i, (main, side, ranges) in enumerate(stages):
-            if after_stage is None and self.overlap and self._ovl == 'tail' and i > 0:
-                # diagnostics: keep the BPTT chain alone on the chip, all weight gradients afterwards on both streams
-                if side is not None:
-                    held.append(side)
-                if i == len(stages) - 1:
-                    for sd in held:
-                        deferred.append(self.fork_side(lambda sd=sd: sd(train)))
-                main(train)
-            elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i == 0:
+            if after_stage is None and self.overlap and side is not None and i == 0:
                 # auxiliary head: joined where the main branch first touches dY[aux_layer] (_bwd_enc_rec)
                 ev = self.fork_point()
                 main(train)
                 ws['_aux_join'] = self.run_side(ev, lambda side=side: side(train))
-            elif after_stage is None and self.overlap and self._ovl in ('1', 'defer') and side is not None and i > 0:
+            elif after_stage is None and self.overlap and side is not None and i > 0:
                 # nobody needs a layer's weight gradients before the optimiser: the side stream just queues them (it is
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
                 ev = self.fork_point()
                 main(train)
-                if self.par_gemms and self._ovl == '1':
-                    deferred.append(self.run_side(ev, lambda side=side: side(train, part=0)))
-                    deferred.append(self.run_side(ev, lambda side=side: side(train, part=1), lane=1))
-                else:
-                    deferred.append(self.run_side(ev, lambda side=side: side(train)))
+                deferred.append(self.run_side(ev, lambda side=side: side(train)))
                 if early is not None and i in early:
                     deferred.append(self.run_side(ev, early[i]))
             else:
@@ -1641,25 +929,18 @@ class Seq2SeqEngine:
         self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
                          None, self.E8, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0'], dy_masked=dd is not None)
 
-    def _bwd_head_weights(self, ws, train, part=None):
-        """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them.
-        part 0 / 1: the two halves that run on the two side lanes (None: everything)."""
+    def _bwd_head_weights(self, ws, train):
+        """Weight gradients of the head (projection, decoder, embedding): nothing downstream needs them."""
         s, store = self.spec, self.store
-        if part is None:
-            # projection, decoder input kernel and decoder recurrent kernel: one grouped launch (K = L*B rows each)
-            with self.gemm_group():
-                self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
-                self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
-        if part == 0:
+        # projection, decoder input kernel and decoder recurrent kernel: one grouped launch (K = L*B rows each)
+        with self.gemm_group():
             self.proj.bwd_dw(ws['proj'], ws['dec']['Ydrop'].data_ptr(), ws['dlogits'])
-        if part in (None, 0):
-            # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
-            self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
-            dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
-            lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
-                              store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)
-        if part == 1:
             self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
+        # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
+        self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
+        dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
+        lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
+                          store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)
 
     def _bwd_enc_rec(self, ws, l, train):
         """aux head (if it taps layer l), BPTT of layer l, gradient into the layer below."""
@@ -1713,20 +994,19 @@ class Seq2SeqEngine:
                    d_in_drop=lay.out_drop(train))
             ws['have_dy'][l] = True
 
-    def _bwd_enc_weights(self, ws, l, part=None):
-        """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end).
-        part 0: dW_x (+ conv), part 1: dW_h -- the halves for the two side lanes; None: everything."""
-        if part is None and not self._in_group:
+    def _bwd_enc_weights(self, ws, l):
+        """Weight gradients of encoder layer l (and, for l == 0, of the subject's conv front-end)."""
+        if not self._in_group:
             # every K-major product of the stage (dW_x, dW_h; for the bottom layer also the conv kernels) in one grouped launch
             with self.gemm_group():
-                self._bwd_enc_weights(ws, l, None)
+                self._bwd_enc_weights(ws, l)
             return
         s, store = self.spec, self.store
         M, Mk = ws['M'], ws['Mk']
         st = self.stream
         x = ws['E'].data_ptr() if l == 0 else ws['enc'][l - 1]['Ydrop'].data_ptr()
-        self.enc[l].bwd_weights(ws['enc'][l], x, part)
-        if l > 0 or part == 1:
+        self.enc[l].bwd_weights(ws['enc'][l], x)
+        if l > 0:
             return
         # conv front-end weights: dK = A^T . dEpre  (ones row of AT yields the bias gradient)
         sid = ws['sid']
@@ -1831,7 +1111,7 @@ class Seq2SeqEngine:
         asynchronously right after the stage is enqueued, and Adam waits for all of them."""
         dp = sync is not None and sync.world > 1
         gc = bool(dp and ws.get('global_counts'))          # losses normalised by the global counts: the exchange is a plain sum
-        lazy = use_graph and self.overlap and self._ovl in ('1', 'auxf', 'tail')      # re-pack inside the (first) graph
+        lazy = use_graph and self.overlap      # re-pack inside the (first) graph
         if self._packed != 'p' and not lazy:
             self.pack('p')
         self.grad_scale = (1.0 if gc else sync.grad_scale) if dp else 1.0
@@ -1892,7 +1172,7 @@ class Seq2SeqEngine:
                 nl = len(self.enc)
                 early_end, early = 0, None
                 packed_early, early_sets = [], []
-                if nl >= 2 and self.overlap and self._ovl == '1' and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
+                if nl >= 2 and self.overlap and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
                     # stage i (2 <= i <= nl) queues the weight gradients of layer nl-i+1 on the side stream: behind them,
                     # everything in front of layer nl-i's segment is final
                     early, lo = {}, 0

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip.so')
+# E2T_DEBUG_LIB=1 (scripts/ only): the diagnostics build of the same sources (csrc/build.sh with E2T_DEBUG=1), in which the
+# kernel-variant switches and the phase-stamp buffers exist; the product library has none of them
+LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip_dbg.so' if os.environ.get('E2T_DEBUG_LIB') == '1' else 'libecog2txt_hip.so')
 
 GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK = 1, 2, 4, 8, 16
 PACK_UNITS = 4            # E2T_PACK_UNITS (include/ecog2txt_hip.h): work units of a pack descriptor per workgroup

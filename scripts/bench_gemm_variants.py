@@ -1,6 +1,8 @@
 """Sensitivity of e2t_gemm_nt_bf16 on the encoder input-projection shape: K tail, output dtype, K and N size."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'scripts')) if 'ROOT' in globals() else sys.path.insert(0, 'scripts')
+import _dbg  # noqa: F401  (debug build of the library: the E2T_* kernel switches and phase stamps live there)
 import torch
 from ecog2txt_amd import hip_lib as H
 from ecog2txt_amd.hip_lib import lib

@@ -2,6 +2,8 @@
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'scripts')) if 'ROOT' in globals() else sys.path.insert(0, 'scripts')
+import _dbg  # noqa: F401  (debug build of the library: the E2T_* kernel switches and phase stamps live there)
 import numpy as np
 import torch
 import bench

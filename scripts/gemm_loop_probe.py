@@ -3,6 +3,8 @@ usage: python scripts/gemm_loop_probe.py [wgs_per_cu=1|2] ; env E2T_GEMM_DBG / E
 import sys, ctypes as C
 import torch
 sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(ROOT, 'scripts')) if 'ROOT' in globals() else sys.path.insert(0, 'scripts')
+import _dbg  # noqa: F401  (debug build of the library: the E2T_* kernel switches and phase stamps live there)
 from ecog2txt_amd.hip_lib import lib, GemmEpilogue
 
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 1

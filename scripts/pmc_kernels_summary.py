@@ -10,7 +10,7 @@ def short(name):
     if 'k_gemm_nt<128, 128, 2, 2, true, false' in name: return 'nt128'
     if 'k_gemm_nt<256, 256, 2, 4, false, true' in name: return 'tn256'
     if 'k_gemm_nt<256' in name: return 'nt256'
-    for k in ('k_conv_fwd_ws', 'k_conv_fwd', 'k_conv_pack', 'k_splitk_reduce', 'k_lstm_seq_fwd_persist_wide', 'k_lstm_seq_fwd_persist_shared', 'k_lstm_seq_fwd_persist', 'k_lstm_seq_bwd_persist<25', 'k_lstm_seq_bwd_persist',
+    for k in ('k_conv_fwd_ws', 'k_conv_fwd', 'k_conv_pack', 'k_splitk_reduce', 'k_lstm_seq_fwd_persist_wide', 'k_lstm_seq_fwd_persist', 'k_lstm_seq_bwd_persist<25', 'k_lstm_seq_bwd_persist',
               'k_lstm_seq_fwd_big', 'k_lstm_seq_bwd_big', 'k_lstm_step_fwd', 'k_lstm_step_bwd'):
         if k in name: return k.replace('<25', '_wide')
     return None

@@ -356,27 +356,6 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
     assert np.abs(gc - a['g']).max() <= 5e-3 * np.abs(a['g']).max()
 
 
-@pytest.mark.parametrize('name,B,T,L', [('cfg2_widths', 130, 40, 5), ('mid', 256, 100, 8), ('small_dropout', 70, 50, 6)])
-def test_shared_state_forward_variant_is_bit_identical(name, B, T, L, monkeypatch):
-    """E2T_FWD_SHARED=1: the 16-utterance x 64-unit forward tiling whose four waves share the row tile's state through LDS
-    (a quarter of the stamped loads each) must reproduce the default 64 x 16 tiling bit for bit."""
-    outs = {}
-    for flag in ('0', '1'):
-        monkeypatch.setenv('E2T_FWD_SHARED', flag)
-        import ecog2txt_amd.hip_lib as hl
-        eng, ws, *_ = build(SPECS[name], B, T, L, seed=4, ragged=True)
-        for _ in range(3):
-            eng.forward(ws, train=True)
-            eng.backward(ws, train=True)
-        torch.cuda.synchronize()
-        assert int(eng.sync_err[0].item()) == 0
-        outs[flag] = (ws['enc'][-1]['Yext'].view(torch.int16).cpu().numpy(), ws['enc'][-1]['Ydrop'].view(torch.int16).cpu().numpy(),
-                      eng.losses(ws))
-    np.testing.assert_array_equal(outs['0'][0], outs['1'][0])
-    np.testing.assert_array_equal(outs['0'][1], outs['1'][1])
-    assert outs['0'][2] == outs['1'][2]
-
-
 def test_persistent_bptt_saturates_huge_gate_gradients_without_stalling(monkeypatch):
     """The recurrent hand-off of the persistent BPTT keeps a stamp in the top exponent bit of every bf16 (free for
     |x| < 2): gate gradients beyond that saturate in the exchange copy -- they must neither corrupt the stamp (an
