@@ -96,6 +96,24 @@ __device__ __forceinline__ EpiCtx epi_ctx(const GemmArgs& p) {
     c.dkeep = c.dodrop ? 1.0f / (1.0f - p.drop.rate) : 1.0f;
     return c;
 }
+// Dropout scales of the logical elements e0 .. e0+3 (e0 % 4 != 0) of a row-major tensor whose width is not a multiple of 4 (the
+// 225-unit auxiliary layer: three rows out of four): element e takes word e & 3 of the Philox block of counter e >> 2, so the
+// four elements straddle TWO consecutive blocks -- two evaluations and a shift instead of one evaluation per element
+// (8704 x 225 x 832 with dropout: 42 -> 28 us).  NOT inlined: 16 copies of it in the store loop of a 128 x 128 instance push
+// the loop past hipcc's unrolling limit; it then stays rolled and indexes the accumulators dynamically, which puts all 64 of
+// them into scratch memory (seen: 288 B of scratch per lane).  A pure function of values.
+__device__ __attribute__((noinline)) f32x4 drop_scale4_straddle(unsigned long long e0, unsigned long long key, unsigned stream, unsigned thresh, float keep) {
+    const unsigned sh = (unsigned)(e0 & 3ull);
+    const unsigned long long c0 = e0 >> 2, c1 = c0 + 1;
+    unsigned ra[4], rb[4];
+    philox4x32_10((unsigned)c0, (unsigned)(c0 >> 32), stream, 0u, (unsigned)key, (unsigned)(key >> 32), ra);
+    philox4x32_10((unsigned)c1, (unsigned)(c1 >> 32), stream, 0u, (unsigned)key, (unsigned)(key >> 32), rb);
+    const unsigned w0 = sh == 1 ? ra[1] : (sh == 2 ? ra[2] : ra[3]);
+    const unsigned w1 = sh == 1 ? ra[2] : (sh == 2 ? ra[3] : rb[0]);
+    const unsigned w2 = sh == 1 ? ra[3] : (sh == 2 ? rb[0] : rb[1]);
+    const unsigned w3 = sh == 1 ? rb[0] : (sh == 2 ? rb[1] : rb[2]);
+    return (f32x4){((w0 >> 8) >= thresh) ? keep : 0.f, ((w1 >> 8) >= thresh) ? keep : 0.f, ((w2 >> 8) >= thresh) ? keep : 0.f, ((w3 >> 8) >= thresh) ? keep : 0.f};
+}
 // v: alpha * product (+ bias) of row gm, columns gn0..gn0+3.  RICH = false drops ReLU / mask / dropout.
 template <bool RICH>
 __device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, int gm, int gn0, float (&v)[4], bool rowvalid) {
@@ -115,7 +133,8 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, 
             philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), p.drop.stream, 0u, (unsigned)ec.dkey, (unsigned)(ec.dkey >> 32), rr);
             for (int r = 0; r < 4; ++r) v[r] *= ((rr[r] >> 8) >= ec.dthresh) ? ec.dkeep : 0.f;
         } else {
-            for (int r = 0; r < nv; ++r) v[r] *= drop_scale(p.drop, e0 + r);
+            const f32x4 sc = drop_scale4_straddle(e0, ec.dkey, p.drop.stream, ec.dthresh, ec.dkeep);
+            v[0] *= sc[0]; v[1] *= sc[1]; v[2] *= sc[2]; v[3] *= sc[3];
         }
     }
     if (!rowvalid) { for (int r = 0; r < 4; ++r) v[r] = 0.f; }
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_group(GemmGroupArgs g) {
     for (int j = 1; j < E2T_GEMM_GROUP_MAX; ++j) if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
     const int L = (int)blockIdx.x - g.first[i];
     if (L >= g.count[i]) return;
-    gemm_body<128, 128, 2, 2, true, true, 64, 2, 0>(g.p[i], L);
+    gemm_body<128, 128, 2, 2, false, true, 64, 2, 0>(g.p[i], L);
 }
 
 // C[m][n] (+)= epilogue(sum_s slab[s][m][n]) in fixed split order (deterministic); 4 consecutive columns per thread so
@@ -1045,12 +1064,17 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     GemmArgs p;
     if (int rc = gemm_make_args(tn, A, lda, B, ldb, C, ldc, M, N, K, ep, p)) return rc;
     if (M == 0 || N == 0) return E2T_OK;
+    // the K-major instances store through the lean epilogue (alpha, bias, accumulate, row mask, bf16: 139 registers, which lets
+    // a workgroup share a CU with the persistent BPTT): ReLU / dropout / the ReLU-backward mask exist on their split-K path
+    // only, where the reduction applies the full epilogue
+    const bool rich_ep = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
     const GemmPlan pl = gemm_plan(tn, M, N, K, ep);
     const bool big = pl.tile == 256;
     const int BM = pl.tile, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int batch = pl.batch;
     if (pl.splits > 1 || pl.want_split) { p.splits = pl.splits; p.slab = (float*)ep->splitk_ws; }
+    E2T_CHECK_ARG(!(tn && rich_ep && p.splits <= 1));
     const dim3 grid((unsigned)(ntm * ntn * p.splits * batch));
     const hipStream_t st = (hipStream_t)stream;
     // every instance asks for its LDS explicitly (above the 64-KiB default for most of them)
@@ -1064,13 +1088,13 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     } while (0)
     // E2T_GEMM_DBG=1|2|3 selects the timing-only forms of the 128 x 128 instances (scripts/gemm_loop_probe.py)
     static const int dbg = e2t_dbg_int("E2T_GEMM_DBG", 0);
-    if (tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 1);
-    else if (tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 2);
-    else if (tn && !big && dbg == 3) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 3);
+    if (tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 1);
+    else if (tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 2);
+    else if (tn && !big && dbg == 3) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 3);
     else if (!tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 1);
     else if (!tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 2);
     else if (big && tn) E2T_GEMM_GO(256, 256, 2, 4, false, true, 64, 2, 0);
-    else if (tn) E2T_GEMM_GO(128, 128, 2, 2, true, true, 64, 2, 0);
+    else if (tn) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 0);
     else if (big) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 0);
     else E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 0);
 #undef E2T_GEMM_GO

@@ -55,9 +55,12 @@ def test_gemm_nt_plain(hl, M, N, K):
     np.testing.assert_allclose(host(c), want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
 
 
-def test_gemm_epilogues(hl):
+@pytest.mark.parametrize('N', [52, 53, 225, 50])
+def test_gemm_epilogues(hl, N):
+    """(N % 4 != 0: a lane's four columns straddle two Philox blocks in three rows out of four -- the two-block path of the
+    dropout epilogue; N = 225 is the auxiliary head's hidden width.)"""
     rng = np.random.default_rng(3)
-    M, N, K, rowsB = 96, 52, 72, 8
+    M, K, rowsB = 96, 72, 8
     A, Bm = rng.standard_normal((M, K)), rng.standard_normal((N, K))
     bias = rng.standard_normal(N)
     lens = rng.integers(0, M // rowsB + 1, size=rowsB)
