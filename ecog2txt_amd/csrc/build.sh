@@ -26,3 +26,8 @@ objs=()
 for s in "${srcs[@]}"; do objs+=("$obj/$s.o"); done
 hipcc --offload-arch=gfx950 -fPIC -shared "${objs[@]}" -ldl -o "$out"
 echo "built $out"
+# test helper (tests/native/occupy.hip: a CU-occupying spin kernel for the RCCL-contention test) -- not part of the product library
+th="$here/../../tests/native"
+if [ -f "$th/occupy.hip" ] && { [ ! -f "$th/libe2t_test_occupy.so" ] || [ "$th/occupy.hip" -nt "$th/libe2t_test_occupy.so" ]; }; then
+    hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared "$th/occupy.hip" -o "$th/libe2t_test_occupy.so" > "$obj/occupy.log" 2>&1 || { cat "$obj/occupy.log"; exit 1; }
+fi

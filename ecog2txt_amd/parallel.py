@@ -43,9 +43,19 @@ def global_batches(n, B, world, rng=None):
     return [order[i:i + G] for i in range(0, n, G)]
 
 
-def rank_slice(idx, B, rank):
-    """Rank `rank`'s share of one global batch: utterances [rank*B, (rank+1)*B) of it (possibly fewer, possibly none)."""
-    return idx[rank * B:(rank + 1) * B]
+def rank_slice(idx, B, rank, world=None, lengths=None):
+    """Rank `rank`'s share of one global batch.  Without `lengths`: utterances [rank*B, (rank+1)*B) of it (possibly fewer,
+    possibly none).  With `lengths` (per-utterance sample counts of the WHOLE partition, indexed like `idx`) and `world`:
+    the global batch is dealt out by length -- sorted, longest first, rank r takes every world-th one -- so every rank holds
+    the same mix of long and short utterances and a short last batch is spread over all ranks instead of leaving the last
+    ones empty ("bucket utterances by length before sharding").  The captured step itself costs the same
+    whatever the lengths are (fixed shapes: T of the partition, every step of every layer runs); what the dealing balances is
+    the number of VALID samples and tokens per rank, i.e. each rank's share of the globally normalised loss."""
+    if lengths is None or world is None:
+        return idx[rank * B:(rank + 1) * B]
+    idx = np.asarray(idx)
+    order = idx[np.argsort(-np.asarray(lengths)[idx], kind='stable')]
+    return order[rank::world][:B]
 
 
 class GradSync:

@@ -183,7 +183,8 @@ class SequenceNetwork:
             tl = (A_ != 0).sum(1) if A_.ndim == 2 else (np.abs(A_).max(axis=2) > 0).sum(1)
             vals.append(-(-tl // N))
         A = As[0] if As else None
-        return dict(X=X, Y=Y, A=A, Ax=As[1:], n=n, T=T, L=L, tok=tok, val=(vals[0] if vals else np.zeros(n, np.int64)), valx=vals[1:])
+        xlen = (np.abs(X).max(axis=2) > 0).sum(1).astype(np.int64)        # valid samples per utterance (length-balanced sharding)
+        return dict(X=X, Y=Y, A=A, Ax=As[1:], n=n, T=T, L=L, tok=tok, val=(vals[0] if vals else np.zeros(n, np.int64)), valx=vals[1:], xlen=xlen)
 
     def _batches(self, data, rng=None):
         B = self.N_cases
@@ -297,7 +298,7 @@ class SequenceNetwork:
                 idx = np.full((len(gb), B), -1, np.int32)
                 cnt = np.zeros((len(gb), 2 + len(d.get('valx', []))), np.int64)
                 for k, g in enumerate(gb):
-                    mine = rank_slice(g, B, rank)
+                    mine = rank_slice(g, B, rank, world, d.get('xlen'))
                     idx[k, :len(mine)] = mine
                     cnt[k] = [d['tok'][g].sum(), d['val'][g].sum()] + [v[g].sum() for v in d.get('valx', [])]
                 plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt))
@@ -363,7 +364,7 @@ class SequenceNetwork:
         counts = np.zeros(2, np.int64)                       # correct tokens, tokens
         conf = np.zeros((V, V), np.int64) if V < 100 else None
         for g in global_batches(n, B, world):
-            idx = rank_slice(g, B, rank)
+            idx = rank_slice(g, B, rank, world, data.get('xlen'))
             if len(idx) == 0:
                 continue
             self._load_batch(eng, ws, data, idx)

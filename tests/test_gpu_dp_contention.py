@@ -1,0 +1,112 @@
+"""The data-parallel product configuration as a whole, on ONE GPU: persistent recurrences ON,
+`parallel.RcclSync` (librccl through the C ABI, one-rank communicator reported as two ranks so that the engine takes the
+data-parallel schedule: per-stage graphs, the exchange issued behind each stage, the optimiser following it range by range) --
+while CUs are taken away at exactly the points where the all-reduces run, as RCCL's channel kernels do on a multi-GPU node:
+a spin kernel (tests/native/occupy.hip, test infrastructure) occupies 32, then 64 CUs for the duration of an all-reduce, one
+workgroup per CU, with an LDS request that leaves no room for a persistent-recurrence workgroup beside it.
+
+The persistent recurrences need ALL their workgroups resident at once (cfg2: 200 forward / 224 BPTT of 256 CUs; cfg4: all 256)
+and spin on their peers.  With 32 CUs gone cfg2 still fits; with 64 gone (and at cfg4 with any) late workgroups wait for the
+occupying kernels to end -- a delay bounded by the all-reduce's duration, not a hang: no in-kernel timeout, no skipped update.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _occupy_lib():
+    path = os.path.join(HERE, 'native', 'libe2t_test_occupy.so')
+    if not os.path.exists(path):
+        pytest.skip('tests/native/libe2t_test_occupy.so is not built (ecog2txt_amd/csrc/build.sh builds it)')
+    lib = C.CDLL(path)
+    lib.e2t_test_occupy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.e2t_test_occupy.restype = C.c_int
+    return lib
+
+
+def _contended_sync(eng, n_cus, usec, occ):
+    """RcclSync on a one-rank communicator, reported as two ranks; every all-reduce is accompanied by `n_cus` occupied CUs
+    for `usec` microseconds on a stream of its own, ordered behind the stage that issued the exchange."""
+    from ecog2txt_amd.parallel import RcclSync
+    try:
+        sync = RcclSync(eng.store.g, 0, 1, RcclSync.unique_id(), 0, sum_of_global_means=True)
+    except RuntimeError as e:
+        pytest.skip('cannot create an RCCL communicator here: %r' % (e,))
+    sync.world = 2
+    sync.occ_stream = torch.cuda.Stream()
+    sync.occupied = 0
+    real = sync.allreduce_range
+
+    def allreduce_range(a, b):
+        real(a, b)
+        if n_cus and b > a:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            sync.occ_stream.wait_event(ev)
+            assert occ.e2t_test_occupy(n_cus, usec, 120 * 1024, None, sync.occ_stream.cuda_stream) == 0
+            sync.occupied += 1
+    sync.allreduce_range = allreduce_range
+    return sync
+
+
+def _steps(eng, ws, sync, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.train_step(ws, use_graph=True, sync=sync)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+@pytest.mark.parametrize('name,usec', [('cfg2', 60), ('cfg4', 150)])
+def test_dp_step_with_cus_taken_away_where_the_allreduces_run(name, usec):
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    occ = _occupy_lib()
+    kw, B, T, L = bench.CONFIGS[name]
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=3)
+    assert eng.persistent_fwd and eng.persistent_bwd
+    eng.init_params(seed=0)
+    ws = eng.workspace(401, B, T, L)
+    batch = bench.synth_batch(kw, B, T, L, seed=5)
+    eng.set_batch(ws, batch)
+    ntok, nval = eng.local_counts(batch['decoder_targets'], batch['encoder_targets'])
+    eng.set_global_counts(ws, ntok, nval)
+    times = {}
+    p_prev = None
+    for n_cus in (0, 32, 64):
+        sync = _contended_sync(eng, n_cus, usec, occ)
+        try:
+            _steps(eng, ws, sync, 3)                         # capture + warm-up (the side stream is picked by timing)
+            assert int(eng.sync_err[0].item()) == 0, eng.sync_err.cpu().numpy().tolist()
+            step0 = int(eng.step_t.item())
+            p_prev = eng.store.p.clone()
+            times[n_cus] = _steps(eng, ws, sync, 10)
+            # no in-kernel timeout, every update applied
+            assert int(eng.sync_err[0].item()) == 0, (n_cus, eng.sync_err.cpu().numpy().tolist())
+            assert int(eng.step_t.item()) == step0 + 10
+            assert not torch.equal(eng.store.p, p_prev) and bool(torch.isfinite(eng.store.p).all())
+            if n_cus:
+                assert sync.occupied > 0
+            eng.check_sync()
+        finally:
+            sync.close()
+    lo = eng.losses(ws)
+    assert np.isfinite(lo['total'])
+    print('\n%s: data-parallel step %.3f ms; with 32 CUs taken during every all-reduce %.3f ms (x%.2f); with 64: %.3f ms (x%.2f)' % (
+        name, 1e3 * times[0], 1e3 * times[32], times[32] / times[0], 1e3 * times[64], times[64] / times[0]))
+    if name == 'cfg2':
+        # 224 BPTT workgroups + 32 occupied CUs = 256: everything stays resident
+        assert times[32] <= 1.15 * times[0], times
+    # beyond that late workgroups queue behind the occupying kernels: slower by at most their duration per exchange, no stall
+    nstage = 6
+    assert times[64] <= times[0] + 1.5 * nstage * usec * 1e-6 + 0.15 * times[0], times

@@ -109,6 +109,18 @@ def test_global_batches_give_every_rank_the_same_number_of_steps():
             assert sum(len(p) for p in parts) == len(g)
             seen += [i for p in parts for i in p]
         assert sorted(seen) == list(range(n))                # disjoint cover
+        # the same with the global batch dealt out by length: still a disjoint cover with at most B per rank, every rank's
+        # utterances are as long in total as any other's (to within one utterance), and a short last batch is SPREAD over the ranks
+        lengths = np.random.default_rng(n).integers(1, 400, size=n)
+        seen = []
+        for g in gb:
+            parts = [rank_slice(g, B, r, world, lengths) for r in range(world)]
+            assert all(len(p) <= B for p in parts) and sum(len(p) for p in parts) == len(g)
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            tot = [int(lengths[p].sum()) for p in parts]
+            assert max(tot) - min(tot) <= int(lengths[g].max())
+            seen += [i for p in parts for i in p]
+        assert sorted(seen) == list(range(n))
 
 
 def _uneven_worker(rank, world, port, q):
