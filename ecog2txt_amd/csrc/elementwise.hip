@@ -639,6 +639,98 @@ __global__ void k_greedy_update(const int* pred, int B, int l, int Lmax, int eos
 }
 
 // ---------------------------------------------------------------------------
+// a9, beam_width > 1 (mocha-1_word_sequence.yaml:31; temperature :82): one step of beam search for utterance b = blockIdx.x.
+// Rows b*W + w of `logits` are the W live hypotheses.  Candidates: for a live beam w every token v, scored
+// score[w] + log softmax(logits[w] / temperature)[v]; for a finished beam only "stay finished" (score unchanged).  The W best
+// survive -- ties: lower beam first, within a beam the stay candidate, then lower token ids (oracle/seq2seq.py: beam_decode).
+// Outputs: the new scores / finished flags / token histories (gathered from the parents), rowmap[b*W + k] = row of the parent
+// (for the state reorder), next_tok = the input tokens of the next step.  All arrays are double-buffered by the caller.
+// ---------------------------------------------------------------------------
+#define E2T_BEAM_MAX 16
+__global__ __launch_bounds__(256) void k_beam_step(const float* logits, int ldl, int W, int V, float inv_temp, int l, int Lmax, int eos, int pad,
+                                                   const float* score_in, const int* done_in, const int* hyp_in,
+                                                   float* score_out, int* done_out, int* hyp_out, int* rowmap, int* next_tok) {
+    __shared__ float s_lse[E2T_BEAM_MAX], s_score[E2T_BEAM_MAX];
+    __shared__ int s_done[E2T_BEAM_MAX];
+    __shared__ float s_rv[4]; __shared__ int s_ri[4];
+    __shared__ int s_sel[E2T_BEAM_MAX]; __shared__ float s_selv[E2T_BEAM_MAX];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < W) { s_score[tid] = score_in[b * W + tid]; s_done[tid] = done_in[b * W + tid]; }
+    // log-sum-exp of every beam's row (scaled by 1 / temperature): wave wv takes beams wv, wv + 4, ...
+    for (int w = wv; w < W; w += 4) {
+        const float* row = logits + (size_t)(b * W + w) * ldl;
+        float mx = -INFINITY;
+        for (int v = lane; v < V; v += 64) mx = fmaxf(mx, row[v] * inv_temp);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int v = lane; v < V; v += 64) se += __expf(row[v] * inv_temp - mx);
+        se = wave_sum(se);
+        if (lane == 0) s_lse[w] = mx + __logf(se);
+    }
+    __syncthreads();
+    const int NC = W * (V + 1);                  // candidate id = w * (V + 1) + (token + 1); token -1 = stay finished
+    for (int k = 0; k < W; ++k) {
+        float bv = -INFINITY; int bi = 0x7FFFFFFF;
+        for (int c = tid; c < NC; c += 256) {
+            const int w = c / (V + 1), tv = c - w * (V + 1) - 1;
+            bool taken = false;
+            for (int q = 0; q < k; ++q) taken |= (s_sel[q] == c);
+            if (taken) continue;
+            float val;
+            if (tv < 0) val = s_done[w] ? s_score[w] : -INFINITY;
+            else val = s_done[w] ? -INFINITY : s_score[w] + (logits[(size_t)(b * W + w) * ldl + tv] * inv_temp - s_lse[w]);
+            if (val > bv || (val == bv && c < bi)) { bv = val; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_rv[wv] = bv; s_ri[wv] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 1; q < 4; ++q) if (s_rv[q] > bv || (s_rv[q] == bv && s_ri[q] < bi)) { bv = s_rv[q]; bi = s_ri[q]; }
+            s_sel[k] = bi; s_selv[k] = bv;
+        }
+        __syncthreads();
+    }
+    if (tid < W) {
+        const int c = s_sel[tid];
+        const int w = (c == 0x7FFFFFFF) ? 0 : c / (V + 1);
+        const int tv = (c == 0x7FFFFFFF) ? -1 : c - w * (V + 1) - 1;
+        const bool stay = tv < 0, was = s_done[w] != 0;
+        score_out[b * W + tid] = s_selv[tid];
+        done_out[b * W + tid] = (was || stay || tv == eos) ? 1 : 0;
+        rowmap[b * W + tid] = b * W + w;
+        if (next_tok) next_tok[b * W + tid] = stay ? eos : tv;
+        const int* hi = hyp_in + (size_t)(b * W + w) * Lmax;
+        int* ho = hyp_out + (size_t)(b * W + tid) * Lmax;
+        for (int j = 0; j < Lmax; ++j) ho[j] = (j == l) ? ((stay || was) ? pad : tv) : hi[j];
+    }
+}
+// The decoder state of the surviving hypotheses: h (row-major block of the ext output array) and c (the lane-native save of the
+// step, csrc/lstm.hip) of row r <- those of row rowmap[r].  mode 0: state -> scratch; mode 1: state[r] <- scratch[rowmap[r]].
+__global__ void k_beam_reorder(bf16_t* Yblk, int ldy, float* Cs_step, int B, int H, int H8, const int* rowmap, bf16_t* tmp_h, float* tmp_c, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, u = i - b * H;
+    const int UT = (H + 15) >> 4;
+    auto cidx = [&](int bb) {
+        const size_t tile = (size_t)(bb >> 4) * UT + (u >> 4);
+        const int lane = (((u & 15) >> 2) << 4) + (bb & 15);
+        return ((tile * 2 + ((u & 3) >> 1)) * 64 + lane) * 2 + (u & 1);
+    };
+    if (mode == 0) {
+        tmp_h[(size_t)b * H8 + u] = Yblk[(size_t)b * ldy + u];
+        tmp_c[(size_t)b * H + u] = Cs_step[cidx(b)];
+    } else {
+        const int src = rowmap[b];
+        Yblk[(size_t)b * ldy + u] = tmp_h[(size_t)src * H8 + u];
+        Cs_step[cidx(b)] = tmp_c[(size_t)src * H + u];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a10: fused Adam (TF1 AdamOptimizer form) + EMA shadow over a flat fp32 range
 // ---------------------------------------------------------------------------
 __global__ void k_inc_step(int* step, const int* skip) { if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip != 0)) step[0] += 1; }
@@ -843,6 +935,24 @@ extern "C" int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, in
                                  int32_t* next_tok, void* stream) {
     E2T_CHECK_ARG(pred && done && out && B > 0 && l >= 0 && l < Lmax);
     hipLaunchKernelGGL(k_greedy_update, dim3((B + 255) / 256), dim3(256), 0, ST, pred, B, l, Lmax, eos, pad, done, out, next_tok);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_beam_step(const float* logits, int ldl, int B, int W, int V, float temperature, int l, int Lmax, int eos, int pad,
+                             const float* score_in, const int32_t* done_in, const int32_t* hyp_in, float* score_out, int32_t* done_out,
+                             int32_t* hyp_out, int32_t* rowmap, int32_t* next_tok, void* stream) {
+    E2T_CHECK_ARG(logits && score_in && done_in && hyp_in && score_out && done_out && hyp_out && rowmap);
+    E2T_CHECK_ARG(B > 0 && W >= 1 && W <= E2T_BEAM_MAX && V > 0 && ldl >= V && temperature > 0.f && l >= 0 && l < Lmax);
+    hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(256), 0, ST, logits, ldl, W, V, 1.0f / temperature, l, Lmax, eos, pad, score_in, done_in,
+                       hyp_in, score_out, done_out, hyp_out, rowmap, next_tok);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_beam_reorder(void* Yblk, int ldy, float* Cs_step, int rows, int H, const int32_t* rowmap, void* tmp_h, float* tmp_c,
+                                void* stream) {
+    E2T_CHECK_ARG(Yblk && Cs_step && rowmap && tmp_h && tmp_c && rows > 0 && H > 0 && ldy >= H);
+    const int n = rows * H, H8 = (H + 7) / 8 * 8;
+    for (int mode = 0; mode < 2; ++mode)
+        hipLaunchKernelGGL(k_beam_reorder, dim3((n + 255) / 256), dim3(256), 0, ST, (bf16_t*)Yblk, ldy, Cs_step, rows, H, H8, rowmap,
+                           (bf16_t*)tmp_h, tmp_c, mode);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_inc_step(int32_t* step, const int32_t* skip_if_nonzero, void* stream) {

@@ -80,7 +80,7 @@ class SequenceNetwork:
         self._engine = None
         self._engine_key = None
         self._epoch = 0
-        assert (self.beam_width or 1) == 1, 'only greedy decoding (beam_width 1, mocha-1_word_sequence.yaml:31) is implemented'
+        assert 1 <= int(self.beam_width or 1) <= 16, 'beam_width (mocha-1_word_sequence.yaml:31) must lie in 1..16'
 
     def vprint(self, *a, **k):
         if self.VERBOSE:
@@ -380,7 +380,12 @@ class SequenceNetwork:
                     y = data['Y'][i]
                     for l in range(int((y != 0).sum())):
                         conf[y[l], pred[b, l]] += 1
-            hyp_all[idx] = eng.greedy_decode(ws, which='ema').cpu().numpy()[:len(idx)]
+            W = int(self.beam_width or 1)
+            if W > 1:       # beam search (beam_width, temperature: mocha-1_word_sequence.yaml:31, 82); width 1 = greedy
+                hyp_dev, _ = eng.beam_decode(ws, W, float(self.temperature or 1.0), which='ema')
+            else:
+                hyp_dev = eng.greedy_decode(ws, which='ema')
+            hyp_all[idx] = hyp_dev.cpu().numpy()[:len(idx)]
         eng.check_sync(ws)                                   # a timed-out forward pass must not be reported as a result
         eng.pack('p')
         if sync is not None:

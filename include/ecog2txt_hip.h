@@ -254,6 +254,17 @@ int e2t_softmax_ce(const float* logits, int ldl, int M, int V, const int32_t* tg
                    int lddl, void* stream);
 int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
                       int32_t* next_tok, void* stream);
+/* Beam search (beam_width > 1, mocha-1_word_sequence.yaml:31; temperature :82): one step for B utterances x W hypotheses
+ * (rows b*W + w of logits [B*W][ldl]).  A live hypothesis continues with every token, scored
+ * score + log softmax(logits / temperature); a finished one (it has emitted <EOS>) only as itself; the W best survive (ties:
+ * lower beam, then lower token).  score / done / hyp [B*W][Lmax] are double-buffered by the caller (in -> out); rowmap[r] =
+ * row of hypothesis r's parent; next_tok (may be NULL) = input tokens of the next step.  W <= 16. */
+int e2t_beam_step(const float* logits, int ldl, int B, int W, int V, float temperature, int l, int Lmax, int eos, int pad,
+                  const float* score_in, const int32_t* done_in, const int32_t* hyp_in, float* score_out, int32_t* done_out,
+                  int32_t* hyp_out, int32_t* rowmap, int32_t* next_tok, void* stream);
+/* the decoder state (one direction) of the surviving hypotheses: row r of Yblk (bf16 [rows][ldy], one time block of Yext) and of
+ * the step's lane-native cell save Cs_step <- those of row rowmap[r]; tmp_h bf16 [rows][roundup(H,8)], tmp_c fp32 [rows][H] */
+int e2t_beam_reorder(void* Yblk, int ldy, float* Cs_step, int rows, int H, const int32_t* rowmap, void* tmp_h, float* tmp_c, void* stream);
 /* ---- a8: Gaussian encoder-target head ---- */
 int e2t_mse(const float* P, int ldp, const float* At, int M, int K, const int32_t* lens, int rows_per_step,
             const int32_t* nval, float weight, float* rowloss, void* dP, int lddp, void* stream);

@@ -657,3 +657,70 @@ def greedy_decode(P, spec, batch, max_len=20, emulate_bf16=False):
         if done.all():
             break
     return out, np.stack(all_logits, 0)
+
+
+def beam_decode(P, spec, batch, beam_width, max_len=20, temperature=1.0, emulate_bf16=False):
+    """Beam search over the decoder (`beam_width`, mocha-1_word_sequence.yaml:31; `temperature`, :82 -- both are manifest keys
+    the reference hands to the absent SequenceNetwork, so the exact rule is [BUILD-DEFINES]): the standard one of
+    tf.contrib.seq2seq.BeamSearchDecoder with length_penalty_weight 0.
+      * score of a hypothesis = sum of log softmax(logits / temperature) of its tokens;
+      * at every step the W best of the W x V continuations survive (ties: lower beam, then lower token id);
+        a hypothesis that has emitted <EOS> is finished: its only continuation is itself, score unchanged;
+      * start: beam 0 holds <EOS> as start symbol with score 0, the other beams -inf (W copies of one state);
+      * result: the best-scoring hypothesis per utterance after max_len steps, padded with <pad> behind its <EOS>.
+    beam_width 1 is greedy decoding.  Returns (tokens [B, max_len], scores [B, W] of the final beams, best first)."""
+    q = round_bf16 if emulate_bf16 else _identity
+    W = int(beam_width)
+    dummy = dict(batch)
+    B = np.asarray(batch['encoder_inputs']).shape[0]
+    dummy['decoder_targets'] = np.full((B, 1), EOS_ID, np.int64)
+    dummy.pop('encoder_targets', None)
+    _, cache = forward(P, spec, dummy, train=False, emulate_bf16=emulate_bf16)
+    Emb = q(P['seq2seq/decoder_embedding_%d_%d_0/weights' % (spec.vocab, spec.dec_embed)])
+    Kx, Kh = _split_kernel(P['seq2seq/decoder_rnn/cell_0/kernel'], spec.dec_embed)
+    Wx, Wh = q(Kx), q(Kh)
+    bias = P['seq2seq/decoder_rnn/cell_0/bias']
+    pnames = ff_names('decoder_projection', [spec.dec_rnn] + list(spec.dec_proj_hidden) + [spec.vocab])
+    H, V = spec.dec_rnn, spec.vocab
+    h = np.repeat(cache['h0'], W, axis=0)                     # row b*W + w
+    c = np.repeat(cache['c0'], W, axis=0)
+    u = np.full(B * W, EOS_ID, np.int64)
+    score = np.full((B, W), -np.inf)
+    score[:, 0] = 0.0
+    done = np.zeros((B, W), bool)
+    toks = np.full((B, W, max_len), PAD_ID, np.int64)
+    for l in range(max_len):
+        z = q(Emb[u]) @ Wx + bias + h @ Wh
+        i = sigmoid(z[:, :H]); j = np.tanh(z[:, H:2 * H])
+        f = sigmoid(z[:, 2 * H:3 * H] + spec.forget_bias); o = sigmoid(z[:, 3 * H:])
+        cn = f * c + i * j
+        hn = q(o * np.tanh(cn))
+        logits, _ = ff_fwd(P, pnames, hn, spec, q, False, 0, 0)
+        x = logits / temperature
+        x = x - x.max(-1, keepdims=True)
+        logp = (x - np.log(np.exp(x).sum(-1, keepdims=True))).reshape(B, W, V)
+        cand = score[:, :, None] + logp                          # [B, W, V]
+        # a finished hypothesis continues only as itself (token <pad>, score unchanged)
+        cand = np.where(done[:, :, None], -np.inf, cand)
+        keep = np.where(done, score, -np.inf)                    # [B, W]: the "stay finished" candidate of each beam
+        flat = np.concatenate([cand.reshape(B, W * V), keep], axis=1)      # candidate index: w*V + v, or W*V + w
+        # order: best score first; ties by candidate index of (beam, token) with the stay-candidates ordered by their beam
+        key_beam = np.concatenate([np.repeat(np.arange(W), V), np.arange(W)])
+        key_tok = np.concatenate([np.tile(np.arange(V), W), np.full(W, -1)])
+        new_score = np.empty((B, W)); parent = np.empty((B, W), np.int64); tok = np.empty((B, W), np.int64)
+        for b in range(B):
+            order = np.lexsort((key_tok, key_beam, -flat[b]))[:W]
+            new_score[b] = flat[b, order]; parent[b] = key_beam[order]; tok[b] = key_tok[order]
+        rows = (np.arange(B)[:, None] * W + parent).reshape(-1)
+        h, c = hn[rows], cn[rows]
+        toks = np.take_along_axis(toks, parent[:, :, None], axis=1)
+        was_done = np.take_along_axis(done, parent, axis=1)
+        stay = tok < 0
+        toks[:, :, l] = np.where(stay | was_done, PAD_ID, tok)
+        done = was_done | stay | (tok == EOS_ID)
+        score = new_score
+        u = np.where(stay, EOS_ID, tok).reshape(-1)             # (input of a finished beam: irrelevant)
+        if done.all():
+            break
+    best = np.argmax(score, axis=1)                              # (beams are kept best first: index 0)
+    return toks[np.arange(B), best], score

@@ -44,6 +44,14 @@ def test_readme_flow_learns(small):
     assert res['validation'].word_error_rate < 0.25, res['validation'].word_error_rate
     assert res['validation'].accuracy > 0.8
     assert res['validation'].decoder_confusions.shape == (23, 23)
+    # the same checkpoint assessed with beam search (`beam_width: 4`, `temperature`: manifest keys, mocha-1_word_sequence.yaml:31,
+    # 82 -- a fresh trainer with the keys overridden): the trained model is confident, so the best beam is the greedy sequence
+    tr_b = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False, restore_epoch=60,
+                               SN_kwargs={'N_cases': 32, 'beam_width': 4, 'temperature': 0.8, 'EMA_decay': 0.9}, DG_kwargs={'max_samples': 420})
+    res_b = tr_b.assess_saved_model()
+    assert tr_b.net.beam_width == 4
+    assert res_b['validation'].word_error_rate <= res['validation'].word_error_rate + 0.05
+    assert (np.asarray(res_b['validation'].hypotheses, dtype=object) == np.asarray(res['validation'].hypotheses, dtype=object)).mean() > 0.8
     # sizes recovered from the checkpoint by the reference's variable grammar
     ls, ds, strides, ema = tr.recover_model_sizes()
     assert ls['encoder_rnn'] == [32, 32] and ls['decoder_rnn'] == [64] and ls['encoder_embedding'] == [24]
