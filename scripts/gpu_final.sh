@@ -1,5 +1,5 @@
 # Round-end evidence: tests, bench (cfg2 with roofline + CPU baseline), rocprofv3 stats + timeline, the other configs.
-tag=${1:-r02f}
+tag=${1:-r03}
 out=$PWD/gpurun_out/$tag; mkdir -p $out
 bash scripts/gpu_round.sh $tag tests noprof > $out/round.log 2>&1
 tail -5 $out/pytest.log
