@@ -206,16 +206,18 @@ def main():
         eng.train_step(wss[it[0] % len(wss)], use_graph=not args.no_graph, sync=sync)
         it[0] += 1
 
-    for _ in range(max(args.warmup, len(wss))):
-        step()
-    torch.cuda.synchronize()
-    if sync is not None:
-        sync.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+    # the step loop runs with the engine's own stream current, as SequenceNetwork.fit runs it (engine.on_step_stream)
+    with eng.on_step_stream():
+        for _ in range(max(args.warmup, len(wss))):
+            step()
+        torch.cuda.synchronize()
+        if sync is not None:
+            sync.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
     if sync is not None:
         sync.barrier()
     torch.cuda.synchronize()

@@ -31,3 +31,6 @@ th="$here/../../tests/native"
 if [ -f "$th/occupy.hip" ] && { [ ! -f "$th/libe2t_test_occupy.so" ] || [ "$th/occupy.hip" -nt "$th/libe2t_test_occupy.so" ]; }; then
     hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared "$th/occupy.hip" -o "$th/libe2t_test_occupy.so" > "$obj/occupy.log" 2>&1 || { cat "$obj/occupy.log"; exit 1; }
 fi
+if [ -f "$th/segv_bt.c" ] && { [ ! -f "$th/libe2t_test_segv_bt.so" ] || [ "$th/segv_bt.c" -nt "$th/libe2t_test_segv_bt.so" ]; }; then
+    gcc -O1 -g -shared -fPIC "$th/segv_bt.c" -o "$th/libe2t_test_segv_bt.so" || exit 1
+fi

@@ -115,8 +115,9 @@ __device__ __attribute__((noinline)) f32x4 drop_scale4_straddle(unsigned long lo
     return (f32x4){((w0 >> 8) >= thresh) ? keep : 0.f, ((w1 >> 8) >= thresh) ? keep : 0.f, ((w2 >> 8) >= thresh) ? keep : 0.f, ((w3 >> 8) >= thresh) ? keep : 0.f};
 }
 // v: alpha * product (+ bias) of row gm, columns gn0..gn0+3.  RICH = false drops ReLU / mask / dropout.
+// epi_apply4: everything between the product and the store (the values stay with the lane that computed them)
 template <bool RICH>
-__device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, int gm, int gn0, float (&v)[4], bool rowvalid) {
+__device__ __forceinline__ void epi_apply4(const GemmArgs& p, const EpiCtx& ec, int gm, int gn0, float (&v)[4], bool rowvalid) {
     if (p.last_col_out && gn0 + 3 >= p.N - 1 && gn0 <= p.N - 1) p.last_col_out[gm] = v[p.N - 1 - gn0];
     if (gn0 >= ec.Nst) return;
     const int nv = min(4, ec.Nst - gn0);
@@ -138,6 +139,11 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, 
         }
     }
     if (!rowvalid) { for (int r = 0; r < 4; ++r) v[r] = 0.f; }
+}
+// epi_put4: the lane's 4 consecutive columns to C (8 B of bf16 or 16 B of fp32)
+__device__ __forceinline__ void epi_put4(const GemmArgs& p, const EpiCtx& ec, int gm, int gn0, const float (&v)[4]) {
+    if (gn0 >= ec.Nst) return;
+    const int nv = min(4, ec.Nst - gn0);
     if (ec.out_bf16) {
         bf16_t* c = (bf16_t*)p.C + (size_t)gm * p.ldc + gn0;
         if (nv == 4 && (p.ldc & 3) == 0) *(ushort4*)c = make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
@@ -152,6 +158,26 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, 
             for (int r = 0; r < nv; ++r) c[r] = ec.accum ? (c[r] + v[r]) : v[r];
         }
     }
+}
+// epi_put8_pair: bf16 output of TWO adjacent 16-column sub-tiles.  A lane holds columns fq*4 .. fq*4+3 of both; after two
+// v_permlane16_swap per pair of packed words (odd 16-lane rows of the first operand <-> even rows of the second) lane fq holds
+// EIGHT consecutive columns -- of the first sub-tile for even fq, of the second for odd fq -- and stores 16 B: the wave writes
+// 16 rows x 64 contiguous bytes per instruction (the shape of the fp32 store) instead of two instructions of 16 x 32 B.
+// Needs all 32 columns inside the stored range, ldc % 8 == 0 and C 16-B aligned (wave-uniform conditions, checked by the caller).
+__device__ __forceinline__ void epi_put8_pair(const GemmArgs& p, int gm, int gn_pair0, int fq, const float (&a)[4], const float (&b)[4]) {
+    unsigned a01 = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16), a23 = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
+    unsigned b01 = (unsigned)f2bf(b[0]) | ((unsigned)f2bf(b[1]) << 16), b23 = (unsigned)f2bf(b[2]) | ((unsigned)f2bf(b[3]) << 16);
+    const auto lo = __builtin_amdgcn_permlane16_swap(a01, b01, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(a23, b23, false, false);
+    // lo[0] / hi[0]: rows fq = 0, 2 keep the first sub-tile's own columns, rows 1, 3 got the second sub-tile's columns of fq - 1;
+    // lo[1] / hi[1]: rows 0, 2 got the first sub-tile's columns of fq + 1, rows 1, 3 keep the second sub-tile's own
+    bf16_t* c = (bf16_t*)p.C + (size_t)gm * p.ldc + gn_pair0 + (fq & 1) * 16 + (fq >> 1) * 8;
+    *(uint4*)c = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+}
+template <bool RICH>
+__device__ __forceinline__ void epi_store4(const GemmArgs& p, const EpiCtx& ec, int gm, int gn0, float (&v)[4], bool rowvalid) {
+    epi_apply4<RICH>(p, ec, gm, gn0, v, rowvalid);
+    epi_put4(p, ec, gm, gn0, v);
 }
 
 
@@ -173,7 +199,7 @@ constexpr int gemm_wgs_per_cu(int bm, int bn, int kt, int ns) {
 // 32 x 3, 64 x 4, and a software pipeline across the barrier, were all slower: they add instructions, not overlap).  What
 // pays is fewer bytes and fewer instructions per flop: the locality order of the grid and the scalar-base DMA form below.
 // DBG (diagnostics, scripts/gemm_loop_probe.py): 1 = no operand loads after the prologue, 2 = loads and barriers only (no
-// fragment reads, no MFMA), 3 = fragment reads without MFMAs -- wrong results by design, timing only
+// fragment reads, no MFMA), 3 = fragment reads without MFMAs, 4 = no stores in the epilogue -- wrong results by design, timing only
 template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT, int NS, int DBG>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* workgroup index within this product's launch */) {
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -456,6 +482,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias4[j][r] = (p.bias && !atomic && gn0 + r < ec.Nst) ? p.bias[gn0 + r] : 0.f;
     }
+    static_assert(TJ % 2 == 0, "the epilogue handles the 16-column sub-tiles in pairs");
+    // bf16 outputs go out in pairs of sub-tiles (epi_put8_pair) wherever both lie wholly inside the stored columns
+    const bool pair_base = ec.out_bf16 && !atomic && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int gm = m0 + wm + i * 16 + frow;
@@ -463,24 +492,44 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
         bool rowvalid = true;
         if (!atomic) rowvalid = row_valid(p, gm);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int gn0 = n0 + wn + j * 16 + fq * 4;
-            if (gn0 >= p.N) continue;
-            float v[4];
+        for (int jp = 0; jp < TJ; jp += 2) {
+            const int gnp = n0 + wn + jp * 16;                 // first column of the pair (wave-uniform)
+            if (gnp >= p.N) continue;
+            float v[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[h][r] = acc[i][jp + h][r] * p.alpha;
             if (atomic) {
                 // split-K: dense partial slab (all N columns incl. the bias column); summed in fixed order, and run
                 // through the same epilogue, by k_splitk_reduce
-                float* c = p.slab + ((size_t)ksplit * p.M + gm) * p.N + gn0;
-                const int nn = min(4, p.N - gn0);
-                if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-                else for (int r = 0; r < nn; ++r) c[r] = v[r];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int gn0 = gnp + h * 16 + fq * 4;
+                    if (gn0 >= p.N) continue;
+                    float* c = p.slab + ((size_t)ksplit * p.M + gm) * p.N + gn0;
+                    const int nn = min(4, p.N - gn0);
+                    if (nn == 4 && (p.N & 3) == 0) *(float4*)c = make_float4(v[h][0], v[h][1], v[h][2], v[h][3]);
+                    else for (int r = 0; r < nn; ++r) c[r] = v[h][r];
+                }
                 continue;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bias4[j][r];
-            epi_store4<RICH>(p, ec, gm, gn0, v, rowvalid);
+            for (int h = 0; h < 2; ++h) {
+                const int gn0 = gnp + h * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[h][r] += bias4[jp + h][r];
+                if (gn0 < p.N) epi_apply4<RICH>(p, ec, gm, gn0, v[h], rowvalid);
+            }
+            if (DBG == 4) { asm volatile("" :: "v"(v[0][0]), "v"(v[0][1]), "v"(v[0][2]), "v"(v[0][3]), "v"(v[1][0]), "v"(v[1][1]), "v"(v[1][2]), "v"(v[1][3])); continue; }
+            if (pair_base && gnp + 32 <= ec.Nst) epi_put8_pair(p, gm, gnp, fq, v[0], v[1]);
+            else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int gn0 = gnp + h * 16 + fq * 4;
+                    if (gn0 < p.N) epi_put4(p, ec, gm, gn0, v[h]);
+                }
+            }
         }
     }
 }
@@ -1093,6 +1142,10 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     else if (tn && !big && dbg == 3) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 3);
     else if (!tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 1);
     else if (!tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 2);
+#ifdef E2T_DEBUG
+    else if (big && !tn && dbg == 4) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 4);     // everything but the stores of the epilogue
+    else if (big && !tn && dbg == 2) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 2);     // loads, barriers and the epilogue only
+#endif
     else if (big && tn) E2T_GEMM_GO(256, 256, 2, 4, false, true, 64, 2, 0);
     else if (tn) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 0);
     else if (big) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 0);

@@ -226,7 +226,7 @@ __device__ __forceinline__ void reduce_scatter(const f32x4 (&acc)[NG], float* xb
 }
 
 struct LstmFwdArgs {
-    const float* Gx;        // [S*B][ndir*H*4]  fp32, (dir, unit, gate) interleaved, bias included (row-major, time-major rows)
+    const bf16_t* Gx;       // [S*B][ndir*H*4]  bf16, (dir, unit, gate) interleaved, bias included (row-major, time-major rows)
     const bf16_t* WhF;      // [ndir][4 gates][UT][KB][64 lanes][8]  fragment-packed W_h
     bf16_t* Yext;           // [(S+3)*B][ldy]   time block tau = t+1; block 0 = initial h, S+1.. = zero slack
     bf16_t* Ydrop;          // [S*B][ldy] or null
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     // (finite; their results are discarded); the backward direction's FIRST step must see a zero state and
     // reads the all-zero slack block S+1 (the block at position t = len is only re-zeroed later this pass).
     const bf16_t* srow;
-    const float* gxrow;
+    const bf16_t* gxrow;
     {
         const bool act = (fb < B) && s < flen;
         const int gb = min(fb, B - 1);
@@ -295,11 +295,11 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     const size_t wgs = (size_t)p.UT * KB * 64;
     issue_chunk<4>(wsrc, wgs, KB, srow, 0, lstm_smem, G, wave, lane);
     if (G.nch > 1) issue_chunk<4>(wsrc, wgs, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
-    // Gx of the fetched rows: 8 rows x 256 B = two 8-row x 128-B instructions (unit halves)
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        const int gu = ut * 16 + ch * 8 + (lane & 7);                   // unit whose 4 gates this lane moves
-        dma16_to_lds(gxrow + (gu < H ? (size_t)gu * 4 : 0), lds_addr_of(gx_lds + (wave * 2 + ch) * 64));
+    // Gx of the fetched rows: 8 rows x 16 units x 4 gates of bf16 = 8 x 128 B: ONE instruction, lane (row lane>>3, unit pair lane&7)
+    // moves the 8 gates of units 2*(lane&7), +1 (a unit pair beyond H re-reads pair 0: never used)
+    {
+        const int gu = ut * 16 + 2 * (lane & 7);
+        dma16_to_lds(gxrow + (gu < H ? (size_t)gu * 4 : 0), lds_addr_of(gx_lds + wave * 64));
     }
     const int khalf = wave >> 2;                      // which K half this wave multiplies / which 2 cells it finishes
     const int u0 = ut * 16 + fq * 4 + 2 * khalf;      // first of this lane's 2 units
@@ -343,12 +343,12 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
         if (p.Ydrop && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e4, dsc4);
         float hv[2], cv[2], hd[2];
         const float cp[2] = {cprev.x, cprev.y};
-        const uint4* gxt = gx_lds + (((wave & 3) * 2 + (frow >> 3)) * 2) * 64 + (frow & 7) * 8;
+        // the lane's two units fq*4 + 2*khalf, +1 are ONE 16-B slot: [fetching wave (row tile, row half)][row][unit pair]
+        const uint4 graw = gx_lds[((wave & 3) * 2 + (frow >> 3)) * 64 + (frow & 7) * 8 + fq * 2 + khalf];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-            const int cidx = fq * 4 + 2 * khalf + rr;     // unit index within the tile
-            uint4 raw = gxt[(cidx >> 3) * 64 + (cidx & 7)];
-            const float4 gx = *(float4*)&raw;
+            const unsigned g01 = rr ? graw.z : graw.x, g23 = rr ? graw.w : graw.y;
+            const float4 gx = make_float4(__uint_as_float(g01 << 16), __uint_as_float(g01 & 0xFFFF0000u), __uint_as_float(g23 << 16), __uint_as_float(g23 & 0xFFFF0000u));
             const float gi = fsigmoid(z[0][rr] + gx.x);
             const float gj = ftanh(z[1][rr] + gx.y);
             const float gf = fsigmoid(z[2][rr] + gx.z + p.forget_bias);
@@ -463,9 +463,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
     auto gx_load = [&](int s) {
         const bool act = own && s < len;
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
-        const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
+        const bf16_t* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s % 3) * 4 + r) * 64));
+        for (int r = 0; r < 2; ++r) dma16_to_lds(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
     };
     gx_load(0);
     if (S > 1) gx_load(1);
@@ -575,10 +575,12 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
 
         // ---- lane-local cell update for (utterance b, units u0..u0+3): critical part ----
         float gi[4], gj[4], gf[4], go[4], hv[4];
+        const uint4 gxq[2] = {gxl[((s % 3) * 2 + 0) * 64 + lane], gxl[((s % 3) * 2 + 1) * 64 + lane]};     // units u0, u0+1 | u0+2, u0+3: 4 gates of bf16 each
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint4 graw = gxl[((s % 3) * 4 + r) * 64 + lane];
-            const float gxv[4] = {__uint_as_float(graw.x), __uint_as_float(graw.y), __uint_as_float(graw.z), __uint_as_float(graw.w)};
+            const uint4 graw = gxq[r >> 1];
+            const unsigned g01 = (r & 1) ? graw.z : graw.x, g23 = (r & 1) ? graw.w : graw.y;
+            const float gxv[4] = {__uint_as_float(g01 << 16), __uint_as_float(g01 & 0xFFFF0000u), __uint_as_float(g23 << 16), __uint_as_float(g23 & 0xFFFF0000u)};
             gi[r] = fsigmoid((acc[0][0][r] + acc[1][0][r]) + gxv[0]);
             gj[r] = ftanh((acc[0][1][r] + acc[1][1][r]) + gxv[1]);
             gf[r] = fsigmoid((acc[0][2][r] + acc[1][2][r]) + gxv[2] + p.forget_bias);
@@ -713,9 +715,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
     auto gx_load = [&](int s) {
         const bool act = own && s < len;
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
-        const float* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (own ? u0 : 0)) * 4;
+        const bf16_t* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (own ? u0 : 0)) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dma16_to_lds(q + r * 4, lds_addr_of(gxl + ((s % 3) * 4 + r) * 64));
+        for (int r = 0; r < 2; ++r) dma16_to_lds(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
     };
     gx_load(0);
     if (S > 1) gx_load(1);
@@ -833,13 +835,15 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
         }
         // ---- lane-local cell update for (utterance b, units u0..u0+3) ----
         float gi[4], gj[4], gf[4], go[4], hv[4];
+        const uint4 gxq[2] = {gxl[((s % 3) * 2 + 0) * 64 + lane], gxl[((s % 3) * 2 + 1) * 64 + lane]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint4 graw = gxl[((s % 3) * 4 + r) * 64 + lane];
-            gi[r] = fsigmoid(z[0][r] + __uint_as_float(graw.x));
-            gj[r] = ftanh(z[1][r] + __uint_as_float(graw.y));
-            gf[r] = fsigmoid(z[2][r] + __uint_as_float(graw.z) + p.forget_bias);
-            go[r] = fsigmoid(z[3][r] + __uint_as_float(graw.w));
+            const uint4 graw = gxq[r >> 1];
+            const unsigned g01 = (r & 1) ? graw.z : graw.x, g23 = (r & 1) ? graw.w : graw.y;
+            gi[r] = fsigmoid(z[0][r] + __uint_as_float(g01 << 16));
+            gj[r] = ftanh(z[1][r] + __uint_as_float(g01 & 0xFFFF0000u));
+            gf[r] = fsigmoid(z[2][r] + __uint_as_float(g23 << 16) + p.forget_bias);
+            go[r] = fsigmoid(z[3][r] + __uint_as_float(g23 & 0xFFFF0000u));
             const float cv = fmaf(gf[r], cst[r], gi[r] * gj[r]);
             hv[r] = go[r] * ftanh(cv);
             if (active) cst[r] = cv;
@@ -1362,7 +1366,7 @@ static int set_big_lds(const void* fn) {
     return E2T_OK;
 }
 
-extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext,
+extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext,
                                 void* Ydrop, float* Cs, float* Gs, const int32_t* lens, const float* c0,
                                 int step_begin, int step_end, void* stream) {
     E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens);
@@ -1372,7 +1376,7 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     static const int attr_rc = set_big_lds((const void*)k_lstm_step_fwd);          // (thread-safe one-time init)
     if (attr_rc) return attr_rc;
     LstmFwdArgs p{};
-    p.Gx = Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
+    p.Gx = (const bf16_t*)Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
     p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
@@ -1394,7 +1398,7 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const v
     return E2T_OK;
 }
 
-extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop,
+extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext, void* Ydrop,
                                            float* Cs, float* Gs, const int32_t* lens, const float* c0, void* hx,
                                            int32_t* err, int num_cus, void* stream) {
     E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens && hx && err);
@@ -1402,7 +1406,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* 
     E2T_CHECK_ARG(d->H % 2 == 0 && d->ldy % 8 == 0 && d->ldy >= d->ndir * ((d->H + 7) / 8) * 8);
     LstmPersistArgs pa{};
     LstmFwdArgs& p = pa.a;
-    p.Gx = Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
+    p.Gx = (const bf16_t*)Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
     p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;

@@ -74,7 +74,7 @@ __device__ __forceinline__ void big_block_map(int b, int ncl, int UG, int spread
 }
 
 struct BigFwdArgs {
-    const float* Gx;        // [S*B][ndir*H*4] fp32, (dir, unit, gate) interleaved, bias included
+    const bf16_t* Gx;       // [S*B][ndir*H*4] bf16, (dir, unit, gate) interleaved, bias included
     const bf16_t* WhG;      // [ndir][4H/16 column tiles][KB][64][8]: MFMA fragment image of Bn[n = gate column][k] (e2t_pack_frag)
     bf16_t* Yext;           // [(S+3)*B][ldy]
     bf16_t* Ydrop;          // [S*B][ldy] or null
@@ -160,16 +160,16 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_big(BigFwdArgs p) {
 #define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)
     for (int s = 0; s < S; ++s) {
         PSTAMP(0);
-        // ---- Gx of this step's cells: 8 x 16 B per lane, requested first (used after the MFMAs) ----
-        float4 gx[4][2];
+        // ---- Gx of this step's cells: 8 x 8 B per lane (4 gates of bf16), requested first (used after the MFMAs) ----
+        uint2 gxr[4][2];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const int b = min(rb * 64 + rt * 16 + frow, B - 1);
             const bool act = s < len4[rt];
             const int tt = act ? (dir ? (len4[rt] - 1 - s) : s) : 0;
-            const float* q = p.Gx + (((size_t)tt * B + b) * NH + dir * H + ug * 32 + wave * 8 + fq) * 4;
+            const bf16_t* q = p.Gx + (((size_t)tt * B + b) * NH + dir * H + ug * 32 + wave * 8 + fq) * 4;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) gx[rt][a] = *(const float4*)(q + a * 16);
+            for (int a = 0; a < 2; ++a) gxr[rt][a] = *(const uint2*)(q + a * 16);
         }
         // ---- state of row tile `wave` -> LDS ----
         if (s == 0) {
@@ -267,10 +267,11 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_big(BigFwdArgs p) {
             for (int a = 0; a < 2; ++a) {
                 const f32x4 z = (f32x4){acc[0][rt][a][0] + acc[1][rt][a][0], acc[0][rt][a][1] + acc[1][rt][a][1],
                                         acc[0][rt][a][2] + acc[1][rt][a][2], acc[0][rt][a][3] + acc[1][rt][a][3]};
-                gi[rt][a] = fsigmoid(z[0] + gx[rt][a].x);
-                gj[rt][a] = ftanh(z[1] + gx[rt][a].y);
-                gf[rt][a] = fsigmoid(z[2] + gx[rt][a].z + p.forget_bias);
-                go[rt][a] = fsigmoid(z[3] + gx[rt][a].w);
+                const uint2 gr = gxr[rt][a];
+                gi[rt][a] = fsigmoid(z[0] + __uint_as_float(gr.x << 16));
+                gj[rt][a] = ftanh(z[1] + __uint_as_float(gr.x & 0xFFFF0000u));
+                gf[rt][a] = fsigmoid(z[2] + __uint_as_float(gr.y << 16) + p.forget_bias);
+                go[rt][a] = fsigmoid(z[3] + __uint_as_float(gr.y & 0xFFFF0000u));
                 const float cv = fmaf(gf[rt][a], cst[rt][a], gi[rt][a] * gj[rt][a]);
                 hv[rt][a] = active ? go[rt][a] * ftanh(cv) : 0.f;
                 if (active) cst[rt][a] = cv;
@@ -365,14 +366,14 @@ static void step_fwd_halves(int KB, unsigned char (&kbl)[2][16], unsigned char (
 
 extern "C" int e2t_lstm_big_ok(int H) { return (H % 64 == 0 && H >= 448 && H <= 1024) ? 1 : 0; }
 
-extern "C" int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const float* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs,
+extern "C" int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const void* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs,
                                     float* Gs, const int32_t* lens, const float* c0, void* hx, uint32_t* flags, int32_t* err,
                                     int num_cus, void* stream) {
     E2T_CHECK_ARG(d && Gx && WhG && Yext && Cs && Gs && lens && hx && flags && err);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(e2t_lstm_big_ok(d->H) && d->ldy % 8 == 0 && d->ldy >= d->ndir * d->H);
     BigFwdArgs p{};
-    p.Gx = Gx; p.WhG = (const bf16_t*)WhG; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop; p.Cs = Cs; p.Gs = Gs;
+    p.Gx = (const bf16_t*)Gx; p.WhG = (const bf16_t*)WhG; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop; p.Cs = Cs; p.Gs = Gs;
     p.lens = lens; p.c0 = c0; p.hx = (bf16_t*)hx; p.flags = flags; p.err = err;
     p.S = d->S; p.B = d->B; p.H = d->H; p.ndir = d->ndir; p.ldy = d->ldy; p.UT = d->H / 16; p.KB = d->H / 32;
     p.forget_bias = d->forget_bias;

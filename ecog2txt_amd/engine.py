@@ -120,6 +120,8 @@ class Seq2SeqEngine:
         self.splitk_ws_side = _f32(16 * 1024 * 1024, device=dev)     # ... of the side stream (weight-gradient branch)
         self._on_side = False
         self._wstream = None
+        self._lstream = None
+        self.launch_stream_on = os.environ.get('E2T_LAUNCH_STREAM', '1') != '0'
         # E2T_OVERLAP=0: everything on one stream (diagnostics).  (Measured and dropped in rounds 1-2, DESIGN.md: weight gradients
         # on TWO side streams, the BPTT chain alone on the chip with all weight gradients behind it, per-stage joins.)
         self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
@@ -1108,7 +1110,48 @@ class Seq2SeqEngine:
         """One optimisation step on the batch staged in ws['X'], ws['Y'], ws['auxT'].
 
         sync: optional parallel.GradSync; each backward stage's gradient ranges are all-reduced
-        asynchronously right after the stage is enqueued, and Adam waits for all of them."""
+        asynchronously right after the stage is enqueued, and Adam waits for all of them.
+
+        Captured steps are replayed from a stream of the engine's own, ordered behind the caller's stream and joined back
+        into it (two event operations per step).  Reason: hipGraphLaunch (ROCm 7.0) picks the streams of a graph's parallel
+        branches from a pool with an unchecked scan that skips entries sharing the LAUNCH stream's queue; launched from the
+        default stream it can run off the end of that pool once other libraries (RCCL) have created streams in between
+        (SIGSEGV inside libamdhip64; scripts/probe_graph_streams.py reproduces it with torch alone: 4 of 96 launches from
+        the default stream, 0 of 96 from a side stream)."""
+        if use_graph and self.launch_stream_on and torch.cuda.current_stream(self.device) != self.step_stream():
+            # (a caller that steps in a loop avoids the two cross-stream hand-offs per step -- ~25 us at cfg2 -- by running the
+            #  loop inside `with engine.on_step_stream():`, as SequenceNetwork.fit and bench.py do)
+            with self.on_step_stream():
+                self._train_step(ws, use_graph, sync)
+            return
+        self._train_step(ws, use_graph, sync)
+
+    def step_stream(self):
+        if self._lstream is None:
+            self._lstream = torch.cuda.Stream(device=self.device)
+        return self._lstream
+
+    @contextlib.contextmanager
+    def on_step_stream(self):
+        """Make the engine's own stream current for the duration: ordered behind everything enqueued so far on the caller's
+        stream, and joined back into it on exit (also when the body raises)."""
+        cur = torch.cuda.current_stream(self.device)
+        ls = self.step_stream()
+        if cur == ls or not self.launch_stream_on:
+            yield
+            return
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ls.wait_event(ev)
+        try:
+            with torch.cuda.stream(ls):
+                yield
+        finally:
+            ev2 = torch.cuda.Event()
+            ev2.record(ls)
+            cur.wait_event(ev2)
+
+    def _train_step(self, ws, use_graph, sync):
         dp = sync is not None and sync.world > 1
         gc = bool(dp and ws.get('global_counts'))          # losses normalised by the global counts: the exchange is a plain sum
         lazy = use_graph and self.overlap      # re-pack inside the (first) graph
@@ -1340,8 +1383,8 @@ class Seq2SeqEngine:
                               self.E8, C.byref(dr), st)
             # input projection for this step's rows only
             self.gemm(ws['e'].data_ptr() + 2 * l * B * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
-                      dw['Gx'].data_ptr() + 4 * l * B * self.dec.N4, self.dec.N4, B, self.dec.N4, self.E8,
-                      bias=self.dec.bias_ptr(src))
+                      dw['Gx'].data_ptr() + 2 * l * B * self.dec.N4, self.dec.N4, B, self.dec.N4, self.E8,
+                      bias=self.dec.bias_ptr(src), out_bf16=True)
             self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
             # logits for this step: run the projection stack on rows [l*B, (l+1)*B) of the ext array (t+1 block)
             self._proj_rows(ws, src, l)
@@ -1395,8 +1438,8 @@ class Seq2SeqEngine:
             lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, wb['U'].data_ptr(), l * BW, BW, s.dec_embed, wb['e'].data_ptr(),
                               self.E8, C.byref(dr), st)
             self.gemm(wb['e'].data_ptr() + 2 * l * BW * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
-                      dw['Gx'].data_ptr() + 4 * l * BW * self.dec.N4, self.dec.N4, BW, self.dec.N4, self.E8,
-                      bias=self.dec.bias_ptr(src))
+                      dw['Gx'].data_ptr() + 2 * l * BW * self.dec.N4, self.dec.N4, BW, self.dec.N4, self.E8,
+                      bias=self.dec.bias_ptr(src), out_bf16=True)
             self.dec.fwd(dw, None, wb['dlens'], src, False, c0=wb['c0'], steps=(l, l + 1))
             self._proj_rows(wb, src, l)
             nxt = wb['U'].data_ptr() + 4 * (l + 1) * BW if l + 1 < L else None

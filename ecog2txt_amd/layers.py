@@ -233,7 +233,9 @@ class _Lstm:
         M, Mk = S * B, rk(S * B)
         nd, Hh = self.ndir, self.H
         ws = dict(S=S, B=B, M=M, Mk=Mk)
-        ws['Gx'] = _f32(M, self.N4, device=dev)
+        # input projections of all steps, bf16 (ABI 5; fp32 before: half the bytes for the GEMM to write and the recurrence to read);
+        # one slack row: the recurrences fetch a lane's 4 units as 32 B whatever H % 4 is
+        ws['Gx'] = _bf(M + 1, self.N4, device=dev)
         ws['Yext'] = _bf((S + 3) * B, self.ldy, device=dev)       # block 0 = initial state, S+1.. = zero slack
         ws['Ydrop'] = _bf(M, self.ldy, device=dev)
         if self.ldy > nd * self.H8:
@@ -282,7 +284,7 @@ class _Lstm:
     def fwd_gx(self, ws, x_ptr, src):
         """Input projection of all time steps (no recurrence in it: may run ahead on another stream)."""
         self.eng.gemm(x_ptr, self.in_ld, self.WxT.data_ptr(), self.in_ld, ws['Gx'].data_ptr(), self.N4, ws['M'], self.N4,
-                      self.in_ld, bias=self.bias_ptr(src), alg=(ws['M'], self.N4, self.D))
+                      self.in_ld, bias=self.bias_ptr(src), out_bf16=True, alg=(ws['M'], self.N4, self.D))
 
     def fwd(self, ws, x_ptr, lens, src, train, c0=None, steps=None, gx_done=False, after_gx=None):
         e = self.eng

@@ -251,8 +251,14 @@ class SequenceNetwork:
     def fit(self, subjects, _restore_epoch=None, train_vars_scope=None, reuse_vars_scope=None):
         """Train for self.N_epochs epochs; assess every assessment_epoch_interval epochs on the last subject's
         'training' and 'validation' partitions (EMA weights); checkpoint at the end."""
-        import torch
         eng = self._get_engine(subjects)
+        # the whole fit runs with the engine's own stream current (captured steps are replayed from it: engine.train_step),
+        # ordered behind the caller's stream and joined back into it
+        with eng.on_step_stream():
+            return self._fit(eng, subjects, _restore_epoch, train_vars_scope, reuse_vars_scope)
+
+    def _fit(self, eng, subjects, _restore_epoch, train_vars_scope, reuse_vars_scope):
+        import torch
         start = 0
         if _restore_epoch:
             self._restore(eng, _restore_epoch, reuse_vars_scope)

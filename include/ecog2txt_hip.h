@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 4
+#define E2T_ABI_VERSION 5
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -186,12 +186,12 @@ typedef struct e2t_lstm_desc {
     int rb_begin, rb_count;        /* restrict the launches to utterance blocks [rb_begin, rb_begin+rb_count) of 64 rows
                                       (rb_count 0 = all); disjoint ranges are independent and may run on different streams */
 } e2t_lstm_desc;
-/* Gx [S*B][ndir*H*4] fp32 (dir,unit,gate interleaved; bias folded in); WhF: e2t_pack_frag images
+/* Gx [S*B][ndir*H*4] bf16 (dir,unit,gate interleaved; bias folded in; ABI 5: bf16, was fp32 -- readable 32 B past the last row); WhF: e2t_pack_frag images
  * [ndir][4][UT][KB]; Yext bf16 [(S+3)*B][ldy] (time block t+1; block 0 = initial state, blocks S+1, S+2
  * all-zero slack that no kernel writes); Ydrop bf16 [S*B][ldy] or NULL; Cs / Gs: lane-native per-step saves,
  * S*ndir*ceil(B/16)*ceil(H/16)*64 float4 resp. x4 (layout in csrc/lstm.hip); c0 fp32 [B][ndir*H] or NULL.
  * Runs steps [step_begin, step_end). */
-int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
+int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
                      float* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
 /* Same result (bit for bit) as e2t_lstm_seq_fwd over steps [0,S) in ONE persistent launch: W_h stays in registers,
  * h is exchanged between CUs inside the launch (stamped values, bounded retries).  Applicable when H % 8 == 0 and the
@@ -199,7 +199,7 @@ int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const float* Gx, const void* WhF, v
  * * ndir for H <= 832; returns non-zero otherwise (use e2t_lstm_seq_fwd).  hx: bf16 exchange scratch [2][ndir][4*ceil(B/64)][ceil(H/32)][64][8], zero-filled once by the
  * caller and afterwards only touched by this entry point with the same S, B, H (zero it again after an error);
  * err: int32 [1], set to 1 if a wait timed out (results then invalid). */
-int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const float* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
+int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
                                 float* Gs, const int32_t* lens, const float* c0, void* hx, int32_t* err, int num_cus,
                                 void* stream);
 /* BPTT over all S steps (+ pseudo-step -1 when dh0/dc0 are given).  dG bf16 [(S+1)*B][lddg] out
@@ -232,7 +232,7 @@ int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* d
  * [ndir][4H/16][H/32][64][8].  hx: bf16 [2][ndir][4*ceil(B/64)][H/32][64][8]; flags: uint32 [ceil(B/64)*ndir][128]; both
  * zero-filled once by the caller and afterwards only touched by these entry points (zero them again after an error). */
 int e2t_lstm_big_ok(int H);
-int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const float* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs, float* Gs,
+int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const void* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs, float* Gs,
                          const int32_t* lens, const float* c0, void* hx, uint32_t* flags, int32_t* err, int num_cus, void* stream);
 /* BPTT counterpart (same gradients as e2t_lstm_seq_bwd to fp32 round-off: the K = 4H sum is split in 4 quarters); H in
  * {512, 768, 1024}; no gradient into an initial state (dh0/dc0: use the other entry points).

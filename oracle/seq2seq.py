@@ -398,7 +398,7 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False, counts=None
         for d, name in enumerate(('fw', 'bw')):
             Kx, Kh = _split_kernel(P['seq2seq/encoder_rnn_%d/%s/cell_0/kernel' % (l, name)], D)
             Wx, Wh = q(Kx), q(Kh)
-            Gx = inp @ Wx + P['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, name)]
+            Gx = q(inp @ Wx + P['seq2seq/encoder_rnn_%d/%s/cell_0/bias' % (l, name)])     # the device keeps the input projections in bf16
             Y, Yq, c = lstm_dir_fwd(Gx, lens_d, Wh, reverse=(d == 1), q=q, forget_bias=spec.forget_bias)
             c['Wx'] = Wx
             lay[name] = c
@@ -471,7 +471,7 @@ def forward(P, spec, batch, train=False, seed=0, emulate_bf16=False, counts=None
     e = q(e)
     Kx, Kh = _split_kernel(P['seq2seq/decoder_rnn/cell_0/kernel'], spec.dec_embed)
     Wx, Wh = q(Kx), q(Kh)
-    Gx = e @ Wx + P['seq2seq/decoder_rnn/cell_0/bias']
+    Gx = q(e @ Wx + P['seq2seq/decoder_rnn/cell_0/bias'])
     Yd, Ydq, dc_ = lstm_dir_fwd(Gx, dlens, Wh, reverse=False, q=q, forget_bias=spec.forget_bias,
                                 h0=h0, c0=c0)
     dc_['Wx'] = Wx
@@ -642,7 +642,7 @@ def greedy_decode(P, spec, batch, max_len=20, emulate_bf16=False):
     out = np.full((B, max_len), PAD_ID, np.int64)
     all_logits = []
     for l in range(max_len):
-        z = q(Emb[u]) @ Wx + bias + h @ Wh
+        z = q(q(Emb[u]) @ Wx + bias) + h @ Wh
         i = sigmoid(z[:, :H]); j = np.tanh(z[:, H:2 * H])
         f = sigmoid(z[:, 2 * H:3 * H] + spec.forget_bias); o = sigmoid(z[:, 3 * H:])
         c = f * c + i * j
@@ -690,7 +690,7 @@ def beam_decode(P, spec, batch, beam_width, max_len=20, temperature=1.0, emulate
     done = np.zeros((B, W), bool)
     toks = np.full((B, W, max_len), PAD_ID, np.int64)
     for l in range(max_len):
-        z = q(Emb[u]) @ Wx + bias + h @ Wh
+        z = q(q(Emb[u]) @ Wx + bias) + h @ Wh
         i = sigmoid(z[:, :H]); j = np.tanh(z[:, H:2 * H])
         f = sigmoid(z[:, 2 * H:3 * H] + spec.forget_bias); o = sigmoid(z[:, 3 * H:])
         cn = f * c + i * j

@@ -34,7 +34,7 @@ def relu_class(name):
     return 'encoder_embedding' in name or ('_projection_' in name)
 
 
-def check_grad(name, got, want, relu_outliers=1e-2):
+def check_grad(name, got, want, relu_outliers=1e-2, flip_outliers=1e-3):
     scale = np.abs(want).max() + 1e-12
     err = np.abs(got - want) / scale
     outliers = (err > GRAD_TOL).mean()
@@ -46,8 +46,9 @@ def check_grad(name, got, want, relu_outliers=1e-2):
         assert rel_l2 < 2e-2, (name, float(rel_l2))
     else:
         # recurrent kernels, embeddings, linear layers: at most 0.1 % of the entries beyond 5e-3 (1-ulp bf16 flips amplified
-        # through BPTT), none beyond 2e-2
-        assert outliers <= max(1e-3, 1.0 / err.size) and err.max() < 2e-2, (name, float(err.max()), float(outliers))
+        # through BPTT), none beyond 2e-2.  (flip_outliers: the share grows with the number of bf16 values rounded on the way --
+        # input projections, states, gate gradients: ~4e-4 of them lie within fp32 round-off of a rounding boundary)
+        assert outliers <= max(flip_outliers, 1.0 / err.size) and err.max() < 2e-2, (name, float(err.max()), float(outliers))
         assert rel_l2 < 1e-2, (name, float(rel_l2))
 
 
@@ -257,8 +258,9 @@ def test_train_steps_follow_oracle(name, use_graph):
         # Adam normalises every coordinate to ~lr, so compare against the step size
         err = np.abs(Pd[k] - Po[k])
         # (a coordinate whose gradient is within round-off of zero may take its first step -- of size lr whatever |g| -- in the
-        #  other direction: at most a handful of such coordinates, each off by no more than 2 lr)
-        assert (err > 3 * 5e-4 * 0.35).mean() < 2e-3 and err.max() < 2.1 * 5e-4, (k, float(err.max()), float((err > 3 * 5e-4 * 0.35).mean()))
+        #  other direction: at most a handful of such coordinates -- 5, or 0.2 % of a large tensor -- each off by no more than 2 lr)
+        nflip = int((err > 3 * 5e-4 * 0.35).sum())
+        assert nflip <= max(5, 2e-3 * err.size) and err.max() < 2.1 * 5e-4, (k, float(err.max()), nflip, err.size)
         assert np.abs(Ed[k] - state['ema'][k]).max() < 1e-4, k
     moved = max(np.abs(Pd[k] - P[k]).max() for k in P)
     assert moved > 5e-4
