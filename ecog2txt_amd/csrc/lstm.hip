@@ -47,7 +47,8 @@ extern __shared__ __attribute__((aligned(16))) uint4 lstm_smem[];
 //   => lane (frow, fq) owns utterance b = rt*16 + frow and the FOUR CONSECUTIVE units
 //      u0 .. u0+3, u0 = ut*16 + fq*4.
 // Saved per-cell state is "lane-native", indexed by PROCESSING STEP s (not by time):
-//   Gs[((((s*ndir + dir)*RT + rt)*UT + ut)*4 + r)*64 + lane]  float4 = (i, j, f, o) of unit u0 + r
+//   Gs[((((s*ndir + dir)*RT + rt)*UT + ut)*2 + rp)*64 + lane]  8 x bf16 = (i, j, f, o) of units u0 + 2*rp, u0 + 2*rp + 1 (ABI 5: bf16;
+//       the gates are what BPTT multiplies with -- rounded once, like the gate gradients it writes)
 //   Cs[((((s*ndir + dir)*RT + rt)*UT + ut)*2 + half)*64 + lane]  float2 = c of units u0+2*half, u0+2*half+1
 // so every save/restore is a fully coalesced 1-KiB wave transaction and needs no time index.
 //
@@ -97,6 +98,14 @@ __device__ __forceinline__ void nt_store_bf4(bf16_t* p, bf16_t a, bf16_t b, bf16
     unsigned long long v = (unsigned long long)a | ((unsigned long long)b << 16) | ((unsigned long long)c << 32) | ((unsigned long long)d << 48);
     __builtin_nontemporal_store(v, (unsigned long long*)p);
 }
+// gate saves: (i, j, f, o) of one unit as 4 x bf16 (hardware converter, round-to-nearest-even), and back
+__device__ __forceinline__ uint2 gates_pack(float gi, float gj, float gf, float go) { return make_uint2(f2bf_pk(gi, gj), f2bf_pk(gf, go)); }
+__device__ __forceinline__ float4 gates_unpack(unsigned ij, unsigned fo) {
+    return make_float4(__uint_as_float(ij << 16), __uint_as_float(ij & 0xFFFF0000u), __uint_as_float(fo << 16), __uint_as_float(fo & 0xFFFF0000u));
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store_u4(void* p, uint4 v) { __builtin_nontemporal_store(*(u32x4_t*)&v, (u32x4_t*)p); }
+__device__ __forceinline__ void nt_store_u2(void* p, uint2 v) { __builtin_nontemporal_store(*(unsigned long long*)&v, (unsigned long long*)p); }
 __device__ __forceinline__ float4 ld4(const float* p, bool vec, int n) {
     if (vec) return *(const float4*)p;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -231,7 +240,7 @@ struct LstmFwdArgs {
     bf16_t* Yext;           // [(S+3)*B][ldy]   time block tau = t+1; block 0 = initial h, S+1.. = zero slack
     bf16_t* Ydrop;          // [S*B][ldy] or null
     float* Cs;              // lane-native, see above
-    float* Gs;              // lane-native, see above
+    bf16_t* Gs;             // lane-native, see above (bf16)
     const int* lens;        // [B]
     const float* c0;        // [B][ndir*H] or null
     int S, B, H, H8, ndir, ldy, UT, KB, step, rb_begin, rb_count;
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
             const float go = fsigmoid(z[3][rr] + gx.w);
             cv[rr] = fmaf(gf, cp[rr], gi * gj);           // explicit: identical rounding in the step and persistent kernels
             hv[rr] = go * ftanh(cv[rr]);
-            if (rr < nu) nt_store_f4(p.Gs + ((tile * 4 + 2 * khalf + rr) * 64 + lane) * 4, gi, gj, gf, go);
+            if (rr < nu) nt_store_u2(p.Gs + (((tile * 2 + khalf) * 64 + lane) * 2 + rr) * 4, gates_pack(gi, gj, gf, go));
             hd[rr] = hv[rr] * (khalf ? dsc4[2 + rr] : dsc4[rr]);
         }
         STAMP(6);
@@ -611,7 +620,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                 const size_t m = (size_t)t * B + b;
                 const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi[r], gj[r], gf[r], go[r]);
+                for (int rp = 0; rp < 2; ++rp) {
+                    const uint2 a = gates_pack(gi[2 * rp], gj[2 * rp], gf[2 * rp], go[2 * rp]), c = gates_pack(gi[2 * rp + 1], gj[2 * rp + 1], gf[2 * rp + 1], go[2 * rp + 1]);
+                    nt_store_u4(p.Gs + ((tile * 2 + rp) * 64 + lane) * 8, make_uint4(a.x, a.y, c.x, c.y));
+                }
                 ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
                 ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
                 if (p.Ydrop) {
@@ -862,7 +874,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
                 const size_t m = (size_t)t * B + b;
                 const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nt_store_f4(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, gi[r], gj[r], gf[r], go[r]);
+                for (int rp = 0; rp < 2; ++rp) {
+                    const uint2 a = gates_pack(gi[2 * rp], gj[2 * rp], gf[2 * rp], go[2 * rp]), c = gates_pack(gi[2 * rp + 1], gj[2 * rp + 1], gf[2 * rp + 1], go[2 * rp + 1]);
+                    nt_store_u4(p.Gs + ((tile * 2 + rp) * 64 + lane) * 8, make_uint4(a.x, a.y, c.x, c.y));
+                }
                 ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
                 ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
                 if (p.Ydrop) {
@@ -890,7 +905,7 @@ struct LstmBwdArgs {
     const bf16_t* WhB;      // [ndir][UT][KB4][64][8]  fragment-packed W_h^T operand (K = 4H gate columns)
     bf16_t* dG;             // [(S+1)*B][lddg]  (dir, unit, gate) interleaved, bf16, time-major rows; block S = zero slack
     const float* dY;        // [S*B][lddy] gradient wrt the (dropped) layer output, or null
-    const float* Gs; const float* Cs;     // lane-native saves of the forward pass
+    const bf16_t* Gs; const float* Cs;    // lane-native saves of the forward pass (gates bf16, cell state fp32)
     const int* lens;
     const float* c0;        // [B][ndir*H] or null
     const float* dh_final;  // [B][ndir*H] or null: gradient wrt final state h
@@ -950,8 +965,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     const size_t m = active ? ((size_t)t * B + b) : 0;
     if (active && nu > 0) {
         const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) g4[rr] = ((const float4*)p.Gs)[(tile * 4 + 2 * khalf + rr) * 64 + lane];
+        { const uint4 graw = ((const uint4*)p.Gs)[(tile * 2 + khalf) * 64 + lane]; g4[0] = gates_unpack(graw.x, graw.y); g4[1] = gates_unpack(graw.z, graw.w); }
         c_t = ((const float2*)p.Cs)[(tile * 2 + khalf) * 64 + lane];
         if (s > 0) cprev = ((const float2*)p.Cs)[(native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 2 + khalf) * 64 + lane];
         else if (p.c0) cprev = ld2(p.c0 + su);
@@ -1125,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         const int rtp = min(rt, RT - 1);
         const size_t tile = native_tile(s, dir, rtp, ut, p.ndir, RT, p.UT);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dma16_to_lds(p.Gs + ((tile * 4 + r) * 64 + lane) * 4, dst + r * 1024);
+        for (int rp = 0; rp < 2; ++rp) dma16_to_lds(p.Gs + ((tile * 2 + rp) * 64 + lane) * 8, dst + rp * 1024);
         if (s > 0) dma16_to_lds(p.Cs + native_tile(s - 1, dir, rtp, ut, p.ndir, RT, p.UT) * 256 + lane * 4, dst + 4 * 1024);
         if (p.dY) {
             const int t = (s < len) ? (dir ? (len - 1 - s) : s) : 0;
@@ -1178,8 +1192,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint4 raw = src[r * 64 + lane];
-                const float gi = __uint_as_float(raw.x), gj = __uint_as_float(raw.y), gf = __uint_as_float(raw.z), go = __uint_as_float(raw.w);
+                const uint4 raw = src[(r >> 1) * 64 + lane];
+                const float4 g4 = (r & 1) ? gates_unpack(raw.z, raw.w) : gates_unpack(raw.x, raw.y);
+                const float gi = g4.x, gj = g4.y, gf = g4.z, go = g4.w;
                 const float tc = ftanh(ct[r]);
                 f_add[r] = dhf[r] + dy[r] * dsc4[r];
                 k1[r] = go * (1.f - tc * tc);             // d c_t     += dh  * k1
@@ -1324,8 +1339,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
                     // like a timed-out wait does (err[0]: the optimiser kernels skip their update, check_sync() raises)
                     unsigned nonfinite = 0u;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) nonfinite |= (unsigned)((x[i] & 0x7F80u) == 0x7F80u) | (unsigned)((x[i] & 0x7F800000u) == 0x7F800000u);
-                    if (__any(nonfinite != 0u)) { if (lane == 0) atomicCAS((int*)pa.err, 0, 7); }
+                    for (int i = 0; i < 8; ++i) nonfinite |= ((x[i] & 0x7F807F80u) + 0x00800080u) & 0x80008000u;     // a half with all exponent bits set carries into its sign bit
+                    if (__any(nonfinite != 0u)) { if (lane == 0) __hip_atomic_fetch_or((unsigned*)pa.err, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (1 | 7 = 7: reported as non-finite)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[i] = (x[i] | (((x[i] & 0x40004000u) >> 14) * 0x3FFFu)) & 0xBFFFBFFFu;
                     if (lane == 0) atomicAdd(pa.err + 8, 1);     // visible to the host: recurrent gate gradients were clipped
@@ -1367,7 +1382,7 @@ static int set_big_lds(const void* fn) {
 }
 
 extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext,
-                                void* Ydrop, float* Cs, float* Gs, const int32_t* lens, const float* c0,
+                                void* Ydrop, float* Cs, void* Gs, const int32_t* lens, const float* c0,
                                 int step_begin, int step_end, void* stream) {
     E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
@@ -1377,7 +1392,7 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const vo
     if (attr_rc) return attr_rc;
     LstmFwdArgs p{};
     p.Gx = (const bf16_t*)Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
-    p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
+    p.Cs = Cs; p.Gs = (bf16_t*)Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
     p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
@@ -1399,7 +1414,7 @@ extern "C" int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const vo
 }
 
 extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext, void* Ydrop,
-                                           float* Cs, float* Gs, const int32_t* lens, const float* c0, void* hx,
+                                           float* Cs, void* Gs, const int32_t* lens, const float* c0, void* hx,
                                            int32_t* err, int num_cus, void* stream) {
     E2T_CHECK_ARG(d && Gx && WhF && Yext && Cs && Gs && lens && hx && err);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
@@ -1407,7 +1422,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* G
     LstmPersistArgs pa{};
     LstmFwdArgs& p = pa.a;
     p.Gx = (const bf16_t*)Gx; p.WhF = (const bf16_t*)WhF; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop;
-    p.Cs = Cs; p.Gs = Gs; p.lens = lens; p.c0 = c0;
+    p.Cs = Cs; p.Gs = (bf16_t*)Gs; p.lens = lens; p.c0 = c0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir; p.ldy = d->ldy;
     p.UT = (d->H + 15) / 16; p.KB = (p.H8 + 31) / 32;
     p.forget_bias = d->forget_bias;
@@ -1459,7 +1474,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* G
 }
 
 extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY,
-                                int lddy, const float* Gs, const float* Cs, const int32_t* lens, const float* c0,
+                                int lddy, const void* Gs, const float* Cs, const int32_t* lens, const float* c0,
                                 const float* dh_final, const float* dc_final, float* dc_carry, float* dh0,
                                 float* dc0, void* stream) {
     E2T_CHECK_ARG(d && WhB && dG && Gs && Cs && lens && dc_carry);
@@ -1469,7 +1484,7 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     static const int attr_rc = set_big_lds((const void*)k_lstm_step_bwd);
     if (attr_rc) return attr_rc;
     LstmBwdArgs p{};
-    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
+    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = (const bf16_t*)Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
     p.dh_final = dh_final; p.dc_final = dc_final; p.dc_carry = dc_carry; p.dh0 = dh0; p.dc0 = dc0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir;
     p.lddg = lddg; p.lddy = lddy;
@@ -1491,7 +1506,7 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
 }
 
 extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY,
-                                           int lddy, const float* Gs, const float* Cs, const int32_t* lens,
+                                           int lddy, const void* Gs, const float* Cs, const int32_t* lens,
                                            const float* c0, const float* dh_final, const float* dc_final, float* dh0,
                                            float* dc0, void* dgx, uint32_t* flags, int32_t* err, int num_cus, void* stream) {
     E2T_CHECK_ARG(d && WhB && dG && Gs && Cs && lens && dgx && flags && err);
@@ -1500,7 +1515,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     E2T_CHECK_ARG((dh0 == nullptr) == (dc0 == nullptr));
     LstmBwdPersistArgs pa{};
     LstmBwdArgs& p = pa.a;
-    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
+    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = (const bf16_t*)Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
     p.dh_final = dh_final; p.dc_final = dc_final; p.dh0 = dh0; p.dc0 = dc0;
     p.S = d->S; p.B = d->B; p.H = d->H; p.H8 = (d->H + 7) / 8 * 8; p.ndir = d->ndir;
     p.lddg = lddg; p.lddy = lddy;

@@ -78,7 +78,7 @@ struct BigFwdArgs {
     const bf16_t* WhG;      // [ndir][4H/16 column tiles][KB][64][8]: MFMA fragment image of Bn[n = gate column][k] (e2t_pack_frag)
     bf16_t* Yext;           // [(S+3)*B][ldy]
     bf16_t* Ydrop;          // [S*B][ldy] or null
-    float* Cs; float* Gs;   // lane-native saves (layout: lstm.hip)
+    float* Cs; bf16_t* Gs;  // lane-native saves (layout: lstm.hip; gates bf16)
     const int* lens;
     const float* c0;
     bf16_t* hx;             // [2 step parities][ndir][4*RB row tiles][KB][64 lanes][8]  h exchange, MFMA operand order
@@ -329,7 +329,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_big(BigFwdArgs p) {
                     // lane-native layout of the step kernels: unit tile ug*2 + wave/2, lane group (wave&1)*2 + a, register fq
                     const size_t tile = native_tile(s, dir, rb * 4 + rt, ug * 2 + (wave >> 1), p.ndir, RT, p.UT);
                     const int ln = ((wave & 1) * 2 + a) * 16 + frow;
-                    __builtin_nontemporal_store((f32x4){gi[rt][a], gj[rt][a], gf[rt][a], go[rt][a]}, (f32x4*)(p.Gs + ((tile * 4 + fq) * 64 + ln) * 4));
+                    {   // (i, j, f, o) of unit register fq as 4 x bf16: half (fq & 1) of the 16-B slot of unit pair fq >> 1 (layout: lstm.hip)
+                        const unsigned long long g = (unsigned long long)f2bf_pk(gi[rt][a], gj[rt][a]) | ((unsigned long long)f2bf_pk(gf[rt][a], go[rt][a]) << 32);
+                        __builtin_nontemporal_store(g, (unsigned long long*)(p.Gs + (((tile * 2 + (fq >> 1)) * 64 + ln) * 2 + (fq & 1)) * 4));
+                    }
                     p.Cs[((tile * 2 + (fq >> 1)) * 64 + ln) * 2 + (fq & 1)] = cst[rt][a];
                 }
             }
@@ -367,13 +370,13 @@ static void step_fwd_halves(int KB, unsigned char (&kbl)[2][16], unsigned char (
 extern "C" int e2t_lstm_big_ok(int H) { return (H % 64 == 0 && H >= 448 && H <= 1024) ? 1 : 0; }
 
 extern "C" int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const void* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs,
-                                    float* Gs, const int32_t* lens, const float* c0, void* hx, uint32_t* flags, int32_t* err,
+                                    void* Gs, const int32_t* lens, const float* c0, void* hx, uint32_t* flags, int32_t* err,
                                     int num_cus, void* stream) {
     E2T_CHECK_ARG(d && Gx && WhG && Yext && Cs && Gs && lens && hx && flags && err);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(e2t_lstm_big_ok(d->H) && d->ldy % 8 == 0 && d->ldy >= d->ndir * d->H);
     BigFwdArgs p{};
-    p.Gx = (const bf16_t*)Gx; p.WhG = (const bf16_t*)WhG; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop; p.Cs = Cs; p.Gs = Gs;
+    p.Gx = (const bf16_t*)Gx; p.WhG = (const bf16_t*)WhG; p.Yext = (bf16_t*)Yext; p.Ydrop = (bf16_t*)Ydrop; p.Cs = Cs; p.Gs = (bf16_t*)Gs;
     p.lens = lens; p.c0 = c0; p.hx = (bf16_t*)hx; p.flags = flags; p.err = err;
     p.S = d->S; p.B = d->B; p.H = d->H; p.ndir = d->ndir; p.ldy = d->ldy; p.UT = d->H / 16; p.KB = d->H / 32;
     p.forget_bias = d->forget_bias;
@@ -414,7 +417,7 @@ struct BigBwdArgs {
     const bf16_t* WhB;      // [ndir][UT][KB4][64][8]  fragment image of W_h^T (rows = units, K = 4H gate columns)
     bf16_t* dG;             // [(S+1)*B][lddg] row-major, (dir, unit, gate) interleaved
     const float* dY;        // [S*B][lddy] or null
-    const float* Gs; const float* Cs;
+    const bf16_t* Gs; const float* Cs;
     const int* lens;
     const float* c0; const float* dh_final; const float* dc_final;
     bf16_t* dgx;            // [2 step parities][ndir][4*RB row tiles][KB4][64][8]  dG exchange, MFMA operand order
@@ -504,7 +507,11 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_big(BigBwdArgs p) {
             for (int r = 0; r < 4; ++r) { g4[u][r] = make_float4(0.f, 0.f, 0.f, 0.f); cp[u][r] = 0.f; dy[u][r] = 0.f; dhf[u][r] = 0.f; }
             if (own && active) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g4[u][r] = ((const float4*)p.Gs)[(tile * 4 + r) * 64 + lane];
+                for (int rp = 0; rp < 2; ++rp) {
+                    const uint4 raw = ((const uint4*)p.Gs)[(tile * 2 + rp) * 64 + lane];
+                    g4[u][2 * rp] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xFFFF0000u), __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xFFFF0000u));
+                    g4[u][2 * rp + 1] = make_float4(__uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xFFFF0000u), __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xFFFF0000u));
+                }
                 if (p.dY) { const float4 v = *(const float4*)(p.dY + m * p.lddy + dir * H + ut * 16 + fq * 4); dy[u][0] = v.x; dy[u][1] = v.y; dy[u][2] = v.z; dy[u][3] = v.w; }
                 if (s == len - 1) {
                     if (p.dh_final) { const float4 v = *(const float4*)(p.dh_final + su); dhf[u][0] = v.x; dhf[u][1] = v.y; dhf[u][2] = v.z; dhf[u][3] = v.w; }
@@ -661,13 +668,13 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_big(BigBwdArgs p) {
 }
 
 extern "C" int e2t_lstm_seq_bwd_big(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
-                                    const float* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
+                                    const void* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
                                     const float* dc_final, void* dgx, uint32_t* flags, int32_t* err, int num_cus, void* stream) {
     E2T_CHECK_ARG(d && WhB && dG && Gs && Cs && lens && dgx && flags && err);
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(e2t_lstm_big_ok(d->H) && d->H % 128 == 0 && lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
     BigBwdArgs p{};
-    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
+    p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = (const bf16_t*)Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
     p.dh_final = dh_final; p.dc_final = dc_final; p.dgx = (bf16_t*)dgx; p.flags = flags; p.err = err;
     p.S = d->S; p.B = d->B; p.H = d->H; p.ndir = d->ndir; p.lddg = lddg; p.lddy = lddy; p.UT = d->H / 16; p.KB4 = d->H / 8;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;

@@ -242,7 +242,7 @@ class _Lstm:
             ws['Ydrop'][:, nd * self.H8] = 1.0        # ones column for the dW_x of the layer above (no kernel writes it)
         RT, UT = ceil_div(B, 16), ceil_div(Hh, 16)
         ws['Cs'] = _f32(S, nd, RT, UT, 2, 64, 2, device=dev)       # lane-native per-step saves (lstm.hip)
-        ws['Gs'] = _f32(S, nd, RT, UT, 4, 64, 4, device=dev)
+        ws['Gs'] = _bf(S, nd, RT, UT, 2, 64, 8, device=dev)         # gates (i, j, f, o) of two units per 16-B slot, bf16
         ws['dG'] = _bf(M + B, rk(self.N4), device=dev)              # block S = zero slack (rows without successor)
         ws['dGT'] = _bf(self.N4, Mk, device=dev)
         ws['YT'] = _bf(nd, Hh, Mk, device=dev)

@@ -188,11 +188,11 @@ typedef struct e2t_lstm_desc {
 } e2t_lstm_desc;
 /* Gx [S*B][ndir*H*4] bf16 (dir,unit,gate interleaved; bias folded in; ABI 5: bf16, was fp32 -- readable 32 B past the last row); WhF: e2t_pack_frag images
  * [ndir][4][UT][KB]; Yext bf16 [(S+3)*B][ldy] (time block t+1; block 0 = initial state, blocks S+1, S+2
- * all-zero slack that no kernel writes); Ydrop bf16 [S*B][ldy] or NULL; Cs / Gs: lane-native per-step saves,
+ * all-zero slack that no kernel writes); Ydrop bf16 [S*B][ldy] or NULL; Cs (fp32) / Gs (bf16 since ABI 5: (i, j, f, o) per cell, 8 B): lane-native per-step saves,
  * S*ndir*ceil(B/16)*ceil(H/16)*64 float4 resp. x4 (layout in csrc/lstm.hip); c0 fp32 [B][ndir*H] or NULL.
  * Runs steps [step_begin, step_end). */
 int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
-                     float* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
+                     void* Gs, const int32_t* lens, const float* c0, int step_begin, int step_end, void* stream);
 /* Same result (bit for bit) as e2t_lstm_seq_fwd over steps [0,S) in ONE persistent launch: W_h stays in registers,
  * h is exchanged between CUs inside the launch (stamped values, bounded retries).  Applicable when H % 8 == 0 and the
  * layer's workgroups fit the CUs one-to-one: ceil(H/16) * ceil(B/64) * ndir of them for H <= 416, ceil(H/32) * ceil(B/32)
@@ -200,12 +200,12 @@ int e2t_lstm_seq_fwd(const e2t_lstm_desc* d, const void* Gx, const void* WhF, vo
  * caller and afterwards only touched by this entry point with the same S, B, H (zero it again after an error);
  * err: int32 [1], set to 1 if a wait timed out (results then invalid). */
 int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* Gx, const void* WhF, void* Yext, void* Ydrop, float* Cs,
-                                float* Gs, const int32_t* lens, const float* c0, void* hx, int32_t* err, int num_cus,
+                                void* Gs, const int32_t* lens, const float* c0, void* hx, int32_t* err, int num_cus,
                                 void* stream);
 /* BPTT over all S steps (+ pseudo-step -1 when dh0/dc0 are given).  dG bf16 [(S+1)*B][lddg] out
  * (block S is all-zero slack that no kernel writes). */
 int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
-                     const float* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
+                     const void* Gs, const float* Cs, const int32_t* lens, const float* c0, const float* dh_final,
                      const float* dc_final, float* dc_carry, float* dh0, float* dc0, void* stream);
 /* Same gradients as e2t_lstm_seq_bwd (to fp32 round-off: the K = 4H sum is split in 4 quarters instead of 2 halves) in
  * ONE persistent launch, incl. the pseudo-step -1 when dh0/dc0 are given.  Applicable when H % 8 == 0 and the workgroups
@@ -221,7 +221,7 @@ int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg
  * saturating range of the exchange copy (|x| >= 2): 0 in healthy training, a warning sign for the loss scales otherwise. */
 int e2t_bwd_persist_kq(int H);
 int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy,
-                                const float* Gs, const float* Cs, const int32_t* lens, const float* c0,
+                                const void* Gs, const float* Cs, const int32_t* lens, const float* c0,
                                 const float* dh_final, const float* dc_final, float* dh0, float* dc0, void* dgx,
                                 uint32_t* flags, int32_t* err, int num_cus, void* stream);
 /* Large hidden sizes (config 4: H = 1024): weight-stationary persistent recurrences in which the four waves of a workgroup
@@ -232,12 +232,12 @@ int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* WhB, void* d
  * [ndir][4H/16][H/32][64][8].  hx: bf16 [2][ndir][4*ceil(B/64)][H/32][64][8]; flags: uint32 [ceil(B/64)*ndir][128]; both
  * zero-filled once by the caller and afterwards only touched by these entry points (zero them again after an error). */
 int e2t_lstm_big_ok(int H);
-int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const void* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs, float* Gs,
+int e2t_lstm_seq_fwd_big(const e2t_lstm_desc* d, const void* Gx, const void* WhG, void* Yext, void* Ydrop, float* Cs, void* Gs,
                          const int32_t* lens, const float* c0, void* hx, uint32_t* flags, int32_t* err, int num_cus, void* stream);
 /* BPTT counterpart (same gradients as e2t_lstm_seq_bwd to fp32 round-off: the K = 4H sum is split in 4 quarters); H in
  * {512, 768, 1024}; no gradient into an initial state (dh0/dc0: use the other entry points).
  * dgx: bf16 [2][ndir][4*ceil(B/64)][4H/32][64][8]; flags as for the forward, a separate array. */
-int e2t_lstm_seq_bwd_big(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy, const float* Gs,
+int e2t_lstm_seq_bwd_big(const e2t_lstm_desc* d, const void* WhB, void* dG, int lddg, const float* dY, int lddy, const void* Gs,
                          const float* Cs, const int32_t* lens, const float* c0, const float* dh_final, const float* dc_final,
                          void* dgx, uint32_t* flags, int32_t* err, int num_cus, void* stream);
 /* encoder final state -> decoder initial state (App. D2) */

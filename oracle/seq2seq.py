@@ -223,7 +223,7 @@ def lstm_dir_fwd(Gx, lens, Wh, reverse, q, forget_bias, h0=None, c0=None):
         Y[ta, ra] = hn[act]
         Yq[ta, ra] = q(hn)[act]
         Cs[ta, ra] = cn[act]
-        Gs[ta, ra] = np.stack([i, j, f, o], 1)[act]
+        Gs[ta, ra] = q(np.stack([i, j, f, o], 1))[act]      # saved for BPTT in bf16 on the device (the forward pass uses them unrounded)
         c = np.where(a, cn, c)
         h = np.where(a, q(hn), h)
     return Y, Yq, dict(Cs=Cs, Gs=Gs, lens=lens, reverse=reverse, Wh=Wh, h0=h0, c0=c0,

@@ -230,7 +230,10 @@ def test_multi_subject_round_robin_follows_oracle():
     assert int(eng.sync_err[0].item()) == 0
     Pd, Ed = eng.store.export_tf('p'), eng.store.export_tf('ema')
     for k in Po:
-        assert np.abs(Pd[k] - Po[k]).max() < 6 * 5e-4 * 0.35, k          # six Adam steps of ~lr each
+        # six Adam steps of ~lr each; a coordinate whose gradient is within round-off of zero may take a step -- of size lr whatever
+        # |g| -- in the other direction (a handful of coordinates, twice each at most)
+        err = np.abs(Pd[k] - Po[k])
+        assert int((err > 6 * 5e-4 * 0.35).sum()) <= max(5, 2e-3 * err.size) and err.max() < 4 * 5e-4, (k, float(err.max()))
         assert np.abs(Ed[k] - state['ema'][k]).max() < 2e-4, k
     # after subject 400's first step only ITS front-end (and the shared body) had moved
     c401 = O.conv_name(ospec, 401) + '/weights'
