@@ -1234,6 +1234,20 @@ class Seq2SeqEngine:
                                 early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
                         lo = hi
                     early_end = lo
+                    if len(early) > 1 and os.environ.get('E2T_EARLY_MERGE', '1') != '0':
+                        # ONE early update, behind the LAST side stage: the optimiser and re-pack kernels are HBM-bound and
+                        # pair well with the MFMA-bound weight gradients of the bottom layer in the step's tail; issued
+                        # earlier they sat between the side stream's GEMM launches and pushed the middle layer's weight
+                        # gradients into that tail, where two GEMM launches then competed (measured: see DESIGN 5.00)
+                        if self.early_pack:
+                            merged = []
+                            for x, y in sorted(r for er in early_sets for r in er):
+                                if merged and merged[-1][1] == x:
+                                    merged[-1] = (merged[-1][0], y)
+                                else:
+                                    merged.append((x, y))
+                            early_sets = [merged]
+                            early = {nl: (lambda er=merged: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))}
                     if not early:
                         early, early_end = None, 0
                 g1 = torch.cuda.CUDAGraph()
