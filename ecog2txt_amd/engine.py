@@ -189,8 +189,10 @@ class Seq2SeqEngine:
             ep.row_lens, ep.rows_per_step = row_lens
             ep.row_group = row_group
         ep.flags = flags
-        if self._group is not None and tn and splitk:
-            # inside `with self.gemm_group():` -- the K-major weight-gradient products of a stage leave in ONE launch
+        if self._group is not None and tn and splitk and self._plan_tile(tn, M, N, K, ep) != 256:
+            # inside `with self.gemm_group():` -- the K-major weight-gradient products of a stage leave in ONE launch.  (A
+            # product large enough for the 256 x 256 instance -- H = 1024: 2049 x 8192 x 8704 -- keeps its own launch: the
+            # grouped kernel works on 128 x 128 tiles, half the flops per staged byte; cfg4 9.49 -> 9.19 ms.)
             self._group.append((A, lda, B, ldb, Cp, ldc, M, N, K, ep, alg or (M, N, K), batch[0] if batch is not None else 1))
             return
         if self._gemm_log is not None:
@@ -203,6 +205,11 @@ class Seq2SeqEngine:
                                        in_bytes=2 * (am * ak + an * ak) * nb, side=self._on_side,
                                        call=(A, lda, B, ldb, Cp, ldc, M, N, K), ep=ep, tn=tn))
         (lib.e2t_gemm_tn_bf16 if tn else lib.e2t_gemm_nt_bf16)(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
+
+    def _plan_tile(self, tn, M, N, K, ep):
+        tile, splits = C.c_int(0), C.c_int(0)
+        lib.e2t_gemm_plan(int(tn), M, N, K, C.byref(ep), C.byref(tile), C.byref(splits))
+        return tile.value
 
     def gemm_replay(self, rec):
         """Re-issue a logged launch (same operands, same epilogue) on the current stream."""
