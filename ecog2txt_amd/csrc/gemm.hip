@@ -1137,16 +1137,19 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     } while (0)
     // E2T_GEMM_DBG=1|2|3 selects the timing-only forms of the 128 x 128 instances (scripts/gemm_loop_probe.py)
     static const int dbg = e2t_dbg_int("E2T_GEMM_DBG", 0);
+    (void)dbg;
+#ifdef E2T_DEBUG
+    // (the timing-only instances exist in the diagnostics build only: the product library carries no kernel it never launches)
     if (tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 1);
     else if (tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 2);
     else if (tn && !big && dbg == 3) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 3);
     else if (!tn && !big && dbg == 1) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 1);
     else if (!tn && !big && dbg == 2) E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 2);
-#ifdef E2T_DEBUG
     else if (big && !tn && dbg == 4) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 4);     // everything but the stores of the epilogue
     else if (big && !tn && dbg == 2) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 2);     // loads, barriers and the epilogue only
+    else
 #endif
-    else if (big && tn) E2T_GEMM_GO(256, 256, 2, 4, false, true, 64, 2, 0);
+    if (big && tn) E2T_GEMM_GO(256, 256, 2, 4, false, true, 64, 2, 0);
     else if (tn) E2T_GEMM_GO(128, 128, 2, 2, false, true, 64, 2, 0);
     else if (big) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 0);
     else E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 0);
