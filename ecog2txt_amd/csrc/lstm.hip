@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             if (active) cst[r] = cv;
         }
         unsigned long long hb = 0ull;
-        if (active) hb = (unsigned long long)f2bf(hv[0]) | ((unsigned long long)f2bf(hv[1]) << 16) | ((unsigned long long)f2bf(hv[2]) << 32) | ((unsigned long long)f2bf(hv[3]) << 48);
+        if (active) hb = (unsigned long long)f2bf_pk(hv[0], hv[1]) | ((unsigned long long)f2bf_pk(hv[2], hv[3]) << 32);      // hardware converter: same bits as f2bf for every non-NaN
         if (own && s + 1 < S) {
             // write-through store into the exchange buffer: unit u0 sits in k-block ut/2, k-group (ut&1)*2 + fq/2,
             // half (fq&1) of the 16-B lane slot.  EVERY owned slot is rewritten EVERY step (padded positions: zeros),
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
             if (active) cst[r] = cv;
         }
         unsigned long long hb = 0ull;
-        if (active) hb = (unsigned long long)f2bf(hv[0]) | ((unsigned long long)f2bf(hv[1]) << 16) | ((unsigned long long)f2bf(hv[2]) << 32) | ((unsigned long long)f2bf(hv[3]) << 48);
+        if (active) hb = (unsigned long long)f2bf_pk(hv[0], hv[1]) | ((unsigned long long)f2bf_pk(hv[2], hv[3]) << 32);      // hardware converter: same bits as f2bf for every non-NaN
         if (own && s + 1 < S) {
             const unsigned long long stamp = ((((s >> 1) & 1) ^ (s & 1 ? base[1] : base[0])) != 0) ? 0x4000400040004000ull : 0ull;
             __hip_atomic_store((unsigned long long*)(pa.hx + (s & 1) * hx_buf + hx_slot), hb | stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1306,19 +1306,17 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         // ---- cell backward for (utterance b, units u0..u0+3): the part that needs dh_rec ----
         uint4 og0 = make_uint4(0u, 0u, 0u, 0u), og1 = make_uint4(0u, 0u, 0u, 0u);      // (i,j,f,o) x units 0,1 / units 2,3
         if (own && active) {
-            bf16_t og[16];
+            unsigned ogp[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dh = rec[r] + f_add[r];
                 const float dct = fmaf(dh, k1[r], dcc[r]);
-                og[r * 4 + 0] = f2bf(dct * k3[r]);
-                og[r * 4 + 1] = f2bf(dct * k4[r]);
-                og[r * 4 + 2] = f2bf(dct * k5[r]);
-                og[r * 4 + 3] = f2bf(dh * k2[r]);
+                ogp[r * 2 + 0] = f2bf_pk(dct * k3[r], dct * k4[r]);          // hardware converter: same bits as f2bf for every non-NaN
+                ogp[r * 2 + 1] = f2bf_pk(dct * k5[r], dh * k2[r]);
                 dcc[r] = dct * k6[r];
             }
-            og0 = make_uint4(og[0] | ((unsigned)og[1] << 16), og[2] | ((unsigned)og[3] << 16), og[4] | ((unsigned)og[5] << 16), og[6] | ((unsigned)og[7] << 16));
-            og1 = make_uint4(og[8] | ((unsigned)og[9] << 16), og[10] | ((unsigned)og[11] << 16), og[12] | ((unsigned)og[13] << 16), og[14] | ((unsigned)og[15] << 16));
+            og0 = make_uint4(ogp[0], ogp[1], ogp[2], ogp[3]);
+            og1 = make_uint4(ogp[4], ogp[5], ogp[6], ogp[7]);
         }
         // nothing of this step is ever waited for from here on: the stores below are fire-and-forget, and the operands the
         // side work reads were fetched two steps ago
