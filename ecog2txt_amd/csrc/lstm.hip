@@ -918,20 +918,26 @@ struct LstmBwdArgs {
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
 };
 
+// NU = unit tiles (of 16 units) per workgroup.  1: the general form.  4: large hidden sizes (H % 64 == 0, the H_d = 2048 decoder of
+// config 4): K = 4H makes the dG rows of a row block (64 x 4H bf16 = 1 MiB at H = 2048) the bulk of what a workgroup pulls through
+// LDS, and with 16 units per workgroup every row block is pulled by H/16 workgroups -- 640 MB per step at H = 2048, L2-bandwidth
+// bound (63 us per step); 64 units per workgroup amortise the rows over four times the weights.
+template <int NU>
 __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int RB = p.rb_count, RT = (p.B + 15) >> 4;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int ut = (slot / (RB * p.ndir)) * 8 + xcd;          // same XCD-aware map as the forward kernel
-    if (ut >= p.UT) return;
+    const int utg = (slot / (RB * p.ndir)) * 8 + xcd;         // same XCD-aware map as the forward kernel (over groups of NU unit tiles)
+    if (utg * NU >= p.UT) return;
+    const int ut0 = utg * NU;
     const int rem = slot % (RB * p.ndir);
     const int rb = p.rb_begin + rem % RB, dir = rem / RB;
     const int s = p.step, B = p.B, H = p.H, KB = p.KB4;
     const int frow = lane & 15, fq = lane >> 4;
     const int K4 = 4 * H;
     const int NH = p.ndir * H;
-    const StepGeom G = step_geom(KB, 1, 256);
+    const StepGeom G = step_geom(KB, NU, NU * 256);
 
     const int fb = (rb * 4 + (wave >> 1)) * 16 + (wave & 1) * 8 + (lane >> 3);       // row this lane fetches for
     const int flen = (fb < B) ? p.lens[fb] : 0;
@@ -946,100 +952,113 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     size_t trow = (size_t)p.S * B;
     if (fb < B && s + 1 < flen) trow = (size_t)(dir ? (flen - 2 - s) : (s + 1)) * B + fb;
     const bf16_t* srow = p.dG + trow * p.lddg + (size_t)dir * K4;
-    const uint4* wsrc = (const uint4*)p.WhB + ((size_t)dir * p.UT + ut) * KB * 64;
-    issue_chunk<1>(wsrc, 0, KB, srow, 0, lstm_smem, G, wave, lane);
-    if (G.nch > 1) issue_chunk<1>(wsrc, 0, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
+    const uint4* wsrc = (const uint4*)p.WhB + ((size_t)dir * p.UT + ut0) * KB * 64;
+    const size_t wts = (size_t)KB * 64;                       // the NU unit tiles' images follow each other
+    issue_chunk<NU>(wsrc, wts, KB, srow, 0, lstm_smem, G, wave, lane);
+    if (G.nch > 1) issue_chunk<NU>(wsrc, wts, KB, srow, 1, lstm_smem + G.bufsz, G, wave, lane);
 
     // ---- epilogue operands (lane-native, coalesced), requested in the same round trip ----------
     const int khalf = wave >> 2;
     const bool active = s >= 0 && s < len;
     const int t = dir ? (len - 1 - s) : s;
-    const int u0 = ut * 16 + fq * 4 + 2 * khalf;             // first of this lane's 2 units
-    const int nu = min(2, H - u0);
-    const size_t su = (size_t)b * NH + dir * H + u0;          // state index [B][ndir*H]
-    float4 g4[2];
-    float2 c_t, cprev, dyv, dcin, dhf;
-    c_t = cprev = dyv = dcin = dhf = make_float2(0.f, 0.f);
-    g4[0] = g4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ld2 = [&](const float* q) { float2 v = make_float2(q[0], 0.f); if (nu > 1) v.y = q[1]; return v; };
     const size_t m = active ? ((size_t)t * B + b) : 0;
-    if (active && nu > 0) {
-        const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
-        { const uint4 graw = ((const uint4*)p.Gs)[(tile * 2 + khalf) * 64 + lane]; g4[0] = gates_unpack(graw.x, graw.y); g4[1] = gates_unpack(graw.z, graw.w); }
-        c_t = ((const float2*)p.Cs)[(tile * 2 + khalf) * 64 + lane];
-        if (s > 0) cprev = ((const float2*)p.Cs)[(native_tile(s - 1, dir, rt, ut, p.ndir, RT, p.UT) * 2 + khalf) * 64 + lane];
-        else if (p.c0) cprev = ld2(p.c0 + su);
-        if (p.dY) dyv = ld2(p.dY + m * p.lddy + dir * p.H8 + u0);
-        if (s == len - 1) {
-            if (p.dh_final) dhf = ld2(p.dh_final + su);
-            if (p.dc_final) dcin = ld2(p.dc_final + su);
-        } else {
-            dcin = ld2(p.dc_carry + su);
+    auto unit0 = [&](int j) { return (ut0 + j) * 16 + fq * 4 + 2 * khalf; };      // first of this lane's 2 units of tile j
+    float4 g4[NU][2];
+    float2 c_t[NU], cprev[NU], dyv[NU], dcin[NU], dhf[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        c_t[j] = cprev[j] = dyv[j] = dcin[j] = dhf[j] = make_float2(0.f, 0.f);
+        g4[j][0] = g4[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int u0 = unit0(j), nu = min(2, H - u0);
+        const size_t su = (size_t)b * NH + dir * H + u0;      // state index [B][ndir*H]
+        auto ld2 = [&](const float* q) { float2 v = make_float2(q[0], 0.f); if (nu > 1) v.y = q[1]; return v; };
+        if (active && nu > 0) {
+            const size_t tile = native_tile(s, dir, rt, ut0 + j, p.ndir, RT, p.UT);
+            { const uint4 graw = ((const uint4*)p.Gs)[(tile * 2 + khalf) * 64 + lane]; g4[j][0] = gates_unpack(graw.x, graw.y); g4[j][1] = gates_unpack(graw.z, graw.w); }
+            c_t[j] = ((const float2*)p.Cs)[(tile * 2 + khalf) * 64 + lane];
+            if (s > 0) cprev[j] = ((const float2*)p.Cs)[(native_tile(s - 1, dir, rt, ut0 + j, p.ndir, RT, p.UT) * 2 + khalf) * 64 + lane];
+            else if (p.c0) cprev[j] = ld2(p.c0 + su);
+            if (p.dY) dyv[j] = ld2(p.dY + m * p.lddy + dir * p.H8 + u0);
+            if (s == len - 1) {
+                if (p.dh_final) dhf[j] = ld2(p.dh_final + su);
+                if (p.dc_final) dcin[j] = ld2(p.dc_final + su);
+            } else {
+                dcin[j] = ld2(p.dc_carry + su);
+            }
         }
     }
 
-    f32x4 accv[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 accv[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) accv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < G.nch; c += 2) {
         dma_wait_all();
         __syncthreads();
         for (int cc = c; cc < min(c + 2, G.nch); ++cc)
-            mma_chunk<1, 8>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
+            mma_chunk<NU, (NU == 1 ? 8 : 2)>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
         if (c + 2 < G.nch) {
             __syncthreads();
-            issue_chunk<1>(wsrc, 0, KB, srow, c + 2, lstm_smem, G, wave, lane);
-            if (c + 3 < G.nch) issue_chunk<1>(wsrc, 0, KB, srow, c + 3, lstm_smem + G.bufsz, G, wave, lane);
+            issue_chunk<NU>(wsrc, wts, KB, srow, c + 2, lstm_smem, G, wave, lane);
+            if (c + 3 < G.nch) issue_chunk<NU>(wsrc, wts, KB, srow, c + 3, lstm_smem + G.bufsz, G, wave, lane);
         }
     }
-    float rec[1][2];
-    reduce_scatter<1>(accv, (float*)(lstm_smem + (size_t)G.nbuf * G.bufsz), wave, khalf, lane, rec);
+    float rec[NU][2];
+    reduce_scatter<NU>(accv, (float*)(lstm_smem + (size_t)G.nbuf * G.bufsz), wave, khalf, lane, rec);
 
-    if (b >= B || nu <= 0) return;
-    if (s < 0) {
-        // pseudo-step -1: gradient into the initial state (decoder <- encoder seam)
-        float2 o_h, o_c;
-        if (len > 0) { o_h = make_float2(rec[0][0], rec[0][1]); o_c = ld2(p.dc_carry + su); }
-        else {
-            o_h = p.dh_final ? ld2(p.dh_final + su) : make_float2(0.f, 0.f);
-            o_c = p.dc_final ? ld2(p.dc_final + su) : make_float2(0.f, 0.f);
-        }
-        p.dh0[su] = o_h.x; p.dc0[su] = o_c.x;
-        if (nu > 1) { p.dh0[su + 1] = o_h.y; p.dc0[su + 1] = o_c.y; }
-        return;
-    }
-    if (active) {
-        const size_t e4 = m * NH + dir * H + (u0 - 2 * khalf);
-        float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.dY && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e4, dsc4);
-        const float ct[2] = {c_t.x, c_t.y}, cp[2] = {cprev.x, cprev.y};
-        const float dy[2] = {dyv.x, dyv.y}, dci[2] = {dcin.x, dcin.y}, dhfv[2] = {dhf.x, dhf.y};
-        bf16_t og[8]; float dcn[2];
+    if (b >= B) return;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const float4 g = g4[rr];
-            const float dh = rec[0][rr] + dhfv[rr] + dy[rr] * (khalf ? dsc4[2 + rr] : dsc4[rr]);
-            const float tc = ftanh(ct[rr]);
-            const float dct = dci[rr] + dh * g.w * (1.f - tc * tc);
-            og[rr * 4 + 3] = f2bf(dh * tc * g.w * (1.f - g.w));            // d_o
-            og[rr * 4 + 0] = f2bf(dct * g.y * g.x * (1.f - g.x));          // d_i
-            og[rr * 4 + 1] = f2bf(dct * g.x * (1.f - g.y * g.y));          // d_j
-            og[rr * 4 + 2] = f2bf(dct * cp[rr] * g.z * (1.f - g.z));       // d_f
-            dcn[rr] = dct * g.z;
+    for (int j = 0; j < NU; ++j) {
+        const int u0 = unit0(j), nu = min(2, H - u0);
+        if (nu <= 0) continue;
+        const size_t su = (size_t)b * NH + dir * H + u0;
+        auto ld2 = [&](const float* q) { float2 v = make_float2(q[0], 0.f); if (nu > 1) v.y = q[1]; return v; };
+        if (s < 0) {
+            // pseudo-step -1: gradient into the initial state (decoder <- encoder seam)
+            float2 o_h, o_c;
+            if (len > 0) { o_h = make_float2(rec[j][0], rec[j][1]); o_c = ld2(p.dc_carry + su); }
+            else {
+                o_h = p.dh_final ? ld2(p.dh_final + su) : make_float2(0.f, 0.f);
+                o_c = p.dc_final ? ld2(p.dc_final + su) : make_float2(0.f, 0.f);
+            }
+            p.dh0[su] = o_h.x; p.dc0[su] = o_c.x;
+            if (nu > 1) { p.dh0[su + 1] = o_h.y; p.dc0[su + 1] = o_c.y; }
+            continue;
         }
-        bf16_t* gp = p.dG + m * p.lddg + (size_t)dir * K4 + u0 * 4;
-        if (nu == 2) {
-            uint4 v;
-            v.x = og[0] | ((unsigned)og[1] << 16); v.y = og[2] | ((unsigned)og[3] << 16);
-            v.z = og[4] | ((unsigned)og[5] << 16); v.w = og[6] | ((unsigned)og[7] << 16);
-            *(uint4*)gp = v;
-        } else {
-            for (int i = 0; i < 4; ++i) gp[i] = og[i];
+        if (active) {
+            const size_t e4 = m * NH + dir * H + (u0 - 2 * khalf);
+            float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.dY && p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, e4, dsc4);
+            const float ct[2] = {c_t[j].x, c_t[j].y}, cp[2] = {cprev[j].x, cprev[j].y};
+            const float dy[2] = {dyv[j].x, dyv[j].y}, dci[2] = {dcin[j].x, dcin[j].y}, dhfv[2] = {dhf[j].x, dhf[j].y};
+            bf16_t og[8]; float dcn[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float4 g = g4[j][rr];
+                const float dh = rec[j][rr] + dhfv[rr] + dy[rr] * (khalf ? dsc4[2 + rr] : dsc4[rr]);
+                const float tc = ftanh(ct[rr]);
+                const float dct = dci[rr] + dh * g.w * (1.f - tc * tc);
+                og[rr * 4 + 3] = f2bf(dh * tc * g.w * (1.f - g.w));            // d_o
+                og[rr * 4 + 0] = f2bf(dct * g.y * g.x * (1.f - g.x));          // d_i
+                og[rr * 4 + 1] = f2bf(dct * g.x * (1.f - g.y * g.y));          // d_j
+                og[rr * 4 + 2] = f2bf(dct * cp[rr] * g.z * (1.f - g.z));       // d_f
+                dcn[rr] = dct * g.z;
+            }
+            bf16_t* gp = p.dG + m * p.lddg + (size_t)dir * K4 + u0 * 4;
+            if (nu == 2) {
+                uint4 v;
+                v.x = og[0] | ((unsigned)og[1] << 16); v.y = og[2] | ((unsigned)og[3] << 16);
+                v.z = og[4] | ((unsigned)og[5] << 16); v.w = og[6] | ((unsigned)og[7] << 16);
+                *(uint4*)gp = v;
+            } else {
+                for (int i = 0; i < 4; ++i) gp[i] = og[i];
+            }
+            p.dc_carry[su] = dcn[0];
+            if (nu > 1) p.dc_carry[su + 1] = dcn[1];
+        } else if (s < p.S) {
+            bf16_t* gp = p.dG + ((size_t)s * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4;
+            if (nu == 2) *(uint4*)gp = make_uint4(0, 0, 0, 0);
+            else { for (int i = 0; i < 4; ++i) gp[i] = 0; }
         }
-        p.dc_carry[su] = dcn[0];
-        if (nu > 1) p.dc_carry[su + 1] = dcn[1];
-    } else if (s < p.S) {
-        bf16_t* gp = p.dG + ((size_t)s * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4;
-        if (nu == 2) *(uint4*)gp = make_uint4(0, 0, 0, 0);
-        else { for (int i = 0; i < 4; ++i) gp[i] = 0; }
     }
 }
 
@@ -1479,7 +1498,7 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
     E2T_CHECK_ARG((dh0 == nullptr) == (dc0 == nullptr));
-    static const int attr_rc = set_big_lds((const void*)k_lstm_step_bwd);
+    static const int attr_rc = set_big_lds((const void*)k_lstm_step_bwd<1>) | set_big_lds((const void*)k_lstm_step_bwd<4>);
     if (attr_rc) return attr_rc;
     LstmBwdArgs p{};
     p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = (const bf16_t*)Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
@@ -1488,16 +1507,21 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     p.lddg = lddg; p.lddy = lddy;
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    const StepGeom G = step_geom(p.KB4, 1, 256);
-    const size_t lds = ((size_t)G.nbuf * G.bufsz + 256) * 16;
+    // 64 units per workgroup where the dG rows dominate the traffic (see the kernel) and enough workgroups remain
+    const bool wide_units = d->H % 64 == 0 && d->H >= 1024;
+    const int NU = wide_units ? 4 : 1;
+    const StepGeom G = step_geom(p.KB4, NU, NU * 256);
+    const size_t lds = ((size_t)G.nbuf * G.bufsz + NU * 256) * 16;
     const int nrb = (d->B + 63) / 64;
     p.rb_begin = d->rb_count > 0 ? d->rb_begin : 0;
     p.rb_count = d->rb_count > 0 ? d->rb_count : nrb;
     E2T_CHECK_ARG(p.rb_begin >= 0 && p.rb_begin + p.rb_count <= nrb);
-    dim3 grid(8 * ((p.UT + 7) / 8) * p.rb_count * d->ndir);      // XCD-major tile map, see kernel
+    const int UG = (p.UT + NU - 1) / NU;
+    dim3 grid(8 * ((UG + 7) / 8) * p.rb_count * d->ndir);        // XCD-major tile map, see kernel
     for (int s = d->S - 1; s >= (dh0 ? -1 : 0); --s) {
         p.step = s;
-        hipLaunchKernelGGL(k_lstm_step_bwd, grid, dim3(512), lds, (hipStream_t)stream, p);
+        if (wide_units) hipLaunchKernelGGL(k_lstm_step_bwd<4>, grid, dim3(512), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(k_lstm_step_bwd<1>, grid, dim3(512), lds, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
