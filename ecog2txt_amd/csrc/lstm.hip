@@ -918,10 +918,12 @@ struct LstmBwdArgs {
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
 };
 
-// NU = unit tiles (of 16 units) per workgroup.  1: the general form.  4: large hidden sizes (H % 64 == 0, the H_d = 2048 decoder of
-// config 4): K = 4H makes the dG rows of a row block (64 x 4H bf16 = 1 MiB at H = 2048) the bulk of what a workgroup pulls through
-// LDS, and with 16 units per workgroup every row block is pulled by H/16 workgroups -- 640 MB per step at H = 2048, L2-bandwidth
-// bound (63 us per step); 64 units per workgroup amortise the rows over four times the weights.
+// NU = unit tiles (of 16 units) per workgroup.  1: the general form.  2: large hidden sizes (H % 32 == 0, H >= 1024: the H_d = 2048
+// decoder of config 4): K = 4H makes the dG rows of a row block (64 x 4H bf16 = 1 MiB at H = 2048) the bulk of what a workgroup
+// pulls through LDS, and every row block is pulled by H / (16 NU) workgroups.  The chunk loop keeps at most two 64-KiB chunks in
+// flight per CU (~48 GB/s per CU at the ~2 us a chunk takes to land), so the step time is the bytes per workgroup over that rate
+// times the rounds of workgroups: NU = 1 -> 512 workgroups x 1.25 MiB: 62.7 us; NU = 2 -> 256 x 1.5 MiB: 41.4 us; NU = 4 -> 128 x 2
+// MiB on half the CUs: 53.6 us (all measured at H = 2048, B = 256).
 template <int NU>
 __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_bwd(LstmBwdArgs p) {
         dma_wait_all();
         __syncthreads();
         for (int cc = c; cc < min(c + 2, G.nch); ++cc)
-            mma_chunk<NU, (NU == 1 ? 8 : 2)>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
+            mma_chunk<NU, (NU == 1 ? 8 : 4)>(accv, lstm_smem + (size_t)(cc & 1) * G.bufsz, G, min(G.kch, KB - cc * G.kch), wave & 3, khalf, lane);
         if (c + 2 < G.nch) {
             __syncthreads();
             issue_chunk<NU>(wsrc, wts, KB, srow, c + 2, lstm_smem, G, wave, lane);
@@ -1498,7 +1500,7 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     E2T_CHECK_ARG(d->S > 0 && d->B > 0 && d->H > 0 && (d->ndir == 1 || d->ndir == 2));
     E2T_CHECK_ARG(d->H % 2 == 0 && lddg % 8 == 0 && lddg >= d->ndir * 4 * d->H);
     E2T_CHECK_ARG((dh0 == nullptr) == (dc0 == nullptr));
-    static const int attr_rc = set_big_lds((const void*)k_lstm_step_bwd<1>) | set_big_lds((const void*)k_lstm_step_bwd<4>);
+    static const int attr_rc = set_big_lds((const void*)k_lstm_step_bwd<1>) | set_big_lds((const void*)k_lstm_step_bwd<2>);
     if (attr_rc) return attr_rc;
     LstmBwdArgs p{};
     p.WhB = (const bf16_t*)WhB; p.dG = (bf16_t*)dG; p.dY = dY; p.Gs = (const bf16_t*)Gs; p.Cs = Cs; p.lens = lens; p.c0 = c0;
@@ -1507,9 +1509,9 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     p.lddg = lddg; p.lddy = lddy;
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
-    // 64 units per workgroup where the dG rows dominate the traffic (see the kernel) and enough workgroups remain
-    const bool wide_units = d->H % 64 == 0 && d->H >= 1024;
-    const int NU = wide_units ? 4 : 1;
+    // 32 units per workgroup where the dG rows dominate the traffic (see the kernel)
+    const bool wide_units = d->H % 32 == 0 && d->H >= 1024;
+    const int NU = wide_units ? 2 : 1;
     const StepGeom G = step_geom(p.KB4, NU, NU * 256);
     const size_t lds = ((size_t)G.nbuf * G.bufsz + NU * 256) * 16;
     const int nrb = (d->B + 63) / 64;
@@ -1520,7 +1522,7 @@ extern "C" int e2t_lstm_seq_bwd(const e2t_lstm_desc* d, const void* WhB, void* d
     dim3 grid(8 * ((UG + 7) / 8) * p.rb_count * d->ndir);        // XCD-major tile map, see kernel
     for (int s = d->S - 1; s >= (dh0 ? -1 : 0); --s) {
         p.step = s;
-        if (wide_units) hipLaunchKernelGGL(k_lstm_step_bwd<4>, grid, dim3(512), lds, (hipStream_t)stream, p);
+        if (NU == 2) hipLaunchKernelGGL(k_lstm_step_bwd<2>, grid, dim3(512), lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(k_lstm_step_bwd<1>, grid, dim3(512), lds, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
