@@ -1,5 +1,8 @@
-import re,sys,glob,subprocess
-for f in sorted(glob.glob('/root/repo/ecog2txt_amd/csrc/build/*.log')):
+"""Registers, scratch and occupancy of every kernel of the product library, from the compiler's own report
+(ecog2txt_amd/csrc/build/*.log: build.sh compiles with -Rpass-analysis=kernel-resource-usage).  usage: kernel_resources.py [regex]"""
+import re,sys,glob,subprocess,os
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for f in sorted(glob.glob(os.path.join(ROOT,'ecog2txt_amd','csrc','build','*.log'))):
     cur={}
     for line in open(f):
         m=re.search(r'remark: (?:[^:]*:\d+:\d+: )?\s*(Function Name|Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|SGPRs Spill|VGPRs Spill): (\S+)',line)

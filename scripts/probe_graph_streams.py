@@ -1,5 +1,5 @@
 """hipGraphLaunch picks the streams of a graph's parallel branches from a pool without a bounds check (seen as a SIGSEGV in
-libamdhip64 at the first replay of a two-branch graph, tests/README).  This probe looks for the history that triggers it:
+libamdhip64 at the first replay of a two-branch graph: DESIGN.md 5.00, profiles/r03_hip_graph_launch_probe.txt).  This probe looks for the history that triggers it:
   child <pre> <nA> <extra> <nB> [launch_on_side]
     pre    : branches of a warm-up graph captured + launched first (0 = none)
     nA, nB : parallel branches of graph A and of graph B (B is made after `extra` unrelated streams were created)
