@@ -1,0 +1,130 @@
+"""Decoding with the trained network (assessment: restore_and_assess, the online predictor): greedy search and beam search,
+one decoder step per token through the launch-per-step kernels.  Mixed into Seq2SeqEngine (engine.py)."""
+from dataclasses import dataclass, field, asdict   # noqa: F401
+import ctypes as C
+import os   # noqa: F401
+
+import numpy as np   # noqa: F401
+import torch
+
+from . import hip_lib as H
+from .hip_lib import lib
+from .params import *       # noqa: F401,F403
+from .layers import _bf, _f32, _i32   # noqa: F401
+
+
+class DecodingMixin:
+    # ------------------------------------------------------------------ decode
+    def greedy_decode(self, ws, which='ema', max_len=None):
+        """beam_width 1 decoding (mocha-1_word_sequence.yaml:31); returns int32 [B, L] token ids."""
+        s = self.spec
+        if self._packed != which:
+            self.pack(which)
+        src = getattr(self.store, which)
+        B, L = ws['B'], ws['L']
+        max_len = L if max_len is None else min(max_len, L)
+        st = self.stream
+        self.encode(ws, src, False)
+        lib.e2t_fill_u32(ws['done'].data_ptr(), B, 0, st)
+        lib.e2t_fill_u32(ws['hyp'].data_ptr(), B * L, PAD_ID, st)
+        lib.e2t_fill_u32(ws['U'].data_ptr(), B, EOS_ID, st)
+        lib.e2t_fill_u32(ws['dlens'].data_ptr(), B, L, st)
+        dw = ws['dec']
+        dr = self._dropout(0.0, STREAM_DEC_EMB)
+        pw = ws['proj']
+        for l in range(max_len):
+            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), l * B, B, s.dec_embed, ws['e'].data_ptr(),
+                              self.E8, C.byref(dr), st)
+            # input projection for this step's rows only
+            self.gemm(ws['e'].data_ptr() + 2 * l * B * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
+                      dw['Gx'].data_ptr() + 2 * l * B * self.dec.N4, self.dec.N4, B, self.dec.N4, self.E8,
+                      bias=self.dec.bias_ptr(src), out_bf16=True)
+            self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
+            # logits for this step: run the projection stack on rows [l*B, (l+1)*B) of the ext array (t+1 block)
+            self._proj_rows(ws, src, l)
+            lib.e2t_softmax_ce(pw['out'].data_ptr() + 4 * l * B * s.vocab, s.vocab, B, s.vocab, None, None, 1, None, 0.0,
+                               None, ws['pred'].data_ptr(), None, None, 0, st)
+            nxt = ws['U'].data_ptr() + 4 * (l + 1) * B if l + 1 < L else None
+            lib.e2t_greedy_update(ws['pred'].data_ptr(), B, l, L, EOS_ID, PAD_ID, ws['done'].data_ptr(),
+                                  ws['hyp'].data_ptr(), nxt, st)
+        return ws['hyp']
+
+    def beam_decode(self, ws, beam_width, temperature=1.0, which='ema', max_len=None):
+        """Beam search (`beam_width`, mocha-1_word_sequence.yaml:31; `temperature`, :82) over the batch staged in ws: returns
+        (int32 [B, L] token ids of the best hypothesis, fp32 [B, W] scores of the final beams).  The encoder runs once on the
+        B utterances; the decoder runs on B x W rows (hypothesis w of utterance b = row b*W + w of a second workspace) with
+        the launch-per-step kernels, e2t_beam_step picks the survivors and e2t_beam_reorder moves their state.
+        beam_width 1 is greedy_decode (identical tokens); oracle: oracle/seq2seq.py beam_decode."""
+        s = self.spec
+        W = int(beam_width)
+        assert 1 <= W <= 16
+        if self._packed != which:
+            self.pack(which)
+        src = getattr(self.store, which)
+        B, L = ws['B'], ws['L']
+        BW = B * W
+        max_len = L if max_len is None else min(max_len, L)
+        st = self.stream
+        wb = self.workspace(ws['sid'], BW, ws['T'], L)          # (only its decoder-side arrays are used)
+        if 'beam' not in wb:
+            dev = self.device
+            wb['beam'] = dict(rep=torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(W).contiguous(),
+                              score=[_f32(BW, device=dev), _f32(BW, device=dev)], done=[_i32(BW, device=dev), _i32(BW, device=dev)],
+                              hyp=[_i32(BW, L, device=dev), _i32(BW, L, device=dev)], rowmap=_i32(BW, device=dev),
+                              tmp_h=_bf(BW, r8(s.dec_rnn), device=dev), tmp_c=_f32(BW, s.dec_rnn, device=dev),
+                              init=torch.tensor([0.0] + [float('-inf')] * (W - 1), dtype=torch.float32, device=dev).repeat(B).contiguous())
+        bm = wb['beam']
+        self.encode(ws, src, False)
+        # every hypothesis starts from the encoder's final state: rows of block 0 of the decoder's ext array and of c0, W times each
+        lib.e2t_gather_rows_u32(ws['dec']['Yext'].data_ptr(), bm['rep'].data_ptr(), BW, BW, self.dec.ldy // 2, wb['dec']['Yext'].data_ptr(), st)
+        lib.e2t_gather_rows_u32(ws['c0'].data_ptr(), bm['rep'].data_ptr(), BW, BW, s.dec_rnn, wb['c0'].data_ptr(), st)
+        bm['score'][0].copy_(bm['init'])                          # beam 0: score 0, the others -inf (W copies of one state)
+        lib.e2t_fill_u32(bm['done'][0].data_ptr(), BW, 0, st)
+        lib.e2t_fill_u32(bm['hyp'][0].data_ptr(), BW * L, PAD_ID, st)
+        lib.e2t_fill_u32(wb['U'].data_ptr(), BW, EOS_ID, st)
+        lib.e2t_fill_u32(wb['dlens'].data_ptr(), BW, L, st)
+        dw, pw = wb['dec'], wb['proj']
+        dr = self._dropout(0.0, STREAM_DEC_EMB)
+        RT, UT = ceil_div(BW, 16), ceil_div(s.dec_rnn, 16)
+        cs_step = RT * UT * 2 * 64 * 2                            # floats of one step's lane-native cell save
+        cur = 0
+        for l in range(max_len):
+            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, wb['U'].data_ptr(), l * BW, BW, s.dec_embed, wb['e'].data_ptr(),
+                              self.E8, C.byref(dr), st)
+            self.gemm(wb['e'].data_ptr() + 2 * l * BW * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
+                      dw['Gx'].data_ptr() + 2 * l * BW * self.dec.N4, self.dec.N4, BW, self.dec.N4, self.E8,
+                      bias=self.dec.bias_ptr(src), out_bf16=True)
+            self.dec.fwd(dw, None, wb['dlens'], src, False, c0=wb['c0'], steps=(l, l + 1))
+            self._proj_rows(wb, src, l)
+            nxt = wb['U'].data_ptr() + 4 * (l + 1) * BW if l + 1 < L else None
+            lib.e2t_beam_step(pw['out'].data_ptr() + 4 * l * BW * s.vocab, s.vocab, B, W, s.vocab, float(temperature), l, L, EOS_ID, PAD_ID,
+                              bm['score'][cur].data_ptr(), bm['done'][cur].data_ptr(), bm['hyp'][cur].data_ptr(),
+                              bm['score'][1 - cur].data_ptr(), bm['done'][1 - cur].data_ptr(), bm['hyp'][1 - cur].data_ptr(),
+                              bm['rowmap'].data_ptr(), nxt, st)
+            cur = 1 - cur
+            if l + 1 < max_len:
+                lib.e2t_beam_reorder(dw['Yext'].data_ptr() + 2 * (l + 1) * BW * self.dec.ldy, self.dec.ldy,
+                                     dw['Cs'].data_ptr() + 4 * l * cs_step, BW, s.dec_rnn, bm['rowmap'].data_ptr(),
+                                     bm['tmp_h'].data_ptr(), bm['tmp_c'].data_ptr(), st)
+        hyp = bm['hyp'][cur].view(B, W, L)[:, 0, :].contiguous()  # survivors are kept best first
+        return hyp, bm['score'][cur].view(B, W)
+
+    def _proj_rows(self, ws, src, l):
+        """Projection stack on decoder step l (un-dropped h_t = ext block l+1)."""
+        s = self.spec
+        B = ws['B']
+        pr, pw = self.proj, ws['proj']
+        cur = ws['dec']['Yext'].data_ptr() + 2 * (l + 1) * B * self.dec.ldy
+        ld = self.dec.ldy
+        for i in range(pr.nl):
+            last = i == pr.nl - 1
+            fout = pr.sizes[i + 1]
+            kin = pr.in_ld if i == 0 else rk(pr.sizes[i])
+            if last:
+                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, pw['out'].data_ptr() + 4 * l * B * fout, fout, B, fout, kin,
+                          bias=pr.bias_ptr(i, src))
+            else:
+                o = pw['act'][i].data_ptr() + 2 * l * B * rk(fout)
+                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, o, rk(fout), B, fout, kin, bias=pr.bias_ptr(i, src),
+                          relu=True, out_bf16=True)
+                cur, ld = o, rk(fout)

@@ -30,9 +30,11 @@ from .hip_lib import lib
 from .params import *       # noqa: F401,F403  (NetSpec, ParamStore, layout helpers, stream ids: re-exported)
 from .params import _tf2int, _int2tf   # noqa: F401
 from .layers import _FFStack, _Lstm, _bf, _f32, _i32   # noqa: F401
+from .packing import PackingMixin
+from .decoding import DecodingMixin
 
 
-class Seq2SeqEngine:
+class Seq2SeqEngine(PackingMixin, DecodingMixin):
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99):
         if not torch.cuda.is_available():
             raise RuntimeError('ecog2txt_amd needs an MI355X (HIP) device; there is no CPU fallback for this path')
@@ -292,126 +294,6 @@ class Seq2SeqEngine:
                 done.record(st)
             cur.wait_event(done)
             lo += cnt
-
-    # ------------------------------------------------------------------ packing
-    def pack_ranges(self, ranges):
-        """Re-pack (from the masters) exactly the images whose source parameters lie in the element ranges `ranges`: used by
-        the captured train step right behind the optimiser update of those ranges, so that the next step starts with
-        only the bottom layer's images left to build."""
-        tab = self._pack_subtable(tuple(ranges))
-        if tab:
-            lib.e2t_pack_batch(tab[0].data_ptr(), tab[1], tab[2], self.store.p.data_ptr(), self.stream)
-
-    def _pack_subtable(self, key):
-        """Descriptor table of the images sourced from the ranges `key` (built once, OUTSIDE any stream capture: it
-        allocates); key ('skip', ranges...) = [head table, table of everything else]."""
-        tab = self._pack_sub.get(key)
-        if tab is None:
-            if self._pack_table is None:
-                self.pack('p')
-            if key and key[0] == 'skip':
-                rest = [op for op in self._pack_ops[1] if not self._op_in(op, key[1:])]
-                tab = [self._pack_descs(t, self.store.p) for t in (self._pack_ops[0], rest) if t]
-            else:
-                ops = [op for op in self._pack_ops[1] if self._op_in(op, key)]
-                tab = self._pack_descs(ops, self.store.p) if ops else False
-            self._pack_sub[key] = tab
-        return tab
-
-    def _op_in(self, op, ranges):
-        off = (op[1] - self.store.p.data_ptr()) // 4
-        return any(a <= off < b for a, b in ranges)
-
-    def pack(self, which='p', after_head=None, skip_ranges=None):
-        """(Re)build every bf16 operand image from the fp32 masters ('p') or the EMA shadows ('ema'): two launches driven
-        by device-resident descriptor tables (built once) -- first the (small) images the front-end needs, the conv
-        kernels of all subjects, then everything else; after_head() runs between the two (an event record: the conv GEMM
-        of a captured step waits for the first launch only, not for the 80 us of the second)."""
-        src = getattr(self.store, which)
-        if skip_ranges:
-            # (a captured train step re-packed these images itself, behind their optimiser update: pack_ranges)
-            tab = self._pack_subtable(('skip',) + tuple(skip_ranges))
-            for i, (dev, n, nblk) in enumerate(tab):
-                lib.e2t_pack_batch(dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
-                if i == 0 and after_head is not None:
-                    after_head()
-            self._packed = None
-            return
-        self._img_early = 'all' if which == 'p' else None      # every image is current (masters): any captured step may follow
-        if self._pack_table is None:
-            st, s = self.store, self.spec
-            base = st.p          # offsets are relative, identical for p and ema
-            head = []
-            for sid, Cc in s.channels.items():
-                lays = self.conv[sid]
-                ci, co, n = lays[0]
-                head.append(('cast', st.ptr(conv_seg(sid, 0), base), 1, co, co, n * ci, self.convT[sid], 0, 0))
-                for j in range(1, len(lays)):
-                    ci, co, n = lays[j]
-                    ldp = self.conv_ld[sid][j - 1]
-                    for w in range(n):
-                        wsrc = st.ptr(conv_seg(sid, j), base, w * ci * co)
-                        head.append(('cast', wsrc, 1, co, co, ci, self.convTj[sid][j], w * ldp, 0))         # [out][w*ld + c]
-                        head.append(('cast', wsrc, co, 1, ci, co, self.convBj[sid][j], 0, w * ldp))         # [w*ld + c][out]
-            ops = []
-            for lay in self.enc:
-                lay.pack_ops(ops, base)
-            if self.aux:
-                self.aux.pack_ops(ops, base)
-            for ax in self.aux_x:
-                ax.pack_ops(ops, base)
-            ops.append(('cast', st.ptr('dec.emb', base), s.dec_embed, 1, s.vocab, s.dec_embed, self.emb, 0, 0))
-            self.dec.pack_ops(ops, base)
-            self.proj.pack_ops(ops, base)
-            self._pack_ops = (head, ops)
-            self._pack_table = [self._pack_descs(t, base) for t in (head, ops) if t]
-        for i, (dev, n, nblk) in enumerate(self._pack_table):
-            lib.e2t_pack_batch(dev.data_ptr(), n, nblk, src.data_ptr(), self.stream)
-            if i == 0 and after_head is not None:
-                after_head()
-        self._packed = which
-
-    def _pack_descs(self, ops, base):
-        if True:
-            descs = (H.PackDesc * len(ops))()
-            nblk = 0
-            p0 = base.data_ptr()
-            for i, op in enumerate(ops):
-                d = descs[i]
-                d.first_block = nblk
-                if op[0] == 'cast':
-                    _, sp, rs, cs, R, Cn, dst, k0, r0 = op
-                    ld = dst.shape[-1]
-                    tr = rs == 1 and cs != 1                 # source contiguous along the image's rows: tiled transpose
-                    off = (sp - p0) // 4
-                    dptr = dst.data_ptr() + 2 * (r0 * ld + k0)
-                    al = off % 4 == 0 and ld % 4 == 0 and dptr % 8 == 0 and Cn % 4 == 0       # 16-B loads / 8-B stores
-                    if tr:
-                        kind = 4 if (al and R % 4 == 0 and cs % 4 == 0) else 2
-                        units = ceil_div(R, 64) * ceil_div(Cn, 64)
-                    else:
-                        kind = 3 if (al and cs == 1 and rs % 4 == 0) else 0
-                        units = R * ceil_div(Cn, 1024) if kind == 3 else R * ceil_div(Cn, 256)
-                    nblk += ceil_div(units, H.PACK_UNITS if kind == 3 else 1)
-                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = kind, off, rs, cs, R, Cn, ld
-                    d.dst = dptr
-                else:
-                    _, sp, ns, ks, Nn, Kk, dst = op
-                    KB = ceil_div(Kk, 32)
-                    off = (sp - p0) // 4
-                    tiled = ns == 1 and ks % 4 == 0 and off % 4 == 0 and Nn % 4 == 0      # contiguous along n: staged via LDS
-                    four = op[0] == 'frag4' and off % 4 == 0                               # gate-interleaved: 4 images, one pass
-                    if op[0] == 'frag4' and not four:
-                        raise RuntimeError('unaligned gate-interleaved weight segment')
-                    d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = (6 if four else 5 if tiled else 1), off, ns, ks, Nn, Kk, KB
-                    d.dst = dst.data_ptr()
-                    if four:
-                        units = ceil_div(Nn, 16) * KB
-                    else:
-                        units = ceil_div(ceil_div(Nn, 16), 4) * KB if tiled else ceil_div(ceil_div(Nn, 16) * KB, 4)
-                    nblk += ceil_div(units, 1 if (tiled or four) else H.PACK_UNITS)
-            raw = bytes(descs)
-            return (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(ops), nblk)
 
     def load_params(self, P):
         self.store.import_tf(P)
@@ -1165,13 +1047,9 @@ class Seq2SeqEngine:
         if self._packed != 'p' and not lazy:
             self.pack('p')
         self.grad_scale = (1.0 if gc else sync.grad_scale) if dp else 1.0
-
-        def after(i, ranges):
-            for a, b in ranges:
-                sync.allreduce_range(a, b)
         if not use_graph:
             self.forward(ws, train=True, global_counts=gc)
-            self.backward(ws, train=True, after_stage=after if dp else None)
+            self.backward(ws, train=True, after_stage=(lambda i, ranges: self._exchange(sync, ranges)) if dp else None)
             if dp:
                 sync.wait()
             self.adam_step(ws['sid'])
@@ -1185,100 +1063,112 @@ class Seq2SeqEngine:
             self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
-            if dp:
-                # one graph per stage for the BPTT chain (main stream) and one per stage for its weight-gradient work
-                # (side stream): the all-reduce of a stage's ranges is issued behind the graph that completes them, the
-                # main chain never waits for the side work (same schedule as the single-GPU graph)
-                stages = self.backward_stages(ws)
-                if self._wstream is None:
-                    self._wstream = torch.cuda.Stream(device=self.device)
-                graphs = []
-                for i, (main, side, ranges) in enumerate(stages):
-                    gm = torch.cuda.CUDAGraph()
-                    with capture(gm):
-                        if i == 0:
-                            self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
-                            ws['have_dy'] = [False] * len(self.enc)
-                            self.run_stage(main, side, True)         # the aux head's backward feeds the chain: joined here
-                        else:
-                            main(True)
-                    gs = None
-                    if i > 0 and side is not None:
-                        gs = torch.cuda.CUDAGraph()
-                        self._on_side = True
-                        try:
-                            with capture(gs):
-                                side(True)
-                        finally:
-                            self._on_side = False
-                    graphs.append((gm, gs, ranges))
-                ga = torch.cuda.CUDAGraph()
-                with capture(ga):
-                    self.adam_step(ws['sid'], repack=not lazy)
-                g = (graphs, ga)
-            else:
-                # parameters whose gradients are final two stages before the end (head, decoder, top encoder layers, an
-                # auxiliary head above the bottom layers) are updated on the side stream under the remaining stages
-                nl = len(self.enc)
-                early_end, early = 0, None
-                packed_early, early_sets = [], []
-                if nl >= 2 and self.overlap and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
-                    # stage i (2 <= i <= nl) queues the weight gradients of layer nl-i+1 on the side stream: behind them,
-                    # everything in front of layer nl-i's segment is final
-                    early, lo = {}, 0
-                    tr = self.trainable_ranges(ws['sid'])
-                    for i in range(2, nl + 1):
-                        hi = self.store.seg_range('enc%d.Wx' % (nl - i))[0]
-                        er = [(max(a, lo), min(b, hi)) for a, b in tr if a < hi and b > lo]
-                        if er:
-                            if self.early_pack:
-                                early_sets.append(er)
-                                # ... and their operand images right behind: the layers that read them in THIS step's backward
-                                # pass (BPTT and input gradient of the layers above the one stage i works on) are done
-                                early[i] = (lambda er=er: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))
-                                packed_early += er
-                            else:
-                                early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
-                        lo = hi
-                    early_end = lo
-                    if len(early) > 1 and os.environ.get('E2T_EARLY_MERGE', '1') != '0':
-                        # ONE early update, behind the LAST side stage: the optimiser and re-pack kernels are HBM-bound and
-                        # pair well with the MFMA-bound weight gradients of the bottom layer in the step's tail; issued
-                        # earlier they sat between the side stream's GEMM launches and pushed the middle layer's weight
-                        # gradients into that tail, where two GEMM launches then competed (measured: see DESIGN 5.00)
-                        if self.early_pack:
-                            merged = []
-                            for x, y in sorted(r for er in early_sets for r in er):
-                                if merged and merged[-1][1] == x:
-                                    merged[-1] = (merged[-1][0], y)
-                                else:
-                                    merged.append((x, y))
-                            early_sets = [merged]
-                            early = {nl: (lambda er=merged: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))}
-                    if not early:
-                        early, early_end = None, 0
-                g1 = torch.cuda.CUDAGraph()
-                if packed_early:
-                    for er_ in early_sets:                       # descriptor tables are built outside the capture
-                        self._pack_subtable(tuple(er_))
-                    self._pack_subtable(('skip',) + tuple(packed_early))
-                with capture(g1):
-                    self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None)
-                    self.backward(ws, train=True, early=early)
-                    self.adam_step(ws['sid'], repack=False, skip_below=early_end)
-                g = (g1, tuple(packed_early))
-            ws['graph'][key] = g
+            g = ws['graph'][key] = self._capture_staged(ws, lazy, gc) if dp else self._capture_step(ws)
         # (a replay does not run forward(): an assessment in between may have left the flag off)
         ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
         for hx, wx in zip(self.spec.aux_extra, ws['auxx']):
             wx['use'] = hx.get('scale', 1.0) != 0.0
-        if not dp:
-            if g[1] and self._img_early != 'all' and self._img_early != g[1]:
-                self.pack('p')           # the graph assumes that the images of ITS early-updated ranges are current
-            g[0].replay()
-            self._packed = None          # the bottom layer's images are those of the weights BEFORE this step's update
-            self._img_early = g[1] if g[1] else None
+        if dp:
+            self._replay_staged(ws, g, sync, lazy)
             return
+        if g[1] and self._img_early != 'all' and self._img_early != g[1]:
+            self.pack('p')           # the graph assumes that the images of ITS early-updated ranges are current
+        g[0].replay()
+        self._packed = None          # the bottom layer's images are those of the weights BEFORE this step's update
+        self._img_early = g[1] if g[1] else None
+
+    @staticmethod
+    def _exchange(sync, ranges):
+        for a, b in ranges:
+            sync.allreduce_range(a, b)
+
+    def _capture_step(self, ws):
+        """The single-process step as ONE graph: forward, backward (weight gradients on the side stream) and the optimiser,
+        with everything above the bottom encoder layer updated and re-packed early.  Returns (graph, early-packed ranges)."""
+        # parameters whose gradients are final two stages before the end (head, decoder, top encoder layers, an
+        # auxiliary head above the bottom layers) are updated on the side stream under the remaining stages
+        nl = len(self.enc)
+        early_end, early = 0, None
+        packed_early, early_sets = [], []
+        if nl >= 2 and self.overlap and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
+            # stage i (2 <= i <= nl) queues the weight gradients of layer nl-i+1 on the side stream: behind them,
+            # everything in front of layer nl-i's segment is final
+            early, lo = {}, 0
+            tr = self.trainable_ranges(ws['sid'])
+            for i in range(2, nl + 1):
+                hi = self.store.seg_range('enc%d.Wx' % (nl - i))[0]
+                er = [(max(a, lo), min(b, hi)) for a, b in tr if a < hi and b > lo]
+                if er:
+                    if self.early_pack:
+                        early_sets.append(er)
+                        # ... and their operand images right behind: the layers that read them in THIS step's backward
+                        # pass (BPTT and input gradient of the layers above the one stage i works on) are done
+                        early[i] = (lambda er=er: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))
+                        packed_early += er
+                    else:
+                        early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
+                lo = hi
+            early_end = lo
+            if len(early) > 1 and self.early_pack and os.environ.get('E2T_EARLY_MERGE', '1') != '0':
+                # ONE early update, behind the LAST side stage: the optimiser and re-pack kernels are HBM-bound and
+                # pair well with the MFMA-bound weight gradients of the bottom layer in the step's tail; issued
+                # earlier they sat between the side stream's GEMM launches and pushed the middle layer's weight
+                # gradients into that tail, where two GEMM launches then competed (measured: see DESIGN 5.00)
+                merged = []
+                for x, y in sorted(r for er in early_sets for r in er):
+                    if merged and merged[-1][1] == x:
+                        merged[-1] = (merged[-1][0], y)
+                    else:
+                        merged.append((x, y))
+                early_sets = [merged]
+                early = {nl: (lambda er=merged: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))}
+            if not early:
+                early, early_end = None, 0
+        g1 = torch.cuda.CUDAGraph()
+        if packed_early:
+            for er_ in early_sets:                       # descriptor tables are built outside the capture
+                self._pack_subtable(tuple(er_))
+            self._pack_subtable(('skip',) + tuple(packed_early))
+        with capture(g1):
+            self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None)
+            self.backward(ws, train=True, early=early)
+            self.adam_step(ws['sid'], repack=False, skip_below=early_end)
+        return (g1, tuple(packed_early))
+
+    def _capture_staged(self, ws, lazy, gc):
+        """The data-parallel step as one graph per backward stage for the BPTT chain (main stream) and one per stage for its
+        weight-gradient work (side stream): the all-reduce of a stage's ranges is issued behind the graph that completes
+        them, the main chain never waits for the side work (same schedule as the single-GPU graph).  Returns
+        ([(main graph, side graph or None, gradient ranges)], optimiser graph)."""
+        stages = self.backward_stages(ws)
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(device=self.device)
+        graphs = []
+        for i, (main, side, ranges) in enumerate(stages):
+            gm = torch.cuda.CUDAGraph()
+            with capture(gm):
+                if i == 0:
+                    self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
+                    ws['have_dy'] = [False] * len(self.enc)
+                    self.run_stage(main, side, True)         # the aux head's backward feeds the chain: joined here
+                else:
+                    main(True)
+            gs = None
+            if i > 0 and side is not None:
+                gs = torch.cuda.CUDAGraph()
+                self._on_side = True
+                try:
+                    with capture(gs):
+                        side(True)
+                finally:
+                    self._on_side = False
+            graphs.append((gm, gs, ranges))
+        ga = torch.cuda.CUDAGraph()
+        with capture(ga):
+            self.adam_step(ws['sid'], repack=not lazy)
+        return (graphs, ga)
+
+    def _replay_staged(self, ws, g, sync, lazy):
         cur = torch.cuda.current_stream(self.device)
 
         def replay_stages(side_stream, exchange):
@@ -1290,10 +1180,10 @@ class Seq2SeqEngine:
                     with torch.cuda.stream(side_stream):
                         gs.replay()
                         if exchange:
-                            after(0, ranges)         # the collective orders itself behind the side stream
+                            self._exchange(sync, ranges)     # the collective orders itself behind the side stream
                 gm.replay()
                 if gs is None and exchange:
-                    after(0, ranges)
+                    self._exchange(sync, ranges)
             ev = torch.cuda.Event()
             ev.record(side_stream)
             cur.wait_event(ev)
@@ -1380,118 +1270,3 @@ class Seq2SeqEngine:
                 out['aux_x%d' % j] = float(wx['loss'].item())
                 out['total'] += float(hx.get('scale', 1.0)) * out['aux_x%d' % j]
         return out
-
-    # ------------------------------------------------------------------ decode
-    def greedy_decode(self, ws, which='ema', max_len=None):
-        """beam_width 1 decoding (mocha-1_word_sequence.yaml:31); returns int32 [B, L] token ids."""
-        s = self.spec
-        if self._packed != which:
-            self.pack(which)
-        src = getattr(self.store, which)
-        B, L = ws['B'], ws['L']
-        max_len = L if max_len is None else min(max_len, L)
-        st = self.stream
-        self.encode(ws, src, False)
-        lib.e2t_fill_u32(ws['done'].data_ptr(), B, 0, st)
-        lib.e2t_fill_u32(ws['hyp'].data_ptr(), B * L, PAD_ID, st)
-        lib.e2t_fill_u32(ws['U'].data_ptr(), B, EOS_ID, st)
-        lib.e2t_fill_u32(ws['dlens'].data_ptr(), B, L, st)
-        dw = ws['dec']
-        dr = self._dropout(0.0, STREAM_DEC_EMB)
-        pw = ws['proj']
-        for l in range(max_len):
-            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), l * B, B, s.dec_embed, ws['e'].data_ptr(),
-                              self.E8, C.byref(dr), st)
-            # input projection for this step's rows only
-            self.gemm(ws['e'].data_ptr() + 2 * l * B * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
-                      dw['Gx'].data_ptr() + 2 * l * B * self.dec.N4, self.dec.N4, B, self.dec.N4, self.E8,
-                      bias=self.dec.bias_ptr(src), out_bf16=True)
-            self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
-            # logits for this step: run the projection stack on rows [l*B, (l+1)*B) of the ext array (t+1 block)
-            self._proj_rows(ws, src, l)
-            lib.e2t_softmax_ce(pw['out'].data_ptr() + 4 * l * B * s.vocab, s.vocab, B, s.vocab, None, None, 1, None, 0.0,
-                               None, ws['pred'].data_ptr(), None, None, 0, st)
-            nxt = ws['U'].data_ptr() + 4 * (l + 1) * B if l + 1 < L else None
-            lib.e2t_greedy_update(ws['pred'].data_ptr(), B, l, L, EOS_ID, PAD_ID, ws['done'].data_ptr(),
-                                  ws['hyp'].data_ptr(), nxt, st)
-        return ws['hyp']
-
-    def beam_decode(self, ws, beam_width, temperature=1.0, which='ema', max_len=None):
-        """Beam search (`beam_width`, mocha-1_word_sequence.yaml:31; `temperature`, :82) over the batch staged in ws: returns
-        (int32 [B, L] token ids of the best hypothesis, fp32 [B, W] scores of the final beams).  The encoder runs once on the
-        B utterances; the decoder runs on B x W rows (hypothesis w of utterance b = row b*W + w of a second workspace) with
-        the launch-per-step kernels, e2t_beam_step picks the survivors and e2t_beam_reorder moves their state.
-        beam_width 1 is greedy_decode (identical tokens); oracle: oracle/seq2seq.py beam_decode."""
-        s = self.spec
-        W = int(beam_width)
-        assert 1 <= W <= 16
-        if self._packed != which:
-            self.pack(which)
-        src = getattr(self.store, which)
-        B, L = ws['B'], ws['L']
-        BW = B * W
-        max_len = L if max_len is None else min(max_len, L)
-        st = self.stream
-        wb = self.workspace(ws['sid'], BW, ws['T'], L)          # (only its decoder-side arrays are used)
-        if 'beam' not in wb:
-            dev = self.device
-            wb['beam'] = dict(rep=torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(W).contiguous(),
-                              score=[_f32(BW, device=dev), _f32(BW, device=dev)], done=[_i32(BW, device=dev), _i32(BW, device=dev)],
-                              hyp=[_i32(BW, L, device=dev), _i32(BW, L, device=dev)], rowmap=_i32(BW, device=dev),
-                              tmp_h=_bf(BW, r8(s.dec_rnn), device=dev), tmp_c=_f32(BW, s.dec_rnn, device=dev),
-                              init=torch.tensor([0.0] + [float('-inf')] * (W - 1), dtype=torch.float32, device=dev).repeat(B).contiguous())
-        bm = wb['beam']
-        self.encode(ws, src, False)
-        # every hypothesis starts from the encoder's final state: rows of block 0 of the decoder's ext array and of c0, W times each
-        lib.e2t_gather_rows_u32(ws['dec']['Yext'].data_ptr(), bm['rep'].data_ptr(), BW, BW, self.dec.ldy // 2, wb['dec']['Yext'].data_ptr(), st)
-        lib.e2t_gather_rows_u32(ws['c0'].data_ptr(), bm['rep'].data_ptr(), BW, BW, s.dec_rnn, wb['c0'].data_ptr(), st)
-        bm['score'][0].copy_(bm['init'])                          # beam 0: score 0, the others -inf (W copies of one state)
-        lib.e2t_fill_u32(bm['done'][0].data_ptr(), BW, 0, st)
-        lib.e2t_fill_u32(bm['hyp'][0].data_ptr(), BW * L, PAD_ID, st)
-        lib.e2t_fill_u32(wb['U'].data_ptr(), BW, EOS_ID, st)
-        lib.e2t_fill_u32(wb['dlens'].data_ptr(), BW, L, st)
-        dw, pw = wb['dec'], wb['proj']
-        dr = self._dropout(0.0, STREAM_DEC_EMB)
-        RT, UT = ceil_div(BW, 16), ceil_div(s.dec_rnn, 16)
-        cs_step = RT * UT * 2 * 64 * 2                            # floats of one step's lane-native cell save
-        cur = 0
-        for l in range(max_len):
-            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, wb['U'].data_ptr(), l * BW, BW, s.dec_embed, wb['e'].data_ptr(),
-                              self.E8, C.byref(dr), st)
-            self.gemm(wb['e'].data_ptr() + 2 * l * BW * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
-                      dw['Gx'].data_ptr() + 2 * l * BW * self.dec.N4, self.dec.N4, BW, self.dec.N4, self.E8,
-                      bias=self.dec.bias_ptr(src), out_bf16=True)
-            self.dec.fwd(dw, None, wb['dlens'], src, False, c0=wb['c0'], steps=(l, l + 1))
-            self._proj_rows(wb, src, l)
-            nxt = wb['U'].data_ptr() + 4 * (l + 1) * BW if l + 1 < L else None
-            lib.e2t_beam_step(pw['out'].data_ptr() + 4 * l * BW * s.vocab, s.vocab, B, W, s.vocab, float(temperature), l, L, EOS_ID, PAD_ID,
-                              bm['score'][cur].data_ptr(), bm['done'][cur].data_ptr(), bm['hyp'][cur].data_ptr(),
-                              bm['score'][1 - cur].data_ptr(), bm['done'][1 - cur].data_ptr(), bm['hyp'][1 - cur].data_ptr(),
-                              bm['rowmap'].data_ptr(), nxt, st)
-            cur = 1 - cur
-            if l + 1 < max_len:
-                lib.e2t_beam_reorder(dw['Yext'].data_ptr() + 2 * (l + 1) * BW * self.dec.ldy, self.dec.ldy,
-                                     dw['Cs'].data_ptr() + 4 * l * cs_step, BW, s.dec_rnn, bm['rowmap'].data_ptr(),
-                                     bm['tmp_h'].data_ptr(), bm['tmp_c'].data_ptr(), st)
-        hyp = bm['hyp'][cur].view(B, W, L)[:, 0, :].contiguous()  # survivors are kept best first
-        return hyp, bm['score'][cur].view(B, W)
-
-    def _proj_rows(self, ws, src, l):
-        """Projection stack on decoder step l (un-dropped h_t = ext block l+1)."""
-        s = self.spec
-        B = ws['B']
-        pr, pw = self.proj, ws['proj']
-        cur = ws['dec']['Yext'].data_ptr() + 2 * (l + 1) * B * self.dec.ldy
-        ld = self.dec.ldy
-        for i in range(pr.nl):
-            last = i == pr.nl - 1
-            fout = pr.sizes[i + 1]
-            kin = pr.in_ld if i == 0 else rk(pr.sizes[i])
-            if last:
-                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, pw['out'].data_ptr() + 4 * l * B * fout, fout, B, fout, kin,
-                          bias=pr.bias_ptr(i, src))
-            else:
-                o = pw['act'][i].data_ptr() + 2 * l * B * rk(fout)
-                self.gemm(cur, ld, pr.WT[i].data_ptr(), kin, o, rk(fout), B, fout, kin, bias=pr.bias_ptr(i, src),
-                          relu=True, out_bf16=True)
-                cur, ld = o, rk(fout)
