@@ -1212,12 +1212,25 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         if pend and lazy and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
             # the optimiser follows the exchange range by range (the ranges complete in backward order): only the last
             # range's update is exposed behind its all-reduce, the earlier ones run under the later collectives
+            # The updates of all ranges but the last go out on the SIDE stream, behind its last weight-gradient graph: they are
+            # HBM-bound and run next to the bottom layer's weight gradients, which close the main chain (the single-GPU graph's
+            # early update, same place); they write fp32 masters and optimiser state, which no backward kernel reads.
             tr = self.trainable_ranges(ws['sid'])
-            for w, a, b in list(pend):
+            pl = list(pend)
+            side_stream = ws['graph']['side_stream']
+
+            def update(w, a, b):
                 w.wait()                         # the current stream waits for this collective only
                 er = [(max(a, x), min(b, y)) for x, y in tr if x < b and y > a]
                 if er:
                     self.adam_ranges(er, step_offset=1)
+            with torch.cuda.stream(side_stream):
+                for w, a, b in pl[:-1]:
+                    update(w, a, b)
+                evs = torch.cuda.Event()
+                evs.record(side_stream)
+            update(*pl[-1])
+            cur.wait_event(evs)
             sync.wait()                          # (all done: clears the lists)
             lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
             self._packed = None
