@@ -75,36 +75,32 @@ def recurrent_flops_fwd(spec_kw, S, L):
     return f + L * 2 * Hd * 4 * Hd
 
 
-def cpu_baseline(spec_kw, B, T, L, warmup=3, timed=10):
+def cpu_baseline(spec_kw, B, T, L, timed=5):
     """the CPU number timed beside the GPU run.  The reference's own CPU path (TF1.x + un-vendored
     packages) cannot run here, so this is `oracle/torch_model.py` -- the independent torch-CPU implementation of the
     same architecture (torch.nn.LSTM oneDNN/MKL kernels, fp32, autograd, Adam + EMA, dropout on) -- on the SAME batch
-    size and shapes as the GPU step, all host cores: 3 warm-up steps, >= 10 timed, median (kind "port")."""
+    size and shapes as the GPU step (kind "port").  Bounded sample (about 30 s of CPU work): one warm-up step, ONE timed
+    step at each of 8 / 16 / 32 / 64 threads (all of them: torch's default of every hardware thread is an order of
+    magnitude slower for a recurrence of small per-step GEMMs, and which count is best differs from box to box), then
+    `timed` steps at the best count, median; `cores` = that count, the sweep is reported in `sample`."""
     import torch
     from oracle import seq2seq as O
     from oracle.torch_model import train_step_fn
     sid = list(spec_kw['channels'])[0]
     kw1 = dict(spec_kw, channels={sid: spec_kw['channels'][sid]})
     step, _ = train_step_fn(O.NetSpec(**kw1), synth_batch(kw1, B, T, L, seed=1))
-    # thread count: torch's default is every hardware thread, which is far from the fastest setting for a recurrence of
-    # small per-step GEMMs (128 threads: 15 s/step on the GPU box, an order of magnitude slower than 16-32).  One step at
-    # each of a few counts, keep the fastest -- the baseline should be the CPU's best, not a strawman.
     ncpu = os.cpu_count() or 1
-    best = None
-    for nt in [n for n in (8, 16, 32, 64) if n <= ncpu] or [ncpu]:
+    counts = [n for n in (8, 16, 32, 64) if n <= ncpu] or [ncpu]
+    torch.set_num_threads(counts[min(1, len(counts) - 1)])
+    step()                                        # warm-up (allocations, oneDNN primitive caches)
+    sweep = []
+    for nt in counts:
         torch.set_num_threads(nt)
-        step()
         t0 = time.perf_counter()
         step()
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, nt)
-        elif dt > 1.5 * best[0]:
-            break
-    threads = best[1]
+        sweep.append((time.perf_counter() - t0, nt))
+    threads = min(sweep)[1]
     torch.set_num_threads(threads)
-    for _ in range(warmup):
-        step()
     ts = []
     for _ in range(timed):
         t0 = time.perf_counter()
@@ -119,8 +115,9 @@ def cpu_baseline(spec_kw, B, T, L, warmup=3, timed=10):
         pass
     return dict(value=round(B / med, 3), unit='utterances/s', cores=int(threads), kind='port',
                 sample='torch-CPU fp32 model of the same architecture (oracle/torch_model.py: nn.LSTM, conv1d, autograd, Adam+EMA), '
-                       'B=%d T=%d, %d warm-up + %d timed train steps, median %.3f s/step (min %.3f, max %.3f); host: %s, nproc=%d'
-                       % (B, T, warmup, len(ts), med, min(ts), max(ts), cpu, os.cpu_count() or 0))
+                       'B=%d T=%d; thread sweep (s/step): %s; then %d timed train steps at %d threads, median %.3f s/step '
+                       '(min %.3f, max %.3f); host: %s, nproc=%d'
+                       % (B, T, ', '.join('%d: %.2f' % (n, t) for t, n in sweep), len(ts), threads, med, min(ts), max(ts), cpu, ncpu))
 
 
 # in-step averages (rocprofv3 --kernel-trace --stats of the train step) and HBM bytes (PMC passes) of the GEMM instances, from the
@@ -135,56 +132,53 @@ def roofline_refs():
 
 GEMM_KERNELS = {'tn128g': 'k_gemm_tn_group (K-major operands: the weight gradients of a backward stage in one grouped launch, 128x128 tiles)',
                 'tn256': 'k_gemm_nt<256,256,2,4,false,true> (K-major operands, both output dimensions >= 1024)',
-                'tn128': 'k_gemm_nt<128,128,2,2,true,true> (K-major operands: weight gradients)',
+                'tn128': 'k_gemm_nt<128,128,2,2,false,true> (K-major operands: weight gradients, lean epilogue)',
                 'nt128': 'k_gemm_nt<128,128,2,2,true,false> (K-contiguous, full epilogue)',
                 'nt256': 'k_gemm_nt<256,256,2,4,false,false> (K-contiguous, large plain products)'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', default='cfg2', choices=list(CONFIGS))
-    ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default: the config\'s 256)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--gemm-detail', action='store_true', help='stderr: isolated time of every logged product of the step')
-    args = ap.parse_args()
+def synth_batch_device(spec_kw, sid, B, T, L, seed, device):
+    """The same synthetic workload as synth_batch(), generated ON the device (the other BASELINE configs of the default
+    line: cfg5's batch is 2.1 GB of fp32, which numpy takes tens of seconds to draw): |N(0,1)| standardised + a
+    sentence-dependent low-rank signal, 50 sentences of 3..L-1 words + <EOS>, N(0,1) auxiliary targets."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    C = spec_kw['channels'][sid]
+    V, K = spec_kw['vocab'], spec_kw['aux_dim']
+    rng = np.random.default_rng(seed)
+    nsent = 50
+    sents = [rng.integers(3, V, size=n) for n in rng.integers(3, L, size=nsent)]
+    which = rng.integers(0, nsent, size=B)
+    X = torch.randn(B, T, C, generator=g, device=device).abs_()
+    X.sub_(X.mean()).div_(X.std())
+    basis = torch.randn(nsent, 2, C, generator=g, device=device)
+    tt = torch.linspace(0, 1, T, device=device)[:, None]
+    wd = torch.as_tensor(which, device=device)
+    freq = (1 + wd % 5).to(torch.float32)[:, None, None]
+    X.add_(0.5 * (torch.sin(2 * np.pi * freq * tt[None]) * basis[wd, 0][:, None, :] + tt[None] * basis[wd, 1][:, None, :]))
+    X[X == 0] = 1e-3
+    Y = np.zeros((B, L), np.int32)
+    for b in range(B):
+        w = sents[which[b]]
+        Y[b, :len(w)] = w
+        Y[b, len(w)] = 1
+    A = torch.randn(B, T, K, generator=g, device=device)
+    return X, torch.as_tensor(Y, device=device), A
 
+
+def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory, roofline, device_data=False, batch=None):
+    """One configuration: engine, synthetic batch resident in HBM, `warmup` untimed + `steps` timed train steps (barrier +
+    synchronize on both sides, max over ranks), and -- on rank 0 -- the live roofline legs.  Returns the dict of the line."""
     import torch
     from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec, ceil_div, capture
-    from ecog2txt_amd import parallel
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)        # (diagnostics: several ranks on one GPU with E2T_BENCH_BACKEND=gloo)
-    torch.cuda.set_device(dev_index)
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-
-    spec_kw, B, T, L = CONFIGS[args.config]
-    B = args.batch or B
+    spec_kw, B, T, L = CONFIGS[cfg_name]
+    B = batch or B
     spec = NetSpec(**spec_kw)
-    eng = Seq2SeqEngine(spec, device='cuda:%d' % dev_index, seed=1234 + rank)
+    device = 'cuda:%d' % dev_index
+    eng = Seq2SeqEngine(spec, device=device, seed=1234 + rank)
     eng.init_params(seed=0)
-    # data parallel: RCCL through the C ABI (e2t_comm_*); E2T_COMM=torch selects torch.distributed's "nccl" instead
-    sync = None
-    if world > 1:
-        if os.environ.get('E2T_COMM', 'rccl') == 'rccl':
-            try:
-                sync = parallel.make_sync(eng.store.g)
-            except Exception as e:                          # (symmetric on all ranks of a node: same library, same driver)
-                print('bench: direct RCCL exchange unavailable (%r); falling back to torch.distributed "nccl"' % (e,), file=sys.stderr)
-                os.environ['E2T_COMM'] = 'torch'
-        if sync is None:
-            import torch.distributed as dist
-            backend = os.environ.get('E2T_BENCH_BACKEND', 'nccl')
-            dist.init_process_group(backend, **({'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}))
-            sync = parallel.make_sync(eng.store.g)
+    sync = sync_factory(eng) if sync_factory is not None else None
+    if sync is not None:
         sync.broadcast_([eng.store.p, eng.store.ema])
     eng.pack('p')
     # one workspace per participant (cfg3: four, stepped in turn -- SURVEY.md 8 d2); synthetic batches resident in HBM
@@ -192,11 +186,18 @@ def main():
     wss = []
     for i, sid in enumerate(sids):
         ws = eng.workspace(sid, B, T, L)
-        batch = synth_batch(dict(spec_kw, channels={sid: spec.channels[sid]}), B, T, L, seed=100 + rank + 17 * i)
-        eng.set_batch(ws, batch)
+        if device_data:
+            X, Y, A = synth_batch_device(spec_kw, sid, B, T, L, 100 + rank + 17 * i, device)
+            ws['X'].copy_(X); ws['Y'].copy_(Y); ws['auxT'].copy_(A)
+            del X, A
+            cnt_src = (Y.cpu().numpy(), None)
+        else:
+            batch_ = synth_batch(dict(spec_kw, channels={sid: spec.channels[sid]}), B, T, L, seed=100 + rank + 17 * i)
+            eng.set_batch(ws, batch_)
+            cnt_src = (batch_['decoder_targets'], batch_['encoder_targets'])
         if sync is not None:
             # losses are normalised by the GLOBAL token counts, so the exchange is a plain sum (parallel.py)
-            cnt = sync.allreduce_numpy(np.array(eng.local_counts(batch['decoder_targets'], batch['encoder_targets']), np.int64))
+            cnt = sync.allreduce_numpy(np.array(eng.local_counts(*cnt_src), np.int64))
             eng.set_global_counts(ws, int(cnt[0]), int(cnt[1]))
         wss.append(ws)
     torch.cuda.synchronize()
@@ -208,14 +209,14 @@ def main():
 
     # the step loop runs with the engine's own stream current, as SequenceNetwork.fit runs it (engine.on_step_stream)
     with eng.on_step_stream():
-        for _ in range(max(args.warmup, len(wss))):
+        for _ in range(max(warmup, len(wss))):
             step()
         torch.cuda.synchronize()
         if sync is not None:
             sync.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
     if sync is not None:
@@ -231,15 +232,14 @@ def main():
     assert np.isfinite(losses['total']), losses
 
     # ---- per-kernel rooflines, measured live.  The dominant kernel of the step (rocprofv3 summary under profiles/) is the
-    #      MFMA GEMM, in three instances.  Every product of one eager step is logged with the instance the library picks
+    #      MFMA GEMM, in several instances.  Every product of one eager step is logged with the instance the library picks
     #      for it and its ALGORITHMIC flops (2*M*N*K on the unpadded dimensions); each instance's
     #      launches are then replayed back to back from a hipGraph on the bench stream, bracketed by HIP events on THAT
     #      stream: achieved = sum of flops / sum of launch durations = flops per launch / average launch duration.
     #      (In the step the same launches share the chip with the side stream; the in-step averages are in profiles/.)
     roof, groups, extra = None, {}, {}
-    if rank == 0 and not args.no_roofline:
-        S = ceil_div(T, spec.decimation)
-
+    S = ceil_div(T, spec.decimation)
+    if rank == 0 and roofline:
         def time_graph(fn, reps):
             fn(); torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
@@ -261,7 +261,7 @@ def main():
         eng.backward(ws, train=True)
         torch.cuda.synchronize()
         log, eng._gemm_log = eng._gemm_log, None
-        refs = roofline_refs().get(args.config if B == CONFIGS[args.config][1] else '', {})
+        refs = roofline_refs().get(cfg_name if B == CONFIGS[cfg_name][1] else '', {})
         for inst in ('tn128g', 'tn128', 'tn256', 'nt128', 'nt256'):
             recs = [r for r in log if r['inst'] == inst]
             if not recs:
@@ -307,23 +307,98 @@ def main():
                      lstm_bwd_frac_of_mfma_peak=round(fl / (us_b * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
         eng.check_sync()
 
+    out = None
     if rank == 0:
-        utt = B * world * args.steps / el
-        S = ceil_div(T, spec.decimation)
+        utt = B * world * steps / el
         rec = 3 * recurrent_flops_fwd(spec_kw, S, L) * utt / 1e12
         chans = '/'.join(str(c) for c in spec.channels.values())
-        out = dict(metric='train utterances/sec', value=round(utt, 2), unit='utterances/s', n_gpus=world, steps=args.steps,
-                   warmup=args.warmup, ms_per_step=round(1e3 * el / args.steps, 4), higher_is_better=True, scaling='weak',
+        out = dict(metric='train utterances/sec', value=round(utt, 2), unit='utterances/s', n_gpus=world, steps=steps,
+                   warmup=warmup, ms_per_step=round(1e3 * el / steps, 4), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload='%s: %d subject(s), %s electrodes x %d samples, B=%d/GPU, conv%d -> %dx biLSTM(%d) -> LSTM(%d) -> %d words, L=%d, Adam+EMA'
-                               % (args.config, len(sids), chans, T, B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
+                   config=dict(workload='%s: %d subject(s), %s electrodes x %d samples (fp32 inputs resident in HBM), B=%d/GPU, conv%d -> %dx biLSTM(%d) -> LSTM(%d) -> %d words, L=%d, Adam+EMA'
+                               % (cfg_name, len(sids), chans, T, B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
                                   spec.dec_rnn, spec.vocab, L), global_batch=B * world, parallelism='dp%d' % world,
                                hipgraph=not args.no_graph, exchange=(type(sync).__name__ if sync is not None else None)),
                    recurrent_gemm_tflops=round(rec, 3), recurrent_gemm_frac_of_peak=round(rec / MFMA_BF16_PEAK_TFLOPS / world, 5),
                    final_loss=round(losses['total'], 4), recurrence=extra, roofline=roof,
                    roofline_all_gemm_instances=groups)
+    # release the engine's device memory before the next configuration (cfg5's workspace is ~9 GB)
+    eng._ws.clear()
+    del eng, wss, ws
+    import gc as _gc
+    _gc.collect()
+    torch.cuda.empty_cache()
+    return out, sync
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', default='cfg2', choices=list(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default: the config\'s 256)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the `configs` block (cfg3 / cfg4 / cfg5 measured in the same process)')
+    ap.add_argument('--gemm-detail', action='store_true', help='stderr: isolated time of every logged product of the step')
+    args = ap.parse_args()
+
+    import torch
+    from ecog2txt_amd import parallel
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)        # (diagnostics: several ranks on one GPU with E2T_BENCH_BACKEND=gloo)
+    torch.cuda.set_device(dev_index)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+    # data parallel: RCCL through the C ABI (e2t_comm_*); E2T_COMM=torch selects torch.distributed's "nccl" instead
+    def sync_factory(eng):
+        if os.environ.get('E2T_COMM', 'rccl') == 'rccl':
+            try:
+                return parallel.make_sync(eng.store.g)
+            except Exception as e:                          # (symmetric on all ranks of a node: same library, same driver)
+                print('bench: direct RCCL exchange unavailable (%r); falling back to torch.distributed "nccl"' % (e,), file=sys.stderr)
+                os.environ['E2T_COMM'] = 'torch'
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = os.environ.get('E2T_BENCH_BACKEND', 'nccl')
+            dist.init_process_group(backend, **({'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}))
+        return parallel.make_sync(eng.store.g)
+
+    out, sync = measure(args.config, args, args.steps, args.warmup, rank, world, dev_index, sync_factory if world > 1 else None,
+                        roofline=not args.no_roofline, batch=args.batch)
+    if rank == 0:
+        # The other BASELINE.json configurations, measured in the SAME process on one GPU (10 warm-up + 20 timed steps each,
+        # synthetic inputs generated on the device): cfg3 (4 participants in turn), cfg4 (wide model), cfg5 (long / wide input).
+        if world == 1 and args.config == 'cfg2' and args.batch is None and not args.no_configs:
+            block = {}
+            for c in ('cfg3', 'cfg4', 'cfg5'):
+                t0 = time.perf_counter()
+                try:
+                    o, _ = measure(c, args, 20, 10, 0, 1, dev_index, None, roofline=not args.no_roofline, device_data=True)
+                except Exception as e:                     # the headline line must not die with a side configuration
+                    block[c] = dict(error=repr(e)[:300])
+                    continue
+                dom = o['roofline'] or {}
+                block[c] = dict(workload=o['config']['workload'], ms_per_step=o['ms_per_step'], value=o['value'], unit=o['unit'],
+                                steps=20, warmup=10, recurrent_gemm_frac_of_peak=o['recurrent_gemm_frac_of_peak'],
+                                dominant=dict(instance=dom.get('instance'), kernel=dom.get('kernel'), frac=dom.get('frac'),
+                                              frac_in_step=dom.get('frac_in_step'), in_step_source=dom.get('in_step_source'),
+                                              us_per_launch=dom.get('us_per_launch'), flops_per_launch=dom.get('flops_per_launch'),
+                                              largest=dom.get('largest')),
+                                gemm_instances={k: dict(frac=v['frac'], frac_in_step=v['frac_in_step'], us_per_step=v['us_per_step'])
+                                                for k, v in o['roofline_all_gemm_instances'].items()},
+                                recurrence=o['recurrence'], final_loss=o['final_loss'], wall_s=round(time.perf_counter() - t0, 1))
+            out['configs'] = block
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(spec_kw, B, T, L)
+            spec_kw, B, T, L = CONFIGS[args.config]
+            out['cpu_baseline'] = cpu_baseline(spec_kw, args.batch or B, T, L)
         print(json.dumps(out))
     if sync is not None and hasattr(sync, 'close'):
         sync.barrier()

@@ -260,6 +260,11 @@ class SyntheticSpeechDataGenerator(ECoGDataGenerator):
         return self.trials_per_block * len(list(block_set))
 
     def _ecog_token_generator(self, block):
+        for _, example in self._trials(block):
+            yield example
+
+    def _trials(self, block):
+        """(sentence index, example dict) of every trial of a block."""
         sents = self._sentences()
         C, K = self.num_ECoG_channels, max(self.num_MFCC_features, 0)
         basis = self._rng('basis').standard_normal((len(sents), 3, C))
@@ -277,4 +282,50 @@ class SyntheticSpeechDataGenerator(ECoGDataGenerator):
                 a = np.cumsum(rng.standard_normal((T, K)), 0) / np.sqrt(np.arange(1, T + 1))[:, None] + basis[si, 0, :K] * tt
                 a[np.abs(a).max(1) == 0] = 1e-3
                 example['audio_sequence'] = a.astype(np.float32)
-            yield example
+            yield si, example
+
+
+class SyntheticWaveformDataGenerator(SyntheticSpeechDataGenerator):
+    """The synthetic participant with REAL acoustic features as auxiliary targets: every trial carries a synthetic speech-like
+    waveform (sentence-dependent formant-like sinusoids under a syllable-rate envelope, plus noise; 16 kHz) through the
+    `_get_wav_data` hook, and its `audio_sequence` is `_get_MFCC_features(index, 1 / sampling_rate)` -- the reference's
+    feature path (ecog2txt/data_generators.py:328-380: one frame per ECoG sample, `mfcc_winlen`, `num_mel_features`,
+    `num_cepstral_coeffs`, `USE_LOG_MELS`, `USE_MFCC_DELTAS` from the manifest), restated in speech_features.py."""
+    audio_sampling_rate = 16000
+
+    def _trial_plan(self, block):
+        """(sentence index, number of ECoG samples) of every trial of a block, in the order _ecog_token_generator yields them."""
+        if not hasattr(self, '_plans'):
+            self._plans = {}
+        if block not in self._plans:
+            self._plans[block] = list(self._trials(block))
+        return self._plans[block]
+
+    def _get_wav_data(self, index):
+        """index = (block, trial number).  The waveform lasts as long as the trial's ECoG."""
+        block, trial = index
+        si, ex = self._trial_plan(block)[trial]
+        T = ex['ecog_sequence'].shape[0]
+        n = int(round(T / self.sampling_rate * self.audio_sampling_rate))
+        t = np.arange(n) / self.audio_sampling_rate
+        rng = self._rng('wave', block, trial)
+        f0 = 110.0 + 7.0 * (si % 9)
+        formants = [300.0 + 90.0 * (si % 5), 1200.0 + 160.0 * (si % 7), 2500.0 + 110.0 * (si % 3)]
+        env = 0.55 + 0.45 * np.sin(2 * np.pi * (2.5 + 0.3 * (si % 4)) * t) ** 2          # syllable-rate envelope
+        sig = sum(a * np.sin(2 * np.pi * f * t + 0.3 * np.sin(2 * np.pi * f0 * t)) for a, f in zip((1.0, 0.6, 0.3), formants))
+        sig = env * sig * (1.0 + 0.2 * np.sign(np.sin(2 * np.pi * f0 * t))) + 0.05 * rng.standard_normal(n)
+        return self.audio_sampling_rate, (3000.0 * sig).astype(np.float64)
+
+    def _ecog_token_generator(self, block):
+        for trial, (_, ex) in enumerate(self._trial_plan(block)):
+            out = dict(ex)
+            if self.num_MFCC_features:
+                a = self._get_MFCC_features((block, trial), 1.0 / self.sampling_rate)
+                T = ex['ecog_sequence'].shape[0]
+                feat = np.zeros((T, self.num_MFCC_features))
+                feat[:min(T, a.shape[0])] = a[:T]
+                if a.shape[0] and a.shape[0] < T:
+                    feat[a.shape[0]:] = a[-1]                    # (frame count and sample count differ by at most one frame)
+                feat[np.abs(feat).max(1) == 0] = 1e-3           # a genuine all-zero row would read as padding
+                out['audio_sequence'] = feat.astype(np.float32)
+            yield out

@@ -4,7 +4,7 @@ import os
 
 MANIFEST_TEMPLATE = """
 {sid}:
-  DataGenerator: !!python/name:ecog2txt_amd.data_generators.SyntheticSpeechDataGenerator ''
+  DataGenerator: !!python/name:ecog2txt_amd.data_generators.{generator} ''
   EMA_decay: 0.99
   FF_dropout: 0.1
   N_epochs: {epochs}
@@ -67,10 +67,12 @@ MANIFEST_TEMPLATE = """
 """
 
 
-def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None, extra_aux=False, embedding=(24,)):
+def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4), rate=200, nwords=20, grids=None, extra_aux=False, embedding=(24,),
+                    generator='SyntheticSpeechDataGenerator'):
     """grids: {subject id: (rows, cols)} for participants whose electrode grids differ from `grid`; extra_aux: a second
     auxiliary head ('encoder_0_targets', also on the audio sequence, one hidden layer of 12, penalty scale 0.25); embedding:
-    layer_sizes['encoder_embedding'] (more than one entry = a stack of strided conv layers)."""
+    layer_sizes['encoder_embedding'] (more than one entry = a stack of strided conv layers); generator: the DataGenerator class of
+    ecog2txt_amd.data_generators the manifest names."""
     root = str(root)
     os.makedirs(root, exist_ok=True)
     blocks = {}
@@ -94,7 +96,7 @@ def make_experiment(root, subject_ids=(401,), epochs=2, interval=1, grid=(4, 4),
     with open(path, 'w') as f:
         for sid in subject_ids:
             g = (grids or {}).get(sid, grid)
-            f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=g[0], g1=g[1], rate=rate,
+            f.write(MANIFEST_TEMPLATE.format(sid=sid, root=root, epochs=epochs, interval=interval, g0=g[0], g1=g[1], rate=rate, generator=generator,
                                             extra_map='    encoder_0_targets: audio_sequence\n' if extra_aux else '',
                                             extra_scale='  encoder_0_targets_penalty_scale: 0.25\n' if extra_aux else '',
                                             extra_proj='    encoder_0_projection:\n    - 12\n' if extra_aux else '',

@@ -409,3 +409,42 @@ def test_fit_with_a_stack_of_conv_layers(small):
     assert sal.shape == (16,) and np.isfinite(sal).all() and sal.max() > 0
     act = tr2.get_internal_activations()
     assert act['convolved_inputs'].shape[2] == 24
+
+
+def test_fit_on_audio_targets_made_by_speech_features(small):
+    """SURVEY 8 f4 on the GPU: the auxiliary targets of a fit are MFCCs that `speech_features.mfcc_features` computes from
+    (synthetic) waveforms through the reference's hooks -- `_get_wav_data` -> `_get_MFCC_features(index, winstep)`
+    (ecog2txt/data_generators.py:328-380) -> `audio_sequence` in the records -> `encoder_1_targets` of the HIP train step.
+    The records hold exactly what the feature code returns, the fit consumes them, the auxiliary loss falls."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    from ecog2txt_amd import tfrecord
+    from ecog2txt_amd.speech_features import mfcc_features
+    path = make_experiment(small, subject_ids=(401,), epochs=30, interval=15, generator='SyntheticWaveformDataGenerator')
+    ck = str(small / 'ckw'); os.makedirs(ck)
+    tr = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False,
+                             SN_kwargs={'N_cases': 32, 'learning_rate': 3e-3, 'FF_dropout': 0.0, 'RNN_dropout': 0.1, 'EMA_decay': 0.9},
+                             DG_kwargs={'max_samples': 420})
+    subj = tr.ecog_subjects[-1]
+    dg = subj.data_generator
+    assert type(dg).__name__ == 'SyntheticWaveformDataGenerator' and dg.num_MFCC_features == 5
+    for s in tr.ecog_subjects:
+        s.write_tf_records_maybe()
+    # the records carry the feature code's output for the trial's waveform (one frame per ECoG sample)
+    block = sorted(subj.block_ids['training'])[0]
+    payloads = list(tfrecord.tf_record_iterator(dg.tf_record_partial_path.format(block)))
+    ex = tfrecord.decode_example(payloads[3])
+    rate, wav = dg._get_wav_data((block, 3))
+    want = mfcc_features(wav, rate, dg.mfcc_winlen, 1.0 / dg.sampling_rate, dg.num_mel_features, dg.num_cepstral_coeffs, False, False, 512)
+    got = np.asarray(ex['audio_sequence'], np.float32).reshape(-1, 5)
+    T = np.asarray(ex['ecog_sequence']).size // 16
+    assert got.shape[0] == T and abs(want.shape[0] - T) <= 1
+    n = min(T, want.shape[0])
+    np.testing.assert_allclose(got[:n], want[:n].astype(np.float32), rtol=1e-6, atol=1e-6)
+    assert np.abs(got[:, 0]).min() > 1.0            # c0 = log frame energy of a non-silent waveform
+    a = tr.parallel_transfer_learn()
+    lo = a['training'].losses
+    assert 'aux' in lo[0] and np.isfinite(lo[-1]['aux'])
+    assert lo[-1]['aux'] < 0.5 * lo[0]['aux'], (lo[0], lo[-1])
+    assert lo[-1]['decoder'] < lo[0]['decoder']
+    res = tr.assess_saved_model()
+    assert np.isfinite(res['validation'].word_error_rate)

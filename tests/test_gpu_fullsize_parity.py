@@ -1,6 +1,8 @@
 """Full-size parity leg: the REAL graphs of BASELINE.json's configurations -- cfg2 (256 electrodes x
 400 samples, 3 x biLSTM(400), decoder 800, V = 1806, B = 256: 8704-row GEMMs with split-K, S = 34 persistent sweeps, K = 3072
-conv) and cfg4 (H = 1024 x 4 layers, decoder 2048) -- compared tensor by tensor with CPU checkers:
+conv), cfg4 (H = 1024 x 4 layers, decoder 2048) and cfg5 (1024 electrodes x 2000 samples: S = 167 persistent sweeps, the
+K = 12 288 one-pass front-end the engine picks for HBM-sized batches, fp32 inputs and bf16-staged inputs) -- compared tensor by
+tensor with CPU checkers:
 
  * HIP path vs `oracle/torch_model.py` (the independent torch-CPU model, fp32, autograd) at the full batch.  The HIP path
    multiplies bf16 operands, so the tolerance is the measured bf16-vs-exact band, stated per quantity:
@@ -8,8 +10,9 @@ conv) and cfg4 (H = 1024 x 4 layers, decoder 2048) -- compared tensor by tensor 
  * HIP path vs the bf16-emulating NumPy oracle (`oracle/seq2seq.py`, same rounding points) at B = 16 of the SAME cfg2
    graph, with the tolerances of tests/test_gpu_parity.py (losses 2e-4, gradients 5e-3 of the tensor's maximum).
 
-Dropout is off in all three (the torch model draws Bernoulli masks, not Philox; the Philox path is covered at small sizes by
-test_gpu_parity.py and, at full size, by determinism / linearity in test_gpu_fullsize.py).
+Dropout is off in the torch legs (the torch model draws Bernoulli masks, not Philox); the oracle leg runs twice, the second time
+with dropout ON: Philox4x32-10 on both sides, masks on 8704-row tensors (conv output, layer outputs, the 225-wide auxiliary
+layer whose rows straddle two Philox blocks, decoder input / output) -- the same tolerances.
 """
 import numpy as np
 import pytest
@@ -33,14 +36,16 @@ def _ragged(batch, T, lo, seed=0):
     return lens
 
 
-def _hip(kw, B, T, L, batch, P):
+def _hip(kw, B, T, L, batch, P, train=False, prepare=None):
     from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
     eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=5)
     eng.load_params(P)
     ws = eng.workspace(401, B, T, L)
     eng.set_batch(ws, batch)
-    eng.forward(ws, train=False)
-    eng.backward(ws, train=False)
+    if prepare is not None:
+        prepare(eng, ws)
+    eng.forward(ws, train=train)
+    eng.backward(ws, train=train)
     torch.cuda.synchronize()
     assert int(eng.sync_err[0].item()) == 0
     losses = eng.losses(ws)
@@ -78,7 +83,7 @@ def _biases_off_zero(P, seed):
     return P
 
 
-@pytest.mark.parametrize('name,B', [('cfg2', 256), ('cfg4', 64)])
+@pytest.mark.parametrize('name,B', [('cfg2', 256), ('cfg4', 64), ('cfg5', 64)])
 def test_full_graph_against_torch_cpu(name, B):
     kw, _, T, L = bench.CONFIGS[name]
     from ecog2txt_amd.engine import NetSpec
@@ -87,6 +92,9 @@ def test_full_graph_against_torch_cpu(name, B):
     batch = bench.synth_batch(kw, B, T, L, seed=7)
     _ragged(batch, T, 240, seed=1)
     eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P)
+    if name == 'cfg5':
+        # the engine took the one-pass front-end (e2t_conv_fwd_fused), as it does at B = 256: the batch is HBM-sized (524 MB)
+        assert B * T * kw['channels'][401] * 4 >= (1 << 28) and eng.fused_conv == 'auto' and ws['A_stale'] is False
     want, wlogits, WG = _torch_reference(ospec, batch, P)
     # losses: 1e-2 relative (bf16 operands against fp32)
     for k in ('decoder', 'aux'):
@@ -114,9 +122,11 @@ def test_full_graph_against_torch_cpu(name, B):
         ['%s cos %.5f ratio %.4f' % (k, c, r) for c, r, k in worst[:4]]))
 
 
-def test_cfg2_graph_against_bf16_emulating_oracle():
+@pytest.mark.parametrize('train', [False, True], ids=['dropout_off', 'dropout_on'])
+def test_cfg2_graph_against_bf16_emulating_oracle(train):
     """The same cfg2 graph (3 x 400 bidirectional, decoder 800, V = 1806, T = 400 -> 34 steps, K = 3072 conv) at B = 16 against the
-    NumPy oracle with the device's rounding points: the tight tolerances of test_gpu_parity.py."""
+    NumPy oracle with the device's rounding points: the tight tolerances of test_gpu_parity.py.  train=True: FF dropout 0.1 and
+    RNN dropout 0.5 on, Philox masks on both sides."""
     from test_gpu_parity import check_grad, LOSS_RTOL
     from ecog2txt_amd.engine import NetSpec
     kw, _, T, L = bench.CONFIGS['cfg2']
@@ -125,8 +135,8 @@ def test_cfg2_graph_against_bf16_emulating_oracle():
     P = _biases_off_zero(O.init_params(ospec, seed=5), 6)
     batch = bench.synth_batch(kw, B, T, L, seed=9)
     _ragged(batch, T, 200, seed=2)
-    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P)
-    want, cache = O.forward(P, ospec, batch, train=False, emulate_bf16=True)
+    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P, train=train)
+    want, cache = O.forward(P, ospec, batch, train=train, seed=5, emulate_bf16=True)
     for k in ('decoder', 'aux'):
         assert abs(losses[k] - want[k]) <= LOSS_RTOL * max(1.0, abs(want[k])), (k, losses, want)
     np.testing.assert_array_equal(ws['lens'].cpu().numpy(), cache['lens'])

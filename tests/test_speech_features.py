@@ -118,3 +118,31 @@ def test_sentence_tokenize_word_pieces(tmp_path, monkeypatch):
     assert g.get_class_list('text_sequence')[:3] == ['<pad>_', '<EOS>_', 'the_']
     g.token_type = 'word_sequence'
     assert g._sentence_tokenize(['The', 'cat']) == [b'the_', b'cat_']          # data_generators.py:468-473
+
+
+def test_waveform_generator_feeds_mfccs_of_its_waveforms(tmp_path, monkeypatch):
+    """SyntheticWaveformDataGenerator: `audio_sequence` = `_get_MFCC_features((block, trial), 1 / sampling_rate)` of the trial's
+    waveform, one frame per ECoG sample, no private keys in the examples (the records hold ecog / text / audio only)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from experiment_fixture import make_experiment
+    from ecog2txt_amd.data_generators import ECoGDataGenerator, SyntheticWaveformDataGenerator
+    from ecog2txt_amd.manifests import load_manifest
+    monkeypatch.setattr(ECoGDataGenerator, 'text_dir', str(tmp_path))
+    monkeypatch.setattr(SyntheticWaveformDataGenerator, 'trials_per_block', 3)
+    path = make_experiment(tmp_path, subject_ids=(401,), generator='SyntheticWaveformDataGenerator')
+    man = load_manifest(path)[401]
+    g = SyntheticWaveformDataGenerator(man, 401, max_samples=420)
+    exs = list(g._ecog_token_generator(1))
+    assert len(exs) == 3 and all(set(e) == {'ecog_sequence', 'text_sequence', 'audio_sequence'} for e in exs)
+    for k, e in enumerate(exs):
+        T = e['ecog_sequence'].shape[0]
+        assert e['audio_sequence'].shape == (T, 5)
+        rate, wav = g._get_wav_data((1, k))
+        assert rate == 16000 and abs(len(wav) - T / 200 * 16000) <= 1
+        want = F.mfcc_features(wav, rate, 0.02, 1 / 200.0, 26, 5)
+        n = min(T, want.shape[0])
+        np.testing.assert_allclose(e['audio_sequence'][:n], want[:n].astype(np.float32), rtol=1e-6)
+    # deterministic: a second generator object yields the same features
+    g2 = SyntheticWaveformDataGenerator(man, 401, max_samples=420)
+    np.testing.assert_array_equal(next(iter(g2._ecog_token_generator(1)))['audio_sequence'], exs[0]['audio_sequence'])
