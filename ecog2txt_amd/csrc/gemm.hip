@@ -1119,6 +1119,28 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     const bool rich_ep = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
     const GemmPlan pl = gemm_plan(tn, M, N, K, ep);
     const bool big = pl.tile == 256;
+    // Ragged edge of a large K-major product.  The weight gradient of a layer with D inputs is [x | 1]^T . dG: M = D + 1, and with
+    // D a multiple of 256 the ones column costs a whole extra row of 256 x 256 tiles (cfg4's dW_x, 2049 x 8192 x 8704: 9 x 32 tiles
+    // = 288 on 256 CUs -- two rounds or three K splits; measured 429 us against 257 for 2048 rows).  The few rows (columns) beyond
+    // the last full tile leave as a product of their own on the 128 x 128 split-K instance, behind the main product on the same
+    // stream (its slabs reuse the workspace).  A K-major sub-range of M (N) is a column offset of A (B) and a row (column) offset of C.
+    if (tn && big && pl.batch == 1 && !rich_ep && !(ep && ep->row_lens) && !p.lens) {
+        const int rm = M % 256, rn = N % 256;
+        const int elt = (ep && (ep->flags & E2T_GEMM_OUT_BF16)) ? 2 : 4;
+        if (rm > 0 && rm <= 32 && M > 256) {
+            e2t_gemm_epilogue e0 = *ep, e1 = *ep;
+            if (ep->last_col_out) e1.last_col_out = ep->last_col_out + (M - rm);
+            if (int rc = gemm_launch(true, A, lda, B, ldb, C, ldc, M - rm, N, K, &e0, stream)) return rc;
+            return gemm_launch(true, (const bf16_t*)A + (M - rm), lda, B, ldb, (char*)C + (size_t)(M - rm) * ldc * elt, ldc, rm, N, K, &e1, stream);
+        }
+        if (rn > 0 && rn <= 32 && N > 256) {
+            e2t_gemm_epilogue e0 = *ep, e1 = *ep;
+            e0.last_col_out = nullptr;
+            if (ep->bias) e1.bias = ep->bias + (N - rn);
+            if (int rc = gemm_launch(true, A, lda, B, ldb, C, ldc, M, N - rn, K, &e0, stream)) return rc;
+            return gemm_launch(true, A, lda, (const bf16_t*)B + (N - rn), ldb, (char*)C + (size_t)(N - rn) * elt, ldc, M, rn, K, &e1, stream);
+        }
+    }
     const int BM = pl.tile, BN = BM;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int batch = pl.batch;

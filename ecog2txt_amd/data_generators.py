@@ -325,7 +325,7 @@ class SyntheticWaveformDataGenerator(SyntheticSpeechDataGenerator):
                 feat = np.zeros((T, self.num_MFCC_features))
                 feat[:min(T, a.shape[0])] = a[:T]
                 if a.shape[0] and a.shape[0] < T:
-                    feat[a.shape[0]:] = a[-1]                    # (frame count and sample count differ by at most one frame)
+                    feat[a.shape[0]:] = a[-1]                    # (python_speech_features yields window/step - 1 fewer frames than ECoG samples: hold the last one)
                 feat[np.abs(feat).max(1) == 0] = 1e-3           # a genuine all-zero row would read as padding
                 out['audio_sequence'] = feat.astype(np.float32)
             yield out

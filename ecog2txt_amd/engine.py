@@ -776,10 +776,12 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         main(train)
         self.join_side(join)
 
-    def backward(self, ws, train=True, after_stage=None, early=None):
+    def backward(self, ws, train=True, after_stage=None, early=None, before_join=None):
         """early = {stage index: fn}: fn() is queued on the side stream right behind that stage's side work (the optimiser
         update of the parameter ranges whose gradients are complete by then: HBM-bound, next to the compute-bound
-        weight-gradient GEMMs of the remaining stages)."""
+        weight-gradient GEMMs of the remaining stages).  before_join(): queued on the main stream behind its last stage, in
+        front of the joins with the side stream (the update of the bottom layer, whose gradients the main chain produced
+        itself, runs while the side stream is still busy with the early update and its re-pack)."""
         ws['have_dy'] = [False] * len(self.enc)
         ws['_aux_join'] = None
         ws['fwd_train'] = train
@@ -806,6 +808,8 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         if ws.get('_aux_join') is not None:
             self.join_side(ws['_aux_join'])
             ws['_aux_join'] = None
+        if before_join is not None:
+            before_join()
         for j in deferred:
             self.join_side(j)
 
@@ -1131,8 +1135,18 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             self._pack_subtable(('skip',) + tuple(packed_early))
         with capture(g1):
             self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None)
-            self.backward(ws, train=True, early=early)
-            self.adam_step(ws['sid'], repack=False, skip_below=early_end)
+            if early:
+                # the rest (bottom layer, front-end) is updated on the main stream BEFORE it joins the side stream, which is
+                # still busy with the early update and its re-pack (cfg2: the step ended 30 us after the side stream did);
+                # like the early update it runs on the un-incremented step counter (step_offset = 1)
+                tail = [(max(a, early_end), b) for a, b in self.trainable_ranges(ws['sid']) if b > early_end]
+                self.backward(ws, train=True, early=early, before_join=lambda: self.adam_ranges(tail, step_offset=1))
+                lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
+                self._packed = None
+                self._img_early = None
+            else:
+                self.backward(ws, train=True)
+                self.adam_step(ws['sid'], repack=False, skip_below=early_end)
         return (g1, tuple(packed_early))
 
     def _capture_staged(self, ws, lazy, gc):

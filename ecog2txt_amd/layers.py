@@ -372,8 +372,11 @@ class _Lstm:
             e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.D,
                    rk(self.N4), out_bf16=True, alpha=d_in_alpha, mask_src=d_in_bf16_mask, alg=(M, self.D, self.N4))
         else:
-            e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M, self.in_ld,
-                   rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop, alg=(M, self.D, self.N4))
+            # (a dense input layout needs the D real columns only: in_ld = rk(D + 1) would cost cfg4's 8704 x 2112 x 8192 a ninth
+            #  column of 256-wide tiles for 64 padding columns nobody reads)
+            dense = all(k0 == r0 for (r0, n, k0) in self.in_blocks)
+            e.gemm(ws['dG'].data_ptr(), rk(self.N4), self.WxB.data_ptr(), rk(self.N4), d_in_ptr, d_in_ld, M,
+                   self.D if dense else self.in_ld, rk(self.N4), accumulate=d_in_accumulate, drop=d_in_drop, alg=(M, self.D, self.N4))
 
     def bwd_weights(self, ws, x_ptr):
         """dW_x (+ bias) and dW_h from the dG of bwd_rec.  Nothing downstream of the recurrence depends on it, so the

@@ -16,6 +16,7 @@ for step in "$@"; do
     bench3|bench4|bench5) c=cfg${step#bench}; timeout 900 python bench.py --config $c --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > $out/benchq_$c.json 2> $out/benchq_$c.err; head -c 300 $out/benchq_$c.json; echo;;
     prof2|prof4|prof5) c=cfg${step#prof}; n=30; [ $c = cfg2 ] && n=200; bash scripts/prof_cfg.sh $c $n > $out/prof_$c.log 2>&1; cp gpurun_out/prof_$c/summary.txt $out/${c}_summary.txt; cp gpurun_out/prof_$c/timeline.txt $out/${c}_timeline.txt; cp gpurun_out/prof_$c/b_kernel_stats.csv $out/${c}_kernel_stats.csv; head -22 $out/${c}_summary.txt;;
     py:*) f=${step#py:}; n=$(basename ${f%% *} .py); timeout 900 python $f > $out/$n.txt 2>&1; echo "rc=$?"; tail -40 $out/$n.txt;;
+    sh:*) c=${step#sh:}; echo "$c"; timeout 1500 bash -c "$c" 2>&1 | grep -v amdgpu.ids | tail -40;;
     t:*) t=${step#t:}; timeout 1800 python -m pytest $t -x -q -m gpu > $out/pytest_sel.log 2>&1; echo "pytest rc=$?" >> $out/pytest_sel.log; tail -15 $out/pytest_sel.log;;
     *) echo "unknown step $step";;
   esac

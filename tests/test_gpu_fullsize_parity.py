@@ -142,9 +142,25 @@ def test_cfg2_graph_against_bf16_emulating_oracle(train):
     np.testing.assert_array_equal(ws['lens'].cpu().numpy(), cache['lens'])
     np.testing.assert_allclose(logits, cache['dec']['logits'], atol=3e-2, rtol=1e-2)
     WG = O.backward(P, cache)
+    if train:
+        # the oracle's own distance between its bf16 mode and the exact fp64 spec: the yardstick of the dropout-on leg
+        _, cache_x = O.forward(P, ospec, batch, train=True, seed=5, emulate_bf16=False)
+        XG = O.backward(P, cache_x)
+    rl2 = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-12))
     for k in sorted(WG):
         # 54 400 conv activations here (16 utterances x 34 steps x 100 units) against ~2 000 in the small cases: a few units sit
         # on the ReLU knife edge, each moving one column (1 %) of the conv weight gradient
         # ... and 1.7 M input projections per layer are rounded to bf16 (544 per bias element): two or three entries of a 1600-entry
         # bias gradient beyond 5e-3 (measured 6.3e-3 at most)
-        check_grad(k, G[k], WG[k], relu_outliers=4e-2, flip_outliers=3e-3)
+        if not train:
+            check_grad(k, G[k], WG[k], relu_outliers=4e-2, flip_outliers=3e-3)
+            continue
+        # dropout on (scripts/diag_fullsize_dropout.py): every kept activation carries 1 / keep = 2x, so a 1-ulp bf16 flip or a
+        # flipped ReLU unit of the 225-wide auxiliary layer weighs twice as much in everything below the tapped layer -- relative
+        # L2 error of the layer-0 / layer-1 gradients 7e-3 .. 1.0e-2 (5e-3 .. 7e-3 with dropout off; the top layer and the
+        # decoder, which no ReLU feeds, stay at 1e-3), 1.8 % of a bias gradient's entries beyond 5e-3.  Two checks: the bands of
+        # test_gpu_parity.py widened by that factor (largest error still < 2e-2 / 5e-2), and the HIP path must be CLOSER to the
+        # bf16-emulating oracle than 0.6 of that oracle's own distance from the exact fp64 spec (measured: 0.2 .. 0.46)
+        check_grad(k, G[k], WG[k], relu_outliers=1e-1, flip_outliers=3e-2, l2_scale=1.5)
+        band = rl2(XG[k], WG[k])
+        assert rl2(G[k], WG[k]) <= max(0.6 * band, 2e-3), (k, rl2(G[k], WG[k]), band)

@@ -347,24 +347,31 @@ def test_softmax_ce(hl):
     np.testing.assert_allclose(host(dl)[:, :V], want, rtol=2 ** -7, atol=1e-7)
 
 
-def test_adam_ema_matches_oracle(hl):
+@pytest.mark.parametrize('n,off', [(1000, 0), (1003, 1), (2, 3), (4099, 2), (5, 0)])
+def test_adam_ema_matches_oracle(hl, n, off):
+    """(off: element offset of the range inside its buffers -- the 16-B body of the kernel is framed by a scalar head and tail)"""
     rng = np.random.default_rng(1)
-    n = 1000
     p0, g1, g2 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
     P, state = {'w': p0.copy()}, {}
     for g in (g1, g2):
         O.adam_ema_step(P, {'w': g}, state, lr=1e-2)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda')
-    p, m, v, ema = t(p0), t(np.zeros(n)), t(np.zeros(n)), t(p0)
+    pad = lambda a: np.concatenate([np.full(off, 9.0), a, np.full(7, 9.0)])
+    p, m, v, ema = t(pad(p0)), t(pad(np.zeros(n))), t(pad(np.zeros(n))), t(pad(p0))
     step = torch.zeros(1, dtype=torch.int32, device='cuda')
     h = hl.AdamHyper(1e-2, 0.9, 0.999, 1e-8, 0.99, 1.0)
+    o = 4 * off
     for g in (g1, g2):
         hl.lib.e2t_inc_step(step.data_ptr(), None, st())
-        hl.lib.e2t_adam_ema_step(p.data_ptr(), t(g).data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n,
+        gt = t(pad(g))
+        hl.lib.e2t_adam_ema_step(p.data_ptr() + o, gt.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, ema.data_ptr() + o, n,
                                  step.data_ptr(), C.byref(h), st())
     torch.cuda.synchronize()
-    np.testing.assert_allclose(host(p), P['w'], rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(host(ema), state['ema']['w'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(host(p)[off:off + n], P['w'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(host(ema)[off:off + n], state['ema']['w'], rtol=2e-5, atol=1e-6)
+    for a in (p, ema):                          # nothing outside the range is touched
+        assert np.all(host(a)[:off] == 9.0) and np.all(host(a)[off + n:] == 9.0)
+    assert np.all(host(m)[:off] == 9.0) and np.all(host(m)[off + n:] == 9.0)
 
 
 @pytest.mark.parametrize('M,N,K', [(101, 200, 8704), (401, 130, 2560), (5, 14, 1040), (130, 70, 40)])
@@ -564,6 +571,34 @@ def test_gemm_tn_256_tile_instance(hl, M, N, K, nb):
         want = round_bf16(A[:, z * r8(M):z * r8(M) + M]).T @ round_bf16(Bm[:, z * r8(N):z * r8(N) + N])
         np.testing.assert_allclose(got[z][:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
         assert np.all(got[z][:, N:] == 7.0)
+
+
+@pytest.mark.parametrize('M,N,K', [(2049, 1793, 1500), (1812, 2305, 1100), (2049, 2054, 1100)])
+def test_gemm_tn_256_ragged_edge_leaves_as_its_own_product(hl, M, N, K):
+    """A large K-major product whose M (N) ends a few rows (columns) behind a multiple of 256 -- [x | 1]^T . dG with the ones column
+    -- is launched as the full tiles + an edge product: same result as one product, incl. the bias-column diversion
+    (last_col_out), accumulation onto C and alpha."""
+    rng = np.random.default_rng(M * 3 + N)
+    lda, ldb = r8(M) + 8, r8(N)
+    A = rng.standard_normal((K, lda)); Bm = rng.standard_normal((K, ldb))
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    wsb = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue(); ep.alpha = 0.5
+    ep.flags = hl.GEMM_SPLITK | hl.GEMM_ACCUMULATE
+    ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    lc = torch.full((M,), 3.0, dtype=torch.float32, device='cuda')
+    ep.last_col_out = lc.data_ptr()
+    tile = C.c_int(0)
+    hl.lib.e2t_gemm_plan(1, M, N, K, C.byref(ep), C.byref(tile), None)
+    assert tile.value == 256
+    ldc = N - 1
+    c0 = rng.standard_normal((M, ldc)).astype(np.float32)
+    c = torch.from_numpy(c0.copy()).cuda()
+    hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc, M, N, K, C.byref(ep), st())
+    torch.cuda.synchronize()
+    want = 0.5 * (round_bf16(A[:, :M]).T @ round_bf16(Bm[:, :N]))
+    np.testing.assert_allclose(host(c), c0 + want[:, :N - 1], rtol=1e-5, atol=1e-4 * np.sqrt(K))
+    np.testing.assert_allclose(host(lc), want[:, N - 1], rtol=1e-5, atol=1e-4 * np.sqrt(K))
 
 
 @pytest.mark.parametrize('G', [1, 2, 3])

@@ -34,7 +34,7 @@ def relu_class(name):
     return 'encoder_embedding' in name or ('_projection_' in name)
 
 
-def check_grad(name, got, want, relu_outliers=1e-2, flip_outliers=1e-3):
+def check_grad(name, got, want, relu_outliers=1e-2, flip_outliers=1e-3, l2_scale=1.0):
     scale = np.abs(want).max() + 1e-12
     err = np.abs(got - want) / scale
     outliers = (err > GRAD_TOL).mean()
@@ -43,13 +43,13 @@ def check_grad(name, got, want, relu_outliers=1e-2, flip_outliers=1e-3):
         # at most 1 % of the entries (one unit; three entries of a small bias vector) beyond 5e-3, none beyond 5e-2
         # (relu_outliers: the share grows with the number of activations -- every flipped unit moves one weight column)
         assert outliers <= max(relu_outliers, 3.0 / err.size) and err.max() < 5e-2, (name, float(err.max()), float(outliers))
-        assert rel_l2 < 2e-2, (name, float(rel_l2))
+        assert rel_l2 < 2e-2 * l2_scale, (name, float(rel_l2))
     else:
         # recurrent kernels, embeddings, linear layers: at most 0.1 % of the entries beyond 5e-3 (1-ulp bf16 flips amplified
         # through BPTT), none beyond 2e-2.  (flip_outliers: the share grows with the number of bf16 values rounded on the way --
         # input projections, states, gate gradients: ~4e-4 of them lie within fp32 round-off of a rounding boundary)
         assert outliers <= max(flip_outliers, 1.0 / err.size) and err.max() < 2e-2, (name, float(err.max()), float(outliers))
-        assert rel_l2 < 1e-2, (name, float(rel_l2))
+        assert rel_l2 < 1e-2 * l2_scale, (name, float(rel_l2))
 
 
 def build(spec_kw, B, T, L, seed=0, ragged=True, engine_seed=11):
