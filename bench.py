@@ -166,7 +166,7 @@ def synth_batch_device(spec_kw, sid, B, T, L, seed, device):
     return X, torch.as_tensor(Y, device=device), A
 
 
-def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory, roofline, device_data=False, batch=None):
+def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory, roofline, device_data=False, batch=None, inputs='fp32'):
     """One configuration: engine, synthetic batch resident in HBM, `warmup` untimed + `steps` timed train steps (barrier +
     synchronize on both sides, max over ranks), and -- on rank 0 -- the live roofline legs.  Returns the dict of the line."""
     import torch
@@ -201,6 +201,21 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
             eng.set_global_counts(ws, int(cnt[0]), int(cnt[1]))
         wss.append(ws)
     torch.cuda.synchronize()
+    staging_ms = None
+    if inputs == 'bf16':
+        # SURVEY.md 8 d4 "bf16 in": the inputs are staged ONCE (per fit) as the bf16 im2row rows of the front-end
+        # (Seq2SeqEngine.pack_inputs, timed here) and stay resident in that form; a step's operand is assembled from them by a
+        # blocked row gather (load_packed_batch; outside the timed region, like the gather of the fp32 form)
+        t0 = time.perf_counter()
+        for ws in wss:
+            ws['_pk'] = eng.pack_inputs(ws['sid'], ws['X'])
+        torch.cuda.synchronize()
+        staging_ms = 1e3 * (time.perf_counter() - t0)
+        ident = torch.arange(B, dtype=torch.int32, device=device)
+        for ws in wss:
+            eng.load_packed_batch(ws, ws.pop('_pk'), ident)
+            ws['X'].fill_(float('nan'))                     # (no step may read x from here on)
+        torch.cuda.synchronize()
     it = [0]
 
     def step():
@@ -315,9 +330,12 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
         out = dict(metric='train utterances/sec', value=round(utt, 2), unit='utterances/s', n_gpus=world, steps=steps,
                    warmup=warmup, ms_per_step=round(1e3 * el / steps, 4), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload='%s: %d subject(s), %s electrodes x %d samples (fp32 inputs resident in HBM), B=%d/GPU, conv%d -> %dx biLSTM(%d) -> LSTM(%d) -> %d words, L=%d, Adam+EMA'
-                               % (cfg_name, len(sids), chans, T, B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
-                                  spec.dec_rnn, spec.vocab, L), global_batch=B * world, parallelism='dp%d' % world,
+                   config=dict(workload='%s: %d subject(s), %s electrodes x %d samples (%s), B=%d/GPU, conv%d -> %dx biLSTM(%d) -> LSTM(%d) -> %d words, L=%d, Adam+EMA'
+                               % (cfg_name, len(sids), chans, T,
+                                  'fp32 inputs resident in HBM' if inputs == 'fp32' else
+                                  'inputs resident in HBM as bf16 im2row rows, staged once from fp32 in %.1f ms' % staging_ms,
+                                  B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
+                                  spec.dec_rnn, spec.vocab, L), inputs=inputs, global_batch=B * world, parallelism='dp%d' % world,
                                hipgraph=not args.no_graph, exchange=(type(sync).__name__ if sync is not None else None)),
                    recurrent_gemm_tflops=round(rec, 3), recurrent_gemm_frac_of_peak=round(rec / MFMA_BF16_PEAK_TFLOPS / world, 5),
                    final_loss=round(losses['total'], 4), recurrence=extra, roofline=roof,
@@ -338,6 +356,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='cfg2', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default: the config\'s 256)')
+    ap.add_argument('--inputs', default='fp32', choices=['fp32', 'bf16'],
+                    help='how the inputs are resident in HBM: fp32 [B][T][C] (default, the headline form) or the bf16 im2row rows of the front-end (SURVEY 8 d4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -372,16 +392,17 @@ def main():
         return parallel.make_sync(eng.store.g)
 
     out, sync = measure(args.config, args, args.steps, args.warmup, rank, world, dev_index, sync_factory if world > 1 else None,
-                        roofline=not args.no_roofline, batch=args.batch)
+                        roofline=not args.no_roofline, batch=args.batch, inputs=args.inputs)
     if rank == 0:
         # The other BASELINE.json configurations, measured in the SAME process on one GPU (10 warm-up + 20 timed steps each,
         # synthetic inputs generated on the device): cfg3 (4 participants in turn), cfg4 (wide model), cfg5 (long / wide input).
         if world == 1 and args.config == 'cfg2' and args.batch is None and not args.no_configs:
             block = {}
-            for c in ('cfg3', 'cfg4', 'cfg5'):
+            for c in ('cfg3', 'cfg4', 'cfg5', 'cfg5_bf16_staged'):
                 t0 = time.perf_counter()
                 try:
-                    o, _ = measure(c, args, 20, 10, 0, 1, dev_index, None, roofline=not args.no_roofline, device_data=True)
+                    o, _ = measure(c.replace('_bf16_staged', ''), args, 20, 10, 0, 1, dev_index, None, roofline=not args.no_roofline, device_data=True,
+                                   inputs='bf16' if c.endswith('_bf16_staged') else 'fp32')
                 except Exception as e:                     # the headline line must not die with a side configuration
                     block[c] = dict(error=repr(e)[:300])
                     continue

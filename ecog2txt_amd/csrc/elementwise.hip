@@ -782,9 +782,15 @@ __global__ __launch_bounds__(256) void k_fill_u32(unsigned* dst, size_t n, unsig
 // per destination row; idx < 0 (or beyond the list) = padding utterance: the row is zero-filled, which is exactly what
 // the length kernels read as "no samples".  16-B accesses when the row size allows, HBM-bound copy.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_rows(const unsigned* src, const int* idx, int n, size_t row_words, unsigned* dst) {
+// blockIdx.z = block: the same row selection applied to `gridDim.z` equally shaped blocks of rows (bf16-staged inputs: block t'
+// holds decimated step t' of every utterance of a partition, the batch's rows of that step are gathered into block t' of the
+// time-major operand)
+__global__ __launch_bounds__(256) void k_gather_rows(const unsigned* src, const int* idx, int n, size_t row_words, unsigned* dst,
+                                                      size_t src_block_words, size_t dst_block_words) {
     const int r = blockIdx.y;
     const int i = (r < n) ? idx[r] : -1;
+    src += (size_t)blockIdx.z * src_block_words;
+    dst += (size_t)blockIdx.z * dst_block_words;
     unsigned* d = dst + (size_t)r * row_words;
     const unsigned* sp = (i >= 0) ? src + (size_t)i * row_words : nullptr;
     const bool v4 = (row_words & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
@@ -818,7 +824,20 @@ extern "C" int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, i
     if (rows_out == 0 || row_words == 0) return E2T_OK;
     size_t per = ((row_words & 3) == 0 ? row_words >> 2 : row_words);
     unsigned bx = (unsigned)((per + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(k_gather_rows, dim3(bx, rows_out), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src, idx, n, row_words, (unsigned*)dst);
+    hipLaunchKernelGGL(k_gather_rows, dim3(bx, rows_out), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src, idx, n, row_words, (unsigned*)dst,
+                       (size_t)0, (size_t)0);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_gather_rows_blocks_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, int blocks,
+                                          size_t src_block_words, size_t dst_block_words, void* dst, void* stream) {
+    E2T_CHECK_ARG(src && dst && (idx || n == 0) && n >= 0 && rows_out >= n && blocks >= 0 && blocks <= 65535);
+    E2T_CHECK_ARG(dst_block_words >= (size_t)rows_out * row_words);
+    E2T_CHECK_ARG((row_words & 3) != 0 || ((src_block_words | dst_block_words) & 3) == 0);      // 16-B rows stay 16-B aligned in every block
+    if (rows_out == 0 || row_words == 0 || blocks == 0) return E2T_OK;
+    size_t per = ((row_words & 3) == 0 ? row_words >> 2 : row_words);
+    unsigned bx = (unsigned)((per + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_gather_rows, dim3(bx, rows_out, blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src, idx, n, row_words,
+                       (unsigned*)dst, src_block_words, dst_block_words);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream) {

@@ -396,12 +396,52 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
 
     def set_batch(self, ws, batch):
         self.check_end_padded(batch['encoder_inputs'])
+        ws['packed'] = False
         ws['X'].copy_(torch.as_tensor(np.asarray(batch['encoder_inputs']), dtype=torch.float32))
         ws['Y'].copy_(torch.as_tensor(np.asarray(batch['decoder_targets']), dtype=torch.int32))
         if self.aux and 'encoder_targets' in batch:
             ws['auxT'].copy_(torch.as_tensor(np.asarray(batch['encoder_targets']), dtype=ws['auxT'].dtype))
         for wx, tg in zip(ws['auxx'], batch.get('encoder_targets_extra') or []):
             wx['T'].copy_(torch.as_tensor(np.asarray(tg), dtype=wx['T'].dtype))
+
+    # ------------------------------------------------------------------ bf16-staged inputs ("bf16 in")
+    def packed_inputs_ok(self, sid):
+        """bf16-staged inputs exist for a single-layer front-end (the im2row rows of a conv stack are in grouped order)."""
+        return len(self.conv[sid]) == 1
+
+    def pack_inputs(self, sid, X):
+        """Stage a partition once per fit: X (device, fp32 [n][T][C], end-padded: trainers.py:808-818, subjects.py:386-390) ->
+        the bf16 im2row rows the front-end multiplies -- time-reversed over each utterance's valid prefix, N samples per row, the
+        ones column at N*C, zero beyond the length: exactly what e2t_conv_pack writes per step, so every later result is
+        bit-identical to the fp32-staged path -- as PA [S][n][rk(N*C + 1)] (block t' = decimated step t' of every utterance),
+        plus the lengths.  A step then reads 2 B per input sample (forward product) + 2 B (conv weight gradient) instead of
+        4 B + 2 B written + 2 B read; load_packed_batch() assembles a batch's operand with one blocked row gather."""
+        assert self.packed_inputs_ok(sid), 'bf16-staged inputs: single-layer temporal convolution only'
+        s, dev = self.spec, self.device
+        assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 3 and X.shape[2] == s.channels[sid]
+        n, T, Cc = (int(v) for v in X.shape)
+        N = s.decimation
+        S, Kc8 = ceil_div(T, N), rk(N * Cc + 1)
+        lens, lens_d = _i32(n, device=dev), _i32(n, device=dev)
+        PA = torch.empty(S, n, Kc8, dtype=torch.bfloat16, device=dev)       # (every element is written: zero fill + ones column)
+        st = self.stream
+        lib.e2t_seq_lengths_tail_f32(X.data_ptr(), n, T, Cc, N, lens.data_ptr(), lens_d.data_ptr(), st)
+        lib.e2t_conv_pack(X.data_ptr(), lens.data_ptr(), n, T, Cc, N, PA.data_ptr(), Kc8, st)
+        return dict(PA=PA, lens=lens, lens_d=lens_d, n=n, S=S, T=T, Kc8=Kc8, sid=sid)
+
+    def load_packed_batch(self, ws, pk, idx_dev):
+        """Rows idx_dev (device int32 [B]; -1 = padding utterance) of a pack_inputs() partition into the workspace: the
+        time-major conv operand ws['A'] (one blocked gather: block t' of PA -> rows t'*B .. of A) and both length vectors.
+        The front-end of the following forward passes starts at the product (no lengths pass, no pack, no x)."""
+        B, S = ws['B'], ws['S']
+        assert pk['S'] == S and pk['Kc8'] == ws['Kc8'] and pk['sid'] == ws['sid'] and ws['G0'] == 1
+        rw = ws['Kc8'] // 2                         # 32-bit words per row
+        st = self.stream
+        lib.e2t_gather_rows_blocks_u32(pk['PA'].data_ptr(), idx_dev.data_ptr(), B, B, rw, S, pk['n'] * rw, B * rw, ws['A'].data_ptr(), st)
+        lib.e2t_gather_rows_u32(pk['lens'].data_ptr(), idx_dev.data_ptr(), B, B, 1, ws['lens'].data_ptr(), st)
+        lib.e2t_gather_rows_u32(pk['lens_d'].data_ptr(), idx_dev.data_ptr(), B, B, 1, ws['lens_d'].data_ptr(), st)
+        ws['packed'] = True
+        ws['A_stale'] = False
 
     def set_global_counts(self, ws, ntok, nval=0, nval_extra=()):
         """Data parallel: the batch's token count and auxiliary-sample count(s) over ALL ranks (host integers; every rank
@@ -434,16 +474,19 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         s = self.spec
         B, T, S, M, Cc, N = ws['B'], ws['T'], ws['S'], ws['M'], ws['C'], s.decimation
         st = self.stream
+        packed = bool(ws.get('packed'))       # bf16-staged inputs (load_packed_batch): ws['A'] and the lengths are the batch
         # (searched from the tail: end-padded batches only -- subjects.py:386-390; set_batch / the staging code check that)
-        lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
+        if not packed:
+            lib.e2t_seq_lengths_tail_f32(ws['X'].data_ptr(), B, T, Cc, N, ws['lens'].data_ptr(), ws['lens_d'].data_ptr(), st)
         if after_first is not None:
             after_first()
         stack = len(self.conv[ws['sid']]) > 1
+        assert not (stack and packed)
         fused = (self.fused_conv == '1' or (self.fused_conv == 'auto' and B * T * Cc * 4 >= (1 << 28))) \
-            and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed)) and not stack
+            and bool(H.load().e2t_conv_fwd_fused_ok(Cc, s.enc_embed)) and not stack and not packed
         if stack:
             self._conv_stack_fwd(ws, src, train, before_weights)
-        elif not fused:
+        elif not fused and not packed:
             lib.e2t_conv_pack(ws['X'].data_ptr(), ws['lens'].data_ptr(), B, T, Cc, N, ws['A'].data_ptr(), ws['Kc8'], st)
         ws['A_stale'] = fused and not train   # (inference through the fused kernel leaves no im2row copy; a backward pass after it packs first)
         if before_weights is not None and not stack:
@@ -1060,7 +1103,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             return
         # the captured Adam launches bake in the trainable ranges and the gradient scale
         key = ('train_dp' if dp else 'train', gc, tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
-               tuple(sorted(self.hyper.items())))
+               tuple(sorted(self.hyper.items())), bool(ws.get('packed')))
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture

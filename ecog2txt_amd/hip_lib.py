@@ -57,6 +57,7 @@ _p, _i, _f, _l, _z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 SIGNATURES = {
     'e2t_fill_u32': [_p, _z, C.c_uint32, _p],
     'e2t_gather_rows_u32': [_p, _p, _i, _i, _z, _p, _p],
+    'e2t_gather_rows_blocks_u32': [_p, _p, _i, _i, _z, _i, _z, _z, _p, _p],
     'e2t_seq_lengths_f32': [_p, _i, _i, _i, _i, _p, _p, _p],
     'e2t_seq_lengths_tail_f32': [_p, _i, _i, _i, _i, _p, _p, _p],
     'e2t_seq_lengths_i32': [_p, _i, _i, _i, _i, _p, _p, _p],

@@ -76,7 +76,11 @@ class SequenceNetwork:
                  TEMPORALLY_CONVOLVE=None, EMA_decay=None, beam_width=None, assessment_epoch_interval=None,
                  tf_summaries_dir=None, N_epochs=None, temperature=None, N_cases=256, learning_rate=5e-4,
                  max_hyp_length=20, seed=0, assessment_GPU=0, checkpoint_path='./model.ckpt', inputs_to_occlude=None,
-                 process_group=None, encoder_strides=None):
+                 process_group=None, encoder_strides=None, input_staging='auto'):
+        # input_staging: how a fit keeps its training partitions in HBM -- 'fp32' as padded [n][T][C] arrays (a step reads 4 B per
+        # input sample and packs them itself), 'bf16' as the bf16 im2row rows of the temporal convolution, made once per fit
+        # (Seq2SeqEngine.pack_inputs: 2 B per sample, same bits as the per-step pack), 'auto' = bf16 for HBM-sized batches
+        # (>= 256 MiB of fp32 per batch: BASELINE.json's 1024-electrode x 2000-sample configuration), fp32 otherwise
         self._engine = None
         self._engine_key = None
         self._epoch = 0
@@ -207,20 +211,42 @@ class SequenceNetwork:
                 data['dev']['Ax'] = [torch.from_numpy(a).to(eng.device) for a in data.get('Ax', [])]
         return data['dev']
 
-    def _load_batch(self, eng, ws, data, idx, idx_dev=None):
+    def _pack_partition(self, eng, sid, data):
+        """bf16-staged inputs of a training partition (input_staging), made once per fit from the resident fp32 array; None
+        where the fp32 form stays (small batches, a conv stack, a partition too large to keep resident)."""
+        if data is None or 'packed' in data:
+            return None if data is None else data['packed']
+        data['packed'] = None
+        mode = self.input_staging or 'auto'
+        assert mode in ('auto', 'fp32', 'bf16'), 'input_staging must be auto, fp32 or bf16'
+        big = self.N_cases * data['T'] * data['X'].shape[2] * 4 >= (1 << 28)
+        if mode == 'fp32' or (mode == 'auto' and not big) or not eng.packed_inputs_ok(sid):
+            return None
+        dev = self._resident(eng, data)
+        if dev is not None:
+            data['packed'] = eng.pack_inputs(sid, dev['X'])
+        return data['packed']
+
+    def _load_batch(self, eng, ws, data, idx, idx_dev=None, packed=None):
         """Batch rows `idx` (host index array; -1 = padding utterance) into the workspace.  idx_dev: the same indices
-        already on the device (an epoch's plan is uploaded once), so the step issues no host->device copy at all."""
+        already on the device (an epoch's plan is uploaded once), so the step issues no host->device copy at all.
+        packed: the partition's bf16-staged inputs (_pack_partition) -- the conv operand is gathered instead of x."""
         import torch
         from .hip_lib import lib
         B = ws['B']
         dev = self._resident(eng, data)
+        ws['packed'] = False
         if dev is not None:
             if idx_dev is None:
                 full = np.full(B, -1, np.int32)
                 full[:len(idx)] = idx
                 idx_dev = torch.from_numpy(full).to(eng.device)
             st = eng.stream
-            pairs = [(dev['X'], ws['X']), (dev['Y'], ws['Y'])]
+            pairs = [(dev['Y'], ws['Y'])]
+            if packed is not None:
+                eng.load_packed_batch(ws, packed, idx_dev)
+            else:
+                pairs.append((dev['X'], ws['X']))
             if 'A' in dev and eng.aux is not None:
                 pairs.append((dev['A'], ws['auxT']))
             pairs += [(a, wx['T']) for a, wx in zip(dev.get('Ax', []), ws['auxx'])]
@@ -307,14 +333,14 @@ class SequenceNetwork:
                     mine = rank_slice(g, B, rank, world, d.get('xlen'))
                     idx[k, :len(mine)] = mine
                     cnt[k] = [d['tok'][g].sum(), d['val'][g].sum()] + [v[g].sum() for v in d.get('valx', [])]
-                plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt))
+                plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt, self._pack_partition(eng, s.subnet_id, d)))
             ws = None
             for k in range(max((len(p[2]) for p in plans), default=0)):      # round-robin over subjects ('parallel' learning)
-                for sid, d, idx, idx_dev, cnt in plans:
+                for sid, d, idx, idx_dev, cnt, pk in plans:
                     if k >= len(idx):
                         continue
                     ws = eng.workspace(sid, B, d['T'], d['L'])
-                    self._load_batch(eng, ws, d, idx[k], idx_dev[k])
+                    self._load_batch(eng, ws, d, idx[k], idx_dev[k], packed=pk)
                     if sync is not None:
                         eng.set_global_counts(ws, int(cnt[k, 0]), int(cnt[k, 1]), [int(v) for v in cnt[k, 2:]])
                     eng.train_step(ws, sync=sync)
@@ -496,6 +522,7 @@ class SequenceNetwork:
             x = x[None] if x.ndim == 2 else x
             B, T = x.shape[0], -(-x.shape[1] // N) * N
             ws = eng.workspace(subject.subnet_id, B, T, L)
+            ws['packed'] = False
             ws['X'].zero_()
             ws['X'][:, :x.shape[1]].copy_(torch.from_numpy(np.ascontiguousarray(x)))
             ws['Y'].zero_()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 5
+#define E2T_ABI_VERSION 6
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -58,6 +58,12 @@ typedef struct e2t_dropout {
 /* dst[0..n) = value (32-bit words; fp32 0.0 is word 0) */
 int e2t_fill_u32(void* dst, size_t n, uint32_t value, void* stream);
 int e2t_gather_rows_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, void* dst, void* stream);
+/* ABI 6: the same row selection applied to `blocks` equally shaped blocks of rows -- block t of dst (dst_block_words apart) row r =
+ * block t of src (src_block_words apart) row idx[r].  Batch assembly from a partition whose inputs are staged as the bf16 im2row
+ * rows of e2t_conv_pack (block = decimated step t', one row per utterance: SURVEY.md 8 d4 "bf16 in"; reference input contract
+ * trainers.py:808-818, subjects.py:386-390): the time-major conv operand of a batch is gathered in one launch. */
+int e2t_gather_rows_blocks_u32(const void* src, const int32_t* idx, int n, int rows_out, size_t row_words, int blocks,
+                               size_t src_block_words, size_t dst_block_words, void* dst, void* stream);
 
 /* ---- a4: nn.sequences_tools (trainers.py:789-790, 806-807) ---- */
 int e2t_seq_lengths_f32(const float* x, int B, int T, int C, int div, int32_t* lens, int32_t* lens_div, void* stream);

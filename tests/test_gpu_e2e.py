@@ -131,6 +131,34 @@ def test_readme_flow_learns(small):
     assert res_tf['validation'].accuracy == res['validation'].accuracy
 
 
+def test_fit_with_bf16_staged_inputs_equals_the_fp32_staged_fit(small):
+    """`input_staging='bf16'` (SURVEY.md 8 d4 'bf16 in'; reference input contract trainers.py:808-818): the training partition
+    is staged once as the bf16 im2row rows of the front-end and a step gathers its operand from them -- the fit ends with the
+    same weights, losses and hypotheses as the fp32-staged fit (same bits into every product)."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    out = {}
+    for mode in ('fp32', 'bf16'):
+        path = make_experiment(small / mode, subject_ids=(401,), epochs=6, interval=3)
+        ck = str(small / mode / 'ck'); os.makedirs(ck)
+        tr = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False,
+                                 SN_kwargs={'N_cases': 32, 'learning_rate': 3e-3, 'FF_dropout': 0.1, 'RNN_dropout': 0.1, 'EMA_decay': 0.9,
+                                            'input_staging': mode},
+                                 DG_kwargs={'max_samples': 420})
+        for s in tr.ecog_subjects:
+            s.write_tf_records_maybe()
+        a = tr.parallel_transfer_learn()
+        z = np.load(os.path.join(ck, 'model.ckpt-6.npz'))
+        out[mode] = (a, {k: z[k] for k in z.files})
+    (a0, z0), (a1, z1) = out['fp32'], out['bf16']
+    assert [l['decoder'] for l in a0['training'].losses] == [l['decoder'] for l in a1['training'].losses]
+    assert a0['validation'].hypotheses == a1['validation'].hypotheses
+    for k in z0:
+        if 'decoder_embedding' in k or k.startswith('__'):   # (scatter-add of fp32 atomics: any order; '__adam_*' = whole-store arrays)
+            np.testing.assert_allclose(z0[k], z1[k], atol=1e-5)
+        else:
+            assert np.array_equal(z0[k], z1[k]), k
+
+
 def test_sequential_transfer_and_resume(small):
     from ecog2txt_amd.trainers import MultiSubjectTrainer
     path = make_experiment(small, subject_ids=(400, 401), epochs=2, interval=1)

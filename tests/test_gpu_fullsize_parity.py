@@ -83,16 +83,34 @@ def _biases_off_zero(P, seed):
     return P
 
 
-@pytest.mark.parametrize('name,B', [('cfg2', 256), ('cfg4', 64), ('cfg5', 64)])
+def _stage_bf16(eng, ws):
+    """The batch as bf16-staged inputs (Seq2SeqEngine.pack_inputs / load_packed_batch: SURVEY.md 8 d4 'bf16 in'), rows in a
+    shuffled partition with padding utterances in between, as a fit assembles them."""
+    B = ws['B']
+    rng = np.random.default_rng(5)
+    n = B + 9
+    where = rng.permutation(n)[:B]                       # utterance b of the batch is row where[b] of the partition
+    Xp = torch.zeros(n, ws['T'], ws['C'], device='cuda')
+    Xp[torch.from_numpy(where).cuda()] = ws['X']
+    pk = eng.pack_inputs(ws['sid'], Xp)
+    ws['X'].fill_(float('nan'))                           # the step must not touch x any more
+    eng.load_packed_batch(ws, pk, torch.from_numpy(where.astype(np.int32)).cuda())
+
+
+@pytest.mark.parametrize('name,B', [('cfg2', 256), ('cfg4', 64), ('cfg5', 64), ('cfg5_bf16_staged', 64)])
 def test_full_graph_against_torch_cpu(name, B):
+    staged = name.endswith('_bf16_staged')
+    name = name.replace('_bf16_staged', '')
     kw, _, T, L = bench.CONFIGS[name]
     from ecog2txt_amd.engine import NetSpec
     ospec = O.NetSpec(**NetSpec(**kw).as_dict())
     P = _biases_off_zero(O.init_params(ospec, seed=3), 4)
     batch = bench.synth_batch(kw, B, T, L, seed=7)
     _ragged(batch, T, 240, seed=1)
-    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P)
-    if name == 'cfg5':
+    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P, prepare=_stage_bf16 if staged else None)
+    if staged:
+        assert ws['packed'] and torch.isnan(ws['X']).all()
+    elif name == 'cfg5':
         # the engine took the one-pass front-end (e2t_conv_fwd_fused), as it does at B = 256: the batch is HBM-sized (524 MB)
         assert B * T * kw['channels'][401] * 4 >= (1 << 28) and eng.fused_conv == 'auto' and ws['A_stale'] is False
     want, wlogits, WG = _torch_reference(ospec, batch, P)

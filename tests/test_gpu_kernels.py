@@ -484,6 +484,26 @@ def test_gather_rows_assembles_a_batch_with_padding_rows(hl, row_words):
     np.testing.assert_array_equal(dst.cpu().numpy(), want)
 
 
+def test_gather_rows_in_blocks(hl):
+    """e2t_gather_rows_blocks_u32: the row selection of e2t_gather_rows_u32 applied to every block (bf16-staged inputs: block =
+    decimated step, row = utterance)."""
+    rng = np.random.default_rng(2)
+    n_src, rows_out, n, rw, blocks = 23, 8, 6, 12, 5
+    src = rng.integers(1, 2 ** 31, size=(blocks, n_src, rw), dtype=np.int64).astype(np.int32)
+    idx = np.array([3, -1, 22, 0, 7, 7], np.int32)
+    dst = torch.full((blocks, rows_out + 2, rw), 5, dtype=torch.int32, device='cuda')
+    d_src, d_idx = torch.from_numpy(src).cuda(), torch.from_numpy(idx).cuda()
+    hl.lib.e2t_gather_rows_blocks_u32(d_src.data_ptr(), d_idx.data_ptr(), n, rows_out, rw, blocks, n_src * rw, (rows_out + 2) * rw,
+                                      dst.data_ptr(), st())
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    for t in range(blocks):
+        for r in range(rows_out):
+            want = src[t, idx[r]] if (r < n and idx[r] >= 0) else 0
+            assert np.array_equal(got[t, r], np.broadcast_to(want, (rw,))), (t, r)
+        assert np.all(got[t, rows_out:] == 5)
+
+
 @pytest.mark.parametrize('C_,F,N,T,B', [(64, 100, 12, 50, 9), (256, 100, 12, 400, 40), (1024, 100, 12, 100, 24), (128, 128, 4, 30, 70), (64, 5, 3, 20, 3)])
 def test_fused_conv_forward_matches_pack_plus_gemm(hl, C_, F, N, T, B):
     """e2t_conv_fwd_fused (one pass over the fp32 grid: reversal + im2row + bf16 rounding + GEMM + epilogue) against the

@@ -269,6 +269,41 @@ def test_train_steps_follow_oracle(name, use_graph):
     assert moved > 5e-4
 
 
+@pytest.mark.parametrize('name,B,T,L', [('small_dropout', 19, 26, 6), ('cfg5_frontend', 24, 100, 5)])
+def test_bf16_staged_inputs_equal_the_fp32_staged_path_bit_for_bit(name, B, T, L):
+    """SURVEY.md 8 d4 'bf16 in': a partition staged once as the bf16 im2row rows of the front-end (pack_inputs), batches
+    assembled by the blocked row gather (load_packed_batch: shuffled rows, padding utterances) -- three captured train steps
+    leave exactly the parameters of the fp32-staged path (the rows are what e2t_conv_pack writes per step: same bits)."""
+    eng, ws, ospec, P, batch = build(SPECS[name], B, T, L, seed=9)
+    eng2, ws2, _, _, _ = build(SPECS[name], B, T, L, seed=9)
+    rng = np.random.default_rng(1)
+    n = B + 7
+    where = rng.permutation(n)[:B]
+    Xp = torch.zeros(n, T, ws2['C'], device='cuda')
+    Xp[torch.from_numpy(where).cuda()] = ws2['X']
+    pk = eng2.pack_inputs(ws2['sid'], Xp)
+    np.testing.assert_array_equal(pk['lens'].cpu().numpy()[where], (np.abs(batch['encoder_inputs']).max(axis=2) > 0).sum(1))
+    ws2['X'].fill_(float('nan'))
+    idx = torch.from_numpy(where.astype(np.int32)).cuda()
+    for _ in range(3):
+        eng.train_step(ws, use_graph=True)
+        eng2.load_packed_batch(ws2, pk, idx)
+        eng2.train_step(ws2, use_graph=True)
+    torch.cuda.synchronize()
+    assert ws2['packed'] and not ws.get('packed')
+    la, lb = eng.losses(ws), eng2.losses(ws2)
+    assert la['decoder'] == lb['decoder'] and la.get('aux') == lb.get('aux')
+    a, b = eng.store.p.cpu().numpy(), eng2.store.p.cpu().numpy()
+    emb = slice(*eng.store.seg_range('dec.emb'))
+    keep = np.ones(a.size, bool); keep[emb] = False
+    assert np.array_equal(a[keep], b[keep])                   # (the embedding scatter-add sums fp32 atomics in any order)
+    np.testing.assert_allclose(a[emb], b[emb], atol=1e-6)
+    # the saliency path needs the lengths and the operand only
+    eng2.forward(ws2, train=False); eng2.backward(ws2, train=False)
+    eng.forward(ws, train=False); eng.backward(ws, train=False)
+    assert torch.equal(eng.input_gradient(ws), eng2.input_gradient(ws2))
+
+
 def test_graph_replay_equals_eager():
     eng, ws, ospec, P, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
     eng2, ws2, _, _, _ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
