@@ -138,10 +138,27 @@ static int ticket(e2t_comm* c, int* out) {
     return E2T_OK;
 }
 
+// The communicator's stream waits for everything enqueued so far on `after_stream` and issues nothing.  Inside a stream capture
+// this is how the communicator's stream ENTERS the capture from the capture's origin stream: ROCm 7.0's hipGraphInstantiate crashes
+// on a stream that was pulled into a capture by a stream that was itself pulled in (a fork off a forked stream), so a captured
+// step calls this once on its main stream before the first collective is ordered behind a side stream's work.
+// One rank: RCCL enqueues nothing for an in-place collective, which leaves the communicator's stream without a node of its own
+// inside a captured step -- a stream that only forwards dependencies (ROCm 7.0's graph instantiation then recurses without end on
+// the merged edges).  A one-thread marker kernel stands in for the collective's kernel, so that a one-rank communicator (tests,
+// one-GPU runs of the data-parallel schedule) records the same graph shape as a multi-rank one.
+__global__ void k_comm_marker(int) {}
+static void one_rank_marker(e2t_comm* c) { if (c->nranks == 1) hipLaunchKernelGGL(k_comm_marker, dim3(1), dim3(1), 0, c->stream, 0); }
+
+extern "C" int e2t_comm_order_after(e2t_comm* c, void* after_stream) {
+    E2T_CHECK_ARG(c);
+    return order_after(c, after_stream);
+}
+
 extern "C" int e2t_comm_allreduce_f32(e2t_comm* c, float* buf, size_t n, void* after_stream, int* ticket_out) {
     E2T_CHECK_ARG(c && (buf || n == 0));
     if (int rc = order_after(c, after_stream)) return rc;
     if (n) E2T_NCCL(g_rccl.AllReduce(buf, buf, n, ncclFloat32, ncclSum, c->comm, c->stream));
+    one_rank_marker(c);
     return ticket(c, ticket_out);
 }
 
@@ -149,6 +166,7 @@ extern "C" int e2t_comm_allreduce_i32(e2t_comm* c, int32_t* buf, size_t n, void*
     E2T_CHECK_ARG(c && (buf || n == 0));
     if (int rc = order_after(c, after_stream)) return rc;
     if (n) E2T_NCCL(g_rccl.AllReduce(buf, buf, n, ncclInt32, ncclSum, c->comm, c->stream));
+    one_rank_marker(c);
     return ticket(c, ticket_out);
 }
 

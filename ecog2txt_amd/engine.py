@@ -122,6 +122,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         self.splitk_ws_side = _f32(16 * 1024 * 1024, device=dev)     # ... of the side stream (weight-gradient branch)
         self._on_side = False
         self._wstream = None
+        self._ustream = None          # data parallel: the early optimiser update's stream inside the captured step
         self._lstream = None
         self.launch_stream_on = os.environ.get('E2T_LAUNCH_STREAM', '1') != '0'
         # E2T_OVERLAP=0: everything on one stream (diagnostics).  (Measured and dropped in rounds 1-2, DESIGN.md: weight gradients
@@ -788,13 +789,15 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         ev.record(torch.cuda.current_stream(self.device))
         return ev
 
-    def run_side(self, ev, fn):
-        """fn() on the side stream, ordered after fork_point() event ev.  Returns the event to pass to join_side().
-        (A fork off a forked stream crashes hipGraphInstantiate: side work always forks from the MAIN branch.)"""
+    def run_side(self, ev, fn, stream=None, also=()):
+        """fn() on the side stream (or `stream`), ordered after fork_point() event ev.  Returns the event to pass to
+        join_side().  (A fork off a forked stream crashes hipGraphInstantiate: side work always forks from the MAIN branch.)"""
         if self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
-        stream = self._wstream
+        stream = stream or self._wstream
         stream.wait_event(ev)
+        for e in also:                    # further events the work waits for (of other side branches)
+            stream.wait_event(e)
         with torch.cuda.stream(stream):
             self._on_side = True
             try:
@@ -819,33 +822,65 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         main(train)
         self.join_side(join)
 
-    def backward(self, ws, train=True, after_stage=None, early=None, before_join=None):
-        """early = {stage index: fn}: fn() is queued on the side stream right behind that stage's side work (the optimiser
-        update of the parameter ranges whose gradients are complete by then: HBM-bound, next to the compute-bound
-        weight-gradient GEMMs of the remaining stages).  before_join(): queued on the main stream behind its last stage, in
-        front of the joins with the side stream (the update of the bottom layer, whose gradients the main chain produced
-        itself, runs while the side stream is still busy with the early update and its re-pack)."""
+    def backward(self, ws, train=True, after_stage=None, early=None, before_join=None, exchange=None, after_last_rec=None):
+        """early = (stage index, fn): fn() is queued on the side stream behind that stage's side work AND behind the stage's
+        main-branch work (the optimiser update of the parameter ranges whose gradients are complete by then: HBM-bound, next
+        to the compute-bound weight-gradient GEMMs of the remaining stages; the stage is the last one with a recurrence, so
+        every kernel that can raise `sync_err` has finished before the first update reads it).  before_join(): queued on the
+        main stream behind its last stage, in front of the joins with the side stream (the update of the bottom layer, whose
+        gradients the main chain produced itself, runs while the side stream is still busy with the early update and its
+        re-pack).  exchange(ranges): data parallel inside ONE captured graph -- called on the stream that completes a stage's
+        gradient ranges, right behind the work that completes them (the collective orders itself behind that stream).
+        after_last_rec(): on the main stream behind the last recurrence of the backward pass."""
         ws['have_dy'] = [False] * len(self.enc)
         ws['_aux_join'] = None
         ws['fwd_train'] = train
         deferred = []
+        pending_early = None
         stages = self.backward_stages(ws)
+        last_rec = len(stages) - 2                  # stages: head + aux | one per encoder layer (top .. bottom) | bottom weights
         for i, (main, side, ranges) in enumerate(stages):
+            def side_work(side=side, ranges=ranges):
+                side(train)
+                if exchange is not None:
+                    exchange(ranges)
             if after_stage is None and self.overlap and side is not None and i == 0:
                 # auxiliary head: joined where the main branch first touches dY[aux_layer] (_bwd_enc_rec)
                 ev = self.fork_point()
                 main(train)
-                ws['_aux_join'] = self.run_side(ev, lambda side=side: side(train))
+                ws['_aux_join'] = self.run_side(ev, side_work)
             elif after_stage is None and self.overlap and side is not None and i > 0:
                 # nobody needs a layer's weight gradients before the optimiser: the side stream just queues them (it is
                 # ~1.4x longer than the BPTT chain) and is joined once at the end instead of after every stage
                 ev = self.fork_point()
                 main(train)
-                deferred.append(self.run_side(ev, lambda side=side: side(train)))
-                if early is not None and i in early:
-                    deferred.append(self.run_side(ev, early[i]))
+                deferred.append(self.run_side(ev, side_work))
             else:
                 self.run_stage(main, side, train)
+                if exchange is not None:
+                    exchange(ranges)
+            if i == last_rec and after_last_rec is not None:
+                after_last_rec()
+            if early is not None and i == early[0] and after_stage is None and self.overlap:
+                # the update's fork point: behind this stage's recurrence (the last kernel that can raise sync_err) ...
+                pending_early = (self.fork_point(), deferred[-1])
+            if pending_early is not None and (i > early[0] or exchange is not None):
+                # ... but its branch is CREATED only now, after the main branch's next nodes (fork_point / run_side: of the two
+                # children of a fork the one created first keeps the parent's hardware queue; created first, the update took it
+                # and the executor queued the whole weight-gradient branch behind the main chain: 1.62 -> 1.92 ms at cfg2).
+                # (Data parallel, where the communicator's branch forks off the same point: measured the other way round --
+                #  created at once 1.62 ms, created late 1.94 -- so there it is created at once.  Both are properties of how
+                #  hipGraphLaunch deals branches to hardware queues, not of the step.)
+                # Data parallel: the update waits for the communicator's stream, which waited for the side stream (weight
+                # gradients -> all-reduce).  Two captured streams that wait for EACH OTHER send hipStreamEndCapture of ROCm 7.0
+                # into an endless recursion (stack overflow inside libamdhip64: it walks the streams' wait relation, not the
+                # node graph), so the update has a stream of its own, forked from the main branch: update -> communicator ->
+                # side -> main is a chain.  It is ordered behind the main branch's fork point first (a stream must enter the
+                # capture through the main branch: run_side), then behind the side stream's weight gradients.
+                if self._ustream is None:
+                    self._ustream = torch.cuda.Stream(device=self.device)
+                deferred.append(self.run_side(pending_early[0], early[1], stream=self._ustream, also=(pending_early[1],)))
+                pending_early = None
             if after_stage:
                 after_stage(i, ranges)
         if ws.get('_aux_join') is not None:
@@ -1098,24 +1133,41 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             self.forward(ws, train=True, global_counts=gc)
             self.backward(ws, train=True, after_stage=(lambda i, ranges: self._exchange(sync, ranges)) if dp else None)
             if dp:
+                sync.allreduce_flag(self.sync_err[0:1])      # a step that one rank must skip is skipped by every rank
                 sync.wait()
             self.adam_step(ws['sid'])
             return
         # the captured Adam launches bake in the trainable ranges and the gradient scale
+        one = not dp or (getattr(sync, 'capturable', False) and self.overlap and not ws['graph'].get('dp_staged'))
         key = ('train_dp' if dp else 'train', gc, tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
-               tuple(sorted(self.hyper.items())), bool(ws.get('packed')))
+               tuple(sorted(self.hyper.items())), bool(ws.get('packed')), one, id(sync) if (dp and one) else None)   # (captured collectives belong to THAT communicator)
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture
             self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
-            g = ws['graph'][key] = self._capture_staged(ws, lazy, gc) if dp else self._capture_step(ws)
+            if one and dp:
+                # data parallel: the single graph with the collectives as nodes; should the runtime refuse to record a
+                # collective, the step falls back to one graph per stage with the collectives issued between them
+                try:
+                    g = self._capture_step(ws, sync, gc)
+                except RuntimeError as e:
+                    print('ecog2txt_amd: the data-parallel step could not be captured as one graph (%s); using one graph per '
+                          'backward stage' % (str(e).splitlines()[0][:200],))
+                    torch.cuda.synchronize(self.device)
+                    ws['graph']['dp_staged'] = True
+                    return self._train_step(ws, use_graph, sync)
+            elif dp:
+                g = self._capture_staged(ws, lazy, gc)
+            else:
+                g = self._capture_step(ws)
+            ws['graph'][key] = g
         # (a replay does not run forward(): an assessment in between may have left the flag off)
         ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
         for hx, wx in zip(self.spec.aux_extra, ws['auxx']):
             wx['use'] = hx.get('scale', 1.0) != 0.0
-        if dp:
+        if dp and not one:
             self._replay_staged(ws, g, sync, lazy)
             return
         if g[1] and self._img_early != 'all' and self._img_early != g[1]:
@@ -1129,67 +1181,67 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         for a, b in ranges:
             sync.allreduce_range(a, b)
 
-    def _capture_step(self, ws):
-        """The single-process step as ONE graph: forward, backward (weight gradients on the side stream) and the optimiser,
-        with everything above the bottom encoder layer updated and re-packed early.  Returns (graph, early-packed ranges)."""
+    def _capture_step(self, ws, sync=None, gc=False):
+        """The step as ONE graph: forward, backward (weight gradients on the side stream) and the optimiser, with everything
+        above the bottom encoder layer updated and re-packed early.  Returns (graph, early-packed ranges).
+
+        sync (a transport whose collectives can be captured: parallel.RcclSync): the data-parallel step is the SAME graph
+        plus collective nodes -- the all-reduce of a stage's gradient ranges is recorded on the communicator's stream behind
+        the work that completes them (side stream: weight gradients; main stream: the bottom layer's), the sum of the ranks'
+        `sync_err` words behind the last recurrence, and each optimiser launch waits for the collectives issued before it."""
         # parameters whose gradients are final two stages before the end (head, decoder, top encoder layers, an
         # auxiliary head above the bottom layers) are updated on the side stream under the remaining stages
         nl = len(self.enc)
-        early_end, early = 0, None
-        packed_early, early_sets = [], []
-        if nl >= 2 and self.overlap and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
-            # stage i (2 <= i <= nl) queues the weight gradients of layer nl-i+1 on the side stream: behind them,
-            # everything in front of layer nl-i's segment is final
-            early, lo = {}, 0
-            tr = self.trainable_ranges(ws['sid'])
-            for i in range(2, nl + 1):
-                hi = self.store.seg_range('enc%d.Wx' % (nl - i))[0]
-                er = [(max(a, lo), min(b, hi)) for a, b in tr if a < hi and b > lo]
-                if er:
-                    if self.early_pack:
-                        early_sets.append(er)
-                        # ... and their operand images right behind: the layers that read them in THIS step's backward
-                        # pass (BPTT and input gradient of the layers above the one stage i works on) are done
-                        early[i] = (lambda er=er: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))
-                        packed_early += er
-                    else:
-                        early[i] = (lambda er=er: self.adam_ranges(er, step_offset=1))
-                lo = hi
-            early_end = lo
-            if len(early) > 1 and self.early_pack and os.environ.get('E2T_EARLY_MERGE', '1') != '0':
-                # ONE early update, behind the LAST side stage: the optimiser and re-pack kernels are HBM-bound and
-                # pair well with the MFMA-bound weight gradients of the bottom layer in the step's tail; issued
-                # earlier they sat between the side stream's GEMM launches and pushed the middle layer's weight
-                # gradients into that tail, where two GEMM launches then competed (measured: see DESIGN 5.00)
-                merged = []
-                for x, y in sorted(r for er in early_sets for r in er):
-                    if merged and merged[-1][1] == x:
-                        merged[-1] = (merged[-1][0], y)
-                    else:
-                        merged.append((x, y))
-                early_sets = [merged]
-                early = {nl: (lambda er=merged: (self.adam_ranges(er, step_offset=1), self.pack_ranges(er)))}
-            if not early:
-                early, early_end = None, 0
+        dp = sync is not None
+        early_end, early, packed_early = 0, None, []
+        tr = self.trainable_ranges(ws['sid'])
+        if nl >= 2 and self.overlap:
+            # ONE early update, behind the LAST side stage (the weight gradients of layer 1, queued under the bottom layer's
+            # BPTT): everything in front of the bottom layer's segment is final by then.  The optimiser and re-pack kernels
+            # are HBM-bound and pair with the MFMA-bound weight gradients of the bottom layer in the step's tail; issued
+            # earlier (one update per stage) they sat between the side stream's GEMM launches and pushed the middle layer's
+            # weight gradients into that tail, where two GEMM launches then competed (measured: DESIGN.md, appendix)
+            hi = self.store.seg_range('enc0.Wx')[0]
+            er = [(a, min(b, hi)) for a, b in tr if a < hi]
+            if er:
+                early_end, packed_early = hi, er
+
+                def early_fn(er=er):
+                    if dp:
+                        sync.wait_flag()         # the sync_err sum and, collectives being ordered, every all-reduce issued before it
+                                                 # (these ranges'; not the bottom layer's, which follows)
+                    self.adam_ranges(er, step_offset=1)
+                    self.pack_ranges(er)
+                early = (nl, early_fn)
         g1 = torch.cuda.CUDAGraph()
         if packed_early:
-            for er_ in early_sets:                       # descriptor tables are built outside the capture
-                self._pack_subtable(tuple(er_))
+            self._pack_subtable(tuple(packed_early))          # descriptor tables are built outside the capture
             self._pack_subtable(('skip',) + tuple(packed_early))
+        tail = [(max(a, early_end), b) for a, b in tr if b > early_end]
+
+        def exchange(ranges):
+            for a, b in ranges:
+                sync.allreduce_range(a, b)
+
+        def tail_update():
+            # the rest (bottom layer, front-end) is updated on the main stream BEFORE it joins the side stream, which is
+            # still busy with the early update and its re-pack (cfg2: the step ended 30 us after the side stream did);
+            # like the early update it runs on the un-incremented step counter (step_offset = 1)
+            if dp:
+                sync.join()
+            self.adam_ranges(tail, step_offset=1)
         with capture(g1):
-            self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None)
-            if early:
-                # the rest (bottom layer, front-end) is updated on the main stream BEFORE it joins the side stream, which is
-                # still busy with the early update and its re-pack (cfg2: the step ended 30 us after the side stream did);
-                # like the early update it runs on the un-incremented step counter (step_offset = 1)
-                tail = [(max(a, early_end), b) for a, b in self.trainable_ranges(ws['sid']) if b > early_end]
-                self.backward(ws, train=True, early=early, before_join=lambda: self.adam_ranges(tail, step_offset=1))
-                lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
-                self._packed = None
-                self._img_early = None
-            else:
-                self.backward(ws, train=True)
-                self.adam_step(ws['sid'], repack=False, skip_below=early_end)
+            if dp:
+                sync.attach()
+            self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None, global_counts=gc)
+            self.backward(ws, train=True, early=early, before_join=tail_update, exchange=exchange if dp else None,
+                          after_last_rec=(lambda: sync.allreduce_flag(self.sync_err[0:1])) if dp else None)
+            lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
+        if dp:
+            sync.pending_ranges = []                  # (tickets recorded during a capture mean nothing outside it)
+            sync._flag_pending = False
+        self._packed = None
+        self._img_early = None
         return (g1, tuple(packed_early))
 
     def _capture_staged(self, ws, lazy, gc):
@@ -1229,7 +1281,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         cur = torch.cuda.current_stream(self.device)
 
         def replay_stages(side_stream, exchange):
-            for gm, gs, ranges in g[0]:
+            for i, (gm, gs, ranges) in enumerate(g[0]):
                 if gs is not None:
                     ev = torch.cuda.Event()
                     ev.record(cur)                   # everything the side work reads was enqueued on the main stream before
@@ -1239,6 +1291,10 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                         if exchange:
                             self._exchange(sync, ranges)     # the collective orders itself behind the side stream
                 gm.replay()
+                if exchange and i == len(g[0]) - 2:
+                    # the last kernel that can raise sync_err (the bottom layer's BPTT) has been enqueued: the word's sum over the
+                    # ranks makes a step that one rank must skip a step that every rank skips (the replicas cannot drift apart)
+                    sync.allreduce_flag(self.sync_err[0:1])
                 if gs is None and exchange:
                     self._exchange(sync, ranges)
             ev = torch.cuda.Event()
@@ -1266,7 +1322,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             ws['graph']['side_stream'] = best[1]
         replay_stages(ws['graph']['side_stream'], True)
         pend = getattr(sync, 'pending_ranges', None)
-        if pend and lazy and os.environ.get('E2T_EARLY_ADAM', '1') != '0':
+        if pend and lazy:
             # the optimiser follows the exchange range by range (the ranges complete in backward order): only the last
             # range's update is exposed behind its all-reduce, the earlier ones run under the later collectives
             # The updates of all ranges but the last go out on the SIDE stream, behind its last weight-gradient graph: they are
@@ -1281,7 +1337,13 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 er = [(max(a, x), min(b, y)) for x, y in tr if x < b and y > a]
                 if er:
                     self.adam_ranges(er, step_offset=1)
+            # (no update may read sync_err before the whole main chain -- the bottom layer's BPTT is its last writer -- and the
+            #  sum of the ranks' words are done: a step is applied on every range and every rank, or on none)
+            evm = torch.cuda.Event()
+            evm.record(cur)
+            side_stream.wait_event(evm)
             with torch.cuda.stream(side_stream):
+                sync.wait_flag()
                 for w, a, b in pl[:-1]:
                     update(w, a, b)
                 evs = torch.cuda.Event()
@@ -1313,11 +1375,12 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 for k in ('hx', 'dgx', 'counters', 'flagsb', 'flagsbb', 'dgxb'):
                     if k in lw:
                         lw[k].zero_()
+        # (data parallel: word 0 is the SUM of the ranks' words -- every rank raises, none has updated)
         if info[0] == 7:
             raise RuntimeError('persistent BPTT: a recurrent gate gradient was NaN or infinite (results of this step are invalid, '
-                               'the weights were not updated) %r' % (info,))
-        raise RuntimeError('persistent recurrence: an in-kernel wait timed out (results of this step are invalid, the '
-                           'weights were not updated; E2T_PERSISTENT=0 selects the launch-per-step kernels) %r' % (info,))
+                               'the weights were not updated: no parameter range, on no rank) %r' % (info,))
+        raise RuntimeError('persistent recurrence: an in-kernel wait timed out or, data parallel, several ranks raised the word '
+                           '(results of this step are invalid, the weights were not updated: no parameter range, on no rank) %r' % (info,))
 
     def saturation_events(self, reset=True):
         """How often the persistent BPTT clipped a recurrent gate gradient at |x| >= 2 in its exchange copy since the last

@@ -84,6 +84,18 @@ class GradSync:
         self.pending = []
         self.pending_ranges = []
 
+    def allreduce_flag(self, word):
+        """Sum a one-element int32 device tensor over the ranks (the 'this step is invalid' word of the persistent recurrences:
+        a rank that must skip its update makes every rank skip it, so the replicas cannot drift apart)."""
+        if self.world > 1:
+            self._flag = dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append(self._flag)
+
+    def wait_flag(self):
+        w, self._flag = getattr(self, '_flag', None), None
+        if w is not None:
+            w.wait()
+
     @property
     def grad_scale(self):
         """1 when every rank normalised its loss by the GLOBAL token counts (the sum of the ranks' gradients is the
@@ -134,7 +146,8 @@ class RcclSync:
         lib.e2t_comm_init(C.byref(comm), rank, world, unique_id, int(device))
         self.comm = comm
         self.pending_ranges = []
-        self._i32 = None
+        self._flag_pending = False
+        self.capturable = True             # collectives may be recorded into a hipGraph (csrc/comm.hip)
 
     @staticmethod
     def unique_id():
@@ -152,9 +165,33 @@ class RcclSync:
         self.pending_ranges.append((_Ticket(self, t.value), a, b))
 
     def wait(self):
-        if self.pending_ranges:
+        if self.pending_ranges or self._flag_pending:
             self.lib.e2t_comm_wait(self.comm, -1, torch.cuda.current_stream().cuda_stream)
         self.pending_ranges = []
+        self._flag_pending = False
+
+    def attach(self):
+        """The communicator's stream is ordered behind the current stream's work so far and issues nothing: a captured step
+        calls this on its main stream before anything else, so that the communicator's stream enters the capture from the
+        capture's origin stream (a stream pulled in by a side stream crashes hipGraphInstantiate of ROCm 7.0)."""
+        self.lib.e2t_comm_order_after(self.comm, torch.cuda.current_stream().cuda_stream)
+
+    def join(self):
+        """The current stream waits for every collective issued so far (legal inside a stream capture: the communicator's
+        stream, which joined the capture through the collectives' event edges, is joined back)."""
+        self.lib.e2t_comm_wait(self.comm, -1, torch.cuda.current_stream().cuda_stream)
+
+    def allreduce_flag(self, word):
+        """Sum a one-element int32 device tensor over the ranks, ordered behind the current stream's work so far (the 'this
+        step is invalid' word of the persistent recurrences: a rank that must skip its update makes every rank skip it)."""
+        t = C.c_int(-1)
+        self.lib.e2t_comm_allreduce_i32(self.comm, word.data_ptr(), 1, torch.cuda.current_stream().cuda_stream, C.byref(t))
+        self._flag_pending = _Ticket(self, t.value)
+
+    def wait_flag(self):
+        """The current stream waits for the last allreduce_flag (and, collectives being ordered, everything issued before it)."""
+        if self._flag_pending:
+            self._flag_pending.wait()
 
     @property
     def grad_scale(self):

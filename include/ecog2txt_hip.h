@@ -300,6 +300,9 @@ int e2t_comm_init(e2t_comm** out, int rank, int nranks, const void* id128 /* hos
 int e2t_comm_destroy(e2t_comm* c);
 int e2t_comm_rank(const e2t_comm* c);
 int e2t_comm_size(const e2t_comm* c);
+/* ABI 6: the communicator's stream waits for the work enqueued so far on `after_stream`; nothing is issued.  A captured step calls it
+ * once on the capture's origin stream, so that the communicator's stream enters the capture from there (see csrc/comm.hip). */
+int e2t_comm_order_after(e2t_comm* c, void* after_stream);
 /* in-place sum over ranks of buf[0..n) (a contiguous range of the flat gradient buffer) */
 int e2t_comm_allreduce_f32(e2t_comm* c, float* buf, size_t n, void* after_stream, int* ticket);
 int e2t_comm_allreduce_i32(e2t_comm* c, int32_t* buf, size_t n, void* after_stream, int* ticket);   /* token ids / counts */

@@ -56,6 +56,16 @@ def _contended_sync(eng, n_cus, usec, occ):
             assert occ.e2t_test_occupy(n_cus, usec, 120 * 1024, None, sync.occ_stream.cuda_stream) == 0
             sync.occupied += 1
     sync.allreduce_range = allreduce_range
+    # (the step is ONE captured graph: a stream that joined the capture must be joined back -- whoever waits for the collectives
+    #  issued so far also waits for the occupying kernels issued so far)
+    real_join = sync.join
+
+    def join():
+        real_join()
+        ev = torch.cuda.Event()
+        ev.record(sync.occ_stream)
+        torch.cuda.current_stream().wait_event(ev)
+    sync.join = join
     return sync
 
 

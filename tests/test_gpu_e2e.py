@@ -225,6 +225,8 @@ def test_staged_backward_graphs_match_single_graph():
         world, grad_scale = 2, 1.0
         def __init__(self): self.calls = []
         def allreduce_range(self, a, b): self.calls.append((a, b))
+        def allreduce_flag(self, word): pass
+        def wait_flag(self): pass
         def wait(self): pass
     eng, ws, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
     eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
@@ -341,6 +343,53 @@ def test_optimiser_skips_the_update_after_an_in_kernel_timeout():
     eng.train_step(ws, use_graph=True)                       # and training goes on
     torch.cuda.synchronize()
     assert not torch.equal(eng.store.p, p1) and int(eng.step_t.item()) == t1 + 1
+
+
+@pytest.mark.parametrize('dp', [False, True], ids=['single', 'data_parallel_one_graph'])
+def test_error_word_raised_inside_the_step_leaves_every_range_untouched(dp):
+    """the error word is raised INSIDE a captured step (non-finite gate gradients make the persistent BPTT raise code 7
+    -- at the earliest by the top layer, i.e. after the head's gradients are complete) and the early optimiser update on the side
+    stream must still see it: masters, Adam state, EMA shadows and the step counter of EVERY range stay as they were -- also in
+    the data-parallel graph, where the word is summed over the ranks before any update reads it."""
+    from test_gpu_parity import build, SPECS
+    from ecog2txt_amd.parallel import RcclSync
+    kw = dict(SPECS['cfg2_widths'], enc_rnn=[400, 400])         # persistent recurrences (H = 400), two layers: an early update exists
+    eng, ws, _, _, batch = build(kw, 64, 40, 5, seed=3)
+    assert eng.persistent_bwd and eng.enc[0].persistent_bwd_ok(64, eng.num_cus)
+    sync = None
+    if dp:
+        try:
+            sync = RcclSync(eng.store.g, 0, 1, RcclSync.unique_id(), 0, sum_of_global_means=True)
+        except RuntimeError as e:
+            pytest.skip('cannot create an RCCL communicator here: %r' % (e,))
+        sync.world = 2
+        ntok, nval = eng.local_counts(batch['decoder_targets'], batch['encoder_targets'])
+        eng.set_global_counts(ws, ntok, nval)
+    try:
+        for _ in range(2):
+            eng.train_step(ws, use_graph=True, sync=sync)
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) == 0
+        st = eng.store
+        before = [t.clone() for t in (st.p, st.m, st.v, st.ema)]
+        t1 = int(eng.step_t.item())
+        good = ws['auxT'].clone()
+        ws['auxT'][3, :, 0] = float('inf')                       # -> non-finite auxiliary gradient -> dY of layer 0 -> its BPTT raises
+        eng.train_step(ws, use_graph=True, sync=sync)
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) != 0
+        for a, b in zip(before, (st.p, st.m, st.v, st.ema)):
+            assert torch.equal(a, b)
+        assert int(eng.step_t.item()) == t1
+        with pytest.raises(RuntimeError, match='not updated'):
+            eng.check_sync(ws)
+        ws['auxT'].copy_(good)
+        eng.train_step(ws, use_graph=True, sync=sync)
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) == 0 and int(eng.step_t.item()) == t1 + 1 and not torch.equal(before[0], st.p)
+    finally:
+        if sync is not None:
+            sync.close()
 
 
 def test_forward_after_a_captured_step_sees_the_updated_weights():
