@@ -132,7 +132,7 @@ def roofline_refs():
 
 GEMM_KERNELS = {'tn128g': 'k_gemm_tn_group (K-major operands: the weight gradients of a backward stage in one grouped launch, 128x128 tiles)',
                 'tn256': 'k_gemm_nt<256,256,2,4,false,true> (K-major operands, both output dimensions >= 1024)',
-                'tn128': 'k_gemm_nt<128,128,2,2,false,true> (K-major operands: weight gradients, lean epilogue)',
+                'tn128': 'k_gemm_nt<128,128,2,2,false,true> (K-major operands: weight gradients and the ragged edge of the large ones, lean epilogue)',
                 'nt128': 'k_gemm_nt<128,128,2,2,true,false> (K-contiguous, full epilogue)',
                 'nt256': 'k_gemm_nt<256,256,2,4,false,false> (K-contiguous, large plain products)'}
 
@@ -175,7 +175,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
     B = batch or B
     spec = NetSpec(**spec_kw)
     device = 'cuda:%d' % dev_index
-    eng = Seq2SeqEngine(spec, device=device, seed=1234 + rank)
+    eng = Seq2SeqEngine(spec, device=device, seed=1234 + rank, options=dict(kv.split('=', 1) for kv in args.engine_option))
     eng.init_params(seed=0)
     sync = sync_factory(eng) if sync_factory is not None else None
     if sync is not None:
@@ -358,6 +358,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default: the config\'s 256)')
     ap.add_argument('--inputs', default='fp32', choices=['fp32', 'bf16'],
                     help='how the inputs are resident in HBM: fp32 [B][T][C] (default, the headline form) or the bf16 im2row rows of the front-end (SURVEY 8 d4)')
+    ap.add_argument('--engine-option', action='append', default=[], metavar='KEY=VALUE',
+                    help='override of Seq2SeqEngine.OPTIONS (diagnostics), e.g. persistent=0; may be repeated')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')

@@ -6,12 +6,11 @@ Constants mirror the reference's token/partition contract
 (ecog2txt/__init__.py:10-22)."""
 import os
 
-# Process-wide defaults that must be in place BEFORE the HIP / HSA runtime initialises (it reads them once): dmabuf IPC (the
-# host driver supports nothing else: RCCL's peer-to-peer set-up fails otherwise with `hipIpcGetMemHandle: invalid argument`)
-# and the CUs left to RCCL's channel kernels -- the persistent recurrences of the 256-electrode configuration occupy 200
-# (forward) / 224 (BPTT) of the 256 CUs for a whole layer sweep, one workgroup each; the exchange gets the other 32.
+# The one process-wide default set at import (documented in README.md): it must be in place BEFORE the HIP / HSA runtime
+# initialises, which reads it once -- dmabuf IPC (the host driver supports nothing else: RCCL's peer-to-peer set-up fails
+# otherwise with `hipIpcGetMemHandle: invalid argument`).  (NCCL_MAX_NCHANNELS is defaulted where a communicator is made:
+# parallel.RcclSync.)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
 
 text_dir = os.path.join(os.path.dirname(__file__), 'auxiliary')
 

@@ -1206,6 +1206,9 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
     for (int i = 0; i < n; ++i) {
         const e2t_gemm_call& c = calls[i];
         E2T_CHECK_ARG(c.ep);
+        // the grouped kernel stores through the lean epilogue and a product may end up unsplit (K no deeper than the group's item
+        // depth, or the workspace too small for its slabs): ReLU / dropout / the ReLU-backward mask exist on the reduction's path only
+        E2T_CHECK_ARG(!((c.ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || c.ep->relu_bwd_src));
         GemmArgs p;
         if (int rc = gemm_make_args(true, c.A, c.lda, c.B, c.ldb, c.C, c.ldc, c.M, c.N, c.K, c.ep, p)) return rc;
         if (c.M == 0 || c.N == 0) continue;

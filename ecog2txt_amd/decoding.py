@@ -65,7 +65,7 @@ class DecodingMixin:
         BW = B * W
         max_len = L if max_len is None else min(max_len, L)
         st = self.stream
-        wb = self.workspace(ws['sid'], BW, ws['T'], L)          # (only its decoder-side arrays are used)
+        wb = self._beam_workspace(ws['sid'], B, W, L)
         if 'beam' not in wb:
             dev = self.device
             wb['beam'] = dict(rep=torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(W).contiguous(),
@@ -108,6 +108,26 @@ class DecodingMixin:
                                      bm['tmp_h'].data_ptr(), bm['tmp_c'].data_ptr(), st)
         hyp = bm['hyp'][cur].view(B, W, L)[:, 0, :].contiguous()  # survivors are kept best first
         return hyp, bm['score'][cur].view(B, W)
+
+    def _beam_workspace(self, sid, B, W, L):
+        """The decoder-side arrays of B x W hypothesis rows, and nothing else: a full training workspace of B x W rows would
+        also hold the inputs, the im2row copy and every encoder layer's activations and gradients W times over (tens of GB at
+        beam_width 16), and its cache key could alias a live training workspace of the same row count."""
+        key = ('beam', sid, B, W, L)
+        wb = self._ws.get(key)
+        if wb is None:
+            s, dev = self.spec, self.device
+            BW = B * W
+            Md = L * BW
+            wb = dict(sid=sid, B=BW, L=L, Md=Md, enc=[], graph={})
+            wb['U'] = _i32(Md, device=dev)
+            wb['e'] = _bf(Md, self.E8, device=dev)
+            wb['dec'] = self.dec.alloc(L, BW)
+            wb['c0'] = _f32(BW, s.dec_rnn, device=dev)
+            wb['dlens'] = _i32(BW, device=dev)
+            wb['proj'] = self.proj.alloc(Md)
+            self._ws[key] = wb
+        return wb
 
     def _proj_rows(self, ws, src, l):
         """Projection stack on decoder step l (un-dropped h_t = ext block l+1)."""

@@ -35,7 +35,16 @@ from .decoding import DecodingMixin
 
 
 class Seq2SeqEngine(PackingMixin, DecodingMixin):
-    def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99):
+    # Schedule options (constructor argument `options`, a dict of overrides; diagnostics and tests -- the defaults are the product):
+    #   persistent   '1' whole-sequence weight-stationary recurrences / '0' one launch per time step / 'fwd', 'bwd' one side only
+    #   overlap      weight gradients, optimiser and re-pack on side branches of the captured step (False: one stream)
+    #   fused_conv   'auto' one-pass front-end (e2t_conv_fwd_fused) for HBM-sized batches (>= 256 MiB) / '1' always / '0' never
+    #   tn           weight gradients straight from the K-major activations (False: operand transposes + K-contiguous GEMM)
+    #   group_gemms  the K-major products of a backward stage in one grouped launch (False: one launch per product)
+    #   launch_stream  captured steps replayed from a stream of the engine's own (False: the caller's stream)
+    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True)
+
+    def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
             raise RuntimeError('ecog2txt_amd needs an MI355X (HIP) device; there is no CPU fallback for this path')
         H.load()
@@ -108,8 +117,18 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         self._gemm_log = None         # a list while bench.py records the step's products (instance, shape, flops)
         self._in_group = False
         self._group = None            # a list while gemm_group() collects a stage's K-major weight-gradient products
-        self.group_gemms = os.environ.get('E2T_GROUP_GEMMS', '1') != '0'   # (diagnostics: 0 = one launch per product)
-        mode = os.environ.get('E2T_PERSISTENT', '1')          # '0' launch-per-step, 'fwd' / 'bwd' one side only (diagnostics)
+        opt = dict(self.OPTIONS)
+        unknown = set(options or {}) - set(opt)
+        assert not unknown, 'unknown engine options %r (known: %r)' % (sorted(unknown), sorted(opt))
+        opt.update(options or {})
+        for k, v in opt.items():              # (command lines hand over strings)
+            if isinstance(self.OPTIONS[k], bool) and isinstance(v, str):
+                assert v.lower() in ('0', '1', 'false', 'true'), (k, v)
+                opt[k] = v.lower() in ('1', 'true')
+        self.options = opt
+        self.group_gemms = bool(opt['group_gemms'])
+        mode = str(opt['persistent'])
+        assert mode in ('0', '1', 'fwd', 'bwd')
         self.persistent = mode != '0'
         self.persistent_fwd, self.persistent_bwd = mode in ('1', 'fwd'), mode in ('1', 'bwd')
         self.num_cus = H.load().e2t_device_cus(self.device.index or 0)
@@ -124,16 +143,16 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         self._wstream = None
         self._ustream = None          # data parallel: the early optimiser update's stream inside the captured step
         self._lstream = None
-        self.launch_stream_on = os.environ.get('E2T_LAUNCH_STREAM', '1') != '0'
-        # E2T_OVERLAP=0: everything on one stream (diagnostics).  (Measured and dropped in rounds 1-2, DESIGN.md: weight gradients
-        # on TWO side streams, the BPTT chain alone on the chip with all weight gradients behind it, per-stage joins.)
-        self.overlap = os.environ.get('E2T_OVERLAP', '1') != '0'
+        self.launch_stream_on = bool(opt['launch_stream'])
+        # (measured and dropped in rounds 1-2, DESIGN.md appendix: weight gradients on TWO side streams, the BPTT chain alone
+        #  on the chip with all weight gradients behind it, per-stage joins)
+        self.overlap = bool(opt['overlap'])
         # front-end in ONE pass over x (e2t_conv_fwd_fused: reversal + im2row + bf16 rounding in the DMA path of the product, the
         # packed copy for the backward pass emitted on the way): 'auto' = when the input batch is HBM-sized (>= 256 MiB: cfg5
         # 894 -> 483 us inference / 729 us training; at cfg2's 105 MB the two-kernel path is as fast), '1' / '0' force it
-        self.fused_conv = os.environ.get('E2T_FUSED_CONV', 'auto')
-        self.early_pack = os.environ.get('E2T_EARLY_PACK', '1') != '0'     # images of early-updated ranges re-packed under the backward pass
-        self.tn = os.environ.get('E2T_TN', '1') != '0'       # weight gradients straight from the K-major activations (no transposes)
+        self.fused_conv = str(opt['fused_conv'])
+        assert self.fused_conv in ('auto', '0', '1')
+        self.tn = bool(opt['tn'])       # weight gradients straight from the K-major activations (no transposes)
         self.trainable = None         # None = everything; else set of segment names
 
     def init_params(self, seed=0):

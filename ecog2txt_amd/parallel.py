@@ -140,9 +140,12 @@ class RcclSync:
         self.rank, self.world = rank, world
         self.sum_of_global_means = sum_of_global_means
         comm = C.c_void_p()
-        # (HSA_ENABLE_IPC_MODE_LEGACY=0 -- the host driver only supports dmabuf IPC -- and NCCL_MAX_NCHANNELS=32 -- the CUs the
-        #  persistent recurrences leave to RCCL's channel kernels -- are defaulted at package import, ecog2txt_amd/__init__.py:
-        #  the HSA runtime reads its variable when it initialises, long before a communicator is made)
+        # the CUs left to RCCL's channel kernels: the persistent recurrences of the 256-electrode configuration occupy 200
+        # (forward) / 224 (BPTT) of the 256 CUs for a whole layer sweep, one workgroup each; the exchange gets the other 32
+        # (RCCL reads the variable when the communicator is made; a value the user set wins).  HSA_ENABLE_IPC_MODE_LEGACY=0 --
+        # the host driver only supports dmabuf IPC -- is defaulted at package import: the HSA runtime reads it when it
+        # initialises, long before a communicator is made.
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
         lib.e2t_comm_init(C.byref(comm), rank, world, unique_id, int(device))
         self.comm = comm
         self.pending_ranges = []

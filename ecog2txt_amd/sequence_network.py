@@ -76,7 +76,8 @@ class SequenceNetwork:
                  TEMPORALLY_CONVOLVE=None, EMA_decay=None, beam_width=None, assessment_epoch_interval=None,
                  tf_summaries_dir=None, N_epochs=None, temperature=None, N_cases=256, learning_rate=5e-4,
                  max_hyp_length=20, seed=0, assessment_GPU=0, checkpoint_path='./model.ckpt', inputs_to_occlude=None,
-                 process_group=None, encoder_strides=None, input_staging='auto'):
+                 process_group=None, encoder_strides=None, input_staging='auto', engine_options=None):
+        # engine_options: overrides of Seq2SeqEngine.OPTIONS (schedule diagnostics; the defaults are the product)
         # input_staging: how a fit keeps its training partitions in HBM -- 'fp32' as padded [n][T][C] arrays (a step reads 4 B per
         # input sample and packs them itself), 'bf16' as the bf16 im2row rows of the temporal convolution, made once per fit
         # (Seq2SeqEngine.pack_inputs: 2 B per sample, same bits as the per-step pack), 'auto' = bf16 for HBM-sized batches
@@ -144,7 +145,7 @@ class SequenceNetwork:
             dev = 'cuda:%d' % (self.training_GPUs[0] if self.training_GPUs else 0)
             # (dropout masks differ between the ranks of a data-parallel fit; the initial weights do not: fit() broadcasts them)
             self._engine = Seq2SeqEngine(spec, device=dev, seed=self.seed + 7919 * int(os.environ.get('RANK', '0')),
-                                         lr=self.learning_rate, ema_decay=self.EMA_decay or 0.0)
+                                         lr=self.learning_rate, ema_decay=self.EMA_decay or 0.0, options=self.engine_options)
             self._engine.init_params(self.seed)
             self._engine_key = key
         return self._engine
@@ -187,7 +188,12 @@ class SequenceNetwork:
             tl = (A_ != 0).sum(1) if A_.ndim == 2 else (np.abs(A_).max(axis=2) > 0).sum(1)
             vals.append(-(-tl // N))
         A = As[0] if As else None
-        xlen = (np.abs(X).max(axis=2) > 0).sum(1).astype(np.int64)        # valid samples per utterance (length-balanced sharding)
+        # samples per utterance up to the last non-zero row -- the length the device reads off the end padding -- for the
+        # length-balanced sharding of data-parallel fits (one utterance at a time: no fp32 copy of the partition)
+        xlen = np.zeros(n, np.int64)
+        for i in range(n):
+            nz = np.flatnonzero(X[i].any(axis=1))
+            xlen[i] = nz[-1] + 1 if nz.size else 0
         return dict(X=X, Y=Y, A=A, Ax=As[1:], n=n, T=T, L=L, tok=tok, val=(vals[0] if vals else np.zeros(n, np.int64)), valx=vals[1:], xlen=xlen)
 
     def _batches(self, data, rng=None):
@@ -330,7 +336,7 @@ class SequenceNetwork:
                 idx = np.full((len(gb), B), -1, np.int32)
                 cnt = np.zeros((len(gb), 2 + len(d.get('valx', []))), np.int64)
                 for k, g in enumerate(gb):
-                    mine = rank_slice(g, B, rank, world, d.get('xlen'))
+                    mine = rank_slice(g, B, rank, world, d.get('xlen') if world > 1 else None)
                     idx[k, :len(mine)] = mine
                     cnt[k] = [d['tok'][g].sum(), d['val'][g].sum()] + [v[g].sum() for v in d.get('valx', [])]
                 plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt, self._pack_partition(eng, s.subnet_id, d)))
@@ -354,7 +360,7 @@ class SequenceNetwork:
                 nsat = eng.saturation_events()
                 if nsat:
                     print('WARNING: epoch %d: the persistent BPTT clipped recurrent gate gradients at |x| >= 2 in %d publishes '
-                          '(check the penalty scales; E2T_PERSISTENT=fwd selects the unclipped launch-per-step BPTT)' % (start + epoch, nsat))
+                          '(check the penalty scales; engine_options=dict(persistent="fwd") selects the unclipped launch-per-step BPTT)' % (start + epoch, nsat))
         eng.check_sync()                                             # never checkpoint the results of an invalid step
         self._epoch = start + self.N_epochs
         self._save(eng, self._epoch)
@@ -396,7 +402,7 @@ class SequenceNetwork:
         counts = np.zeros(2, np.int64)                       # correct tokens, tokens
         conf = np.zeros((V, V), np.int64) if V < 100 else None
         for g in global_batches(n, B, world):
-            idx = rank_slice(g, B, rank, world, data.get('xlen'))
+            idx = rank_slice(g, B, rank, world, data.get('xlen') if world > 1 else None)
             if len(idx) == 0:
                 continue
             self._load_batch(eng, ws, data, idx)
@@ -566,23 +572,35 @@ class SequenceNetwork:
             return
         # float32, as the reference's TF1 Saver stores (and restores into) its variables: a DT_DOUBLE entry would be
         # rejected by the reference on restore
-        arrays = {k: v.astype(np.float32) for k, v in eng.store.export_tf('p').items()}
-        arrays.update({k + EMA_SUFFIX: v.astype(np.float32) for k, v in eng.store.export_tf('ema').items()})
-        arrays['__adam_m'] = eng.store.m.cpu().numpy()
-        arrays['__adam_v'] = eng.store.v.cpu().numpy()
-        arrays['__step'] = eng.step_t.cpu().numpy()
-        os.makedirs(os.path.dirname(self.checkpoint_path) or '.', exist_ok=True)
-        # written under temporary names and moved into place (os.replace is atomic): a reader never sees a partial file
-        tmp = self._ckpt(epoch) + '.tmp%d' % os.getpid()
-        np.savez(tmp + '.npz', **arrays)
-        os.replace(tmp + '.npz', self._ckpt(epoch) + '.npz')
-        # the same variables (weights + EMA shadows, reference naming grammar) as a TensorFlow V2 checkpoint:
-        # `model.ckpt-<epoch>.index` is what the trainer's restore_epoch scan looks for (trainers.py:235-252), and the
-        # pair is readable by TF's own checkpoint reader (recover_model_sizes, trainers.py:444-554)
-        from . import tf_checkpoint
-        tf_checkpoint.write_checkpoint(self._ckpt(epoch), {k: v for k, v in arrays.items() if not k.startswith('__')})
-        if sync is not None:
-            sync.barrier()
+        try:
+            arrays = {k: v.astype(np.float32) for k, v in eng.store.export_tf('p').items()}
+            arrays.update({k + EMA_SUFFIX: v.astype(np.float32) for k, v in eng.store.export_tf('ema').items()})
+            arrays['__adam_m'] = eng.store.m.cpu().numpy()
+            arrays['__adam_v'] = eng.store.v.cpu().numpy()
+            arrays['__step'] = eng.step_t.cpu().numpy()
+            ckdir = os.path.dirname(self.checkpoint_path) or '.'
+            os.makedirs(ckdir, exist_ok=True)
+            for f in os.listdir(ckdir):                        # temporaries a crashed writer left behind
+                if f.startswith('.tmp-'):
+                    try:
+                        os.remove(os.path.join(ckdir, f))
+                    except OSError:
+                        pass
+            # written under temporary names and moved into place (os.replace is atomic): a reader never sees a partial file;
+            # the names start with '.tmp-', which the trainer's restore scan ('model.ckpt-<epoch>.index') cannot match
+            final = self._ckpt(epoch)
+            tmp = os.path.join(ckdir, '.tmp-%d-' % os.getpid() + os.path.basename(final))
+            np.savez(tmp + '.npz', **arrays)
+            os.replace(tmp + '.npz', final + '.npz')
+            # the same variables (weights + EMA shadows, reference naming grammar) as a TensorFlow V2 checkpoint:
+            # `model.ckpt-<epoch>.index` is what the trainer's restore_epoch scan looks for (trainers.py:235-252), and the
+            # pair is readable by TF's own checkpoint reader (recover_model_sizes, trainers.py:444-554)
+            from . import tf_checkpoint
+            tf_checkpoint.write_checkpoint(final, {k: v for k, v in arrays.items() if not k.startswith('__')})
+        finally:
+            # (the barrier is reached whatever happened above: the other ranks are waiting in theirs; the error is re-raised)
+            if sync is not None:
+                sync.barrier()
 
     def _restore(self, eng, epoch, reuse_vars_scope):
         import torch

@@ -339,7 +339,10 @@ def write_checkpoint(prefix, arrays):
     os.makedirs(os.path.dirname(prefix) or '.', exist_ok=True)
     # both files are written under temporary names and moved into place, the data shard first and the `.index` -- the file a
     # restore scans for (trainers.py:235-252) -- last: a reader that finds the index finds a complete checkpoint
-    final_prefix, prefix = prefix, prefix + '.tmp%d' % os.getpid()
+    # (temporary names start with '.tmp-': the trainer's restore scan keys on names that START with 'model.ckpt-' and end in
+    #  '.index' -- a temporary index left behind by a crash must not look like a finished epoch)
+    final_prefix = prefix
+    prefix = os.path.join(os.path.dirname(prefix), '.tmp-%d-' % os.getpid() + os.path.basename(prefix))
     with open(_shard_name(prefix, 0, 1), 'wb') as f:
         for name in sorted(arrays, key=lambda s: s.encode('utf-8')):
             a = np.asarray(arrays[name], order='C')              # (ascontiguousarray would turn a scalar into shape (1,))

@@ -135,7 +135,9 @@ int e2t_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
  * decoder kernels of the head), trainers.py:318 (fit) with the kernel shapes of :527-541.  Same results as n calls of
  * e2t_gemm_tn_bf16 with E2T_GEMM_SPLITK (the slabs are summed in fixed order); the K splits are chosen for the group as a whole,
  * so that the workgroups of all products fill whole rounds of the chip.  n <= 8; every call carries its own epilogue (ep != NULL;
- * the split-K workspace of the FIRST call's epilogue serves the whole group). */
+ * the split-K workspace of the FIRST call's epilogue serves the whole group).  The epilogues must be plain (alpha, bias, accumulate,
+ * last_col_out): a call carrying E2T_GEMM_RELU, E2T_GEMM_DROPOUT or relu_bwd_src is refused (E2T_ERR_ARG) -- a grouped product may
+ * run unsplit, and only the split-K reduction applies those. */
 typedef struct e2t_gemm_call {
     const void* A; int lda; const void* B; int ldb; void* C; int ldc; int M, N, K;
     const e2t_gemm_epilogue* ep;

@@ -22,8 +22,7 @@ def timeit(fn, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 for fused in ('0', '1', '1a'):
-    os.environ['E2T_FUSED_CONV'] = fused[0]
-    eng = Seq2SeqEngine(NetSpec(**kw), seed=1)
+    eng = Seq2SeqEngine(NetSpec(**kw), seed=1, options={'fused_conv': fused[0]})
     eng.init_params(0)
     sid = list(kw['channels'])[0]
     ws = eng.workspace(sid, B, T, L)

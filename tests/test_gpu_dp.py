@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, root, ckdir, n_cases, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      E2T_COMM='torch', E2T_PERSISTENT='0')
+                      E2T_COMM='torch')
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -30,7 +30,8 @@ def _worker(rank, world, port, root, ckdir, n_cases, q):
     SyntheticSpeechDataGenerator.trials_per_block = 24
     SyntheticSpeechDataGenerator.max_words = 5
     tr = MultiSubjectTrainer(os.path.join(root, 'experiment.yaml'), [401], checkpoint_dir=ckdir, VERBOSE=False,
-                             SN_kwargs={'N_cases': n_cases, 'learning_rate': 3e-3, 'FF_dropout': 0.0, 'RNN_dropout': 0.0, 'EMA_decay': 0.9},
+                             SN_kwargs={'N_cases': n_cases, 'learning_rate': 3e-3, 'FF_dropout': 0.0, 'RNN_dropout': 0.0, 'EMA_decay': 0.9,
+                                        'engine_options': {'persistent': '0'}},
                              DG_kwargs={'max_samples': 420})
     a = tr.parallel_transfer_learn()
     out = dict(rank=rank, losses=a['training'].losses, wer=a['validation'].decoder_word_error_rates.tolist(),
@@ -92,15 +93,15 @@ def test_two_rank_fit_on_one_gpu_equals_the_single_process_fit(tmp_path):
 
 def test_bench_under_the_launcher_with_two_ranks_on_one_gpu():
     """bench.py exactly as the driver starts it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`),
-    with both ranks mapped onto the one GPU of this box (E2T_BENCH_BACKEND=gloo, launch-per-step recurrences): rank 0 prints
+    with both ranks mapped onto the one GPU of this box (E2T_BENCH_BACKEND=gloo, --engine-option persistent=0: launch-per-step recurrences): rank 0 prints
     ONE JSON line for the whole job, the other rank waits at the closing barrier while rank 0 measures the rooflines, exit 0."""
     import json, socket, subprocess
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, E2T_COMM='torch', E2T_BENCH_BACKEND='gloo', E2T_PERSISTENT='0')
+    env = dict(os.environ, E2T_COMM='torch', E2T_BENCH_BACKEND='gloo')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2'],
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--engine-option', 'persistent=0'],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]

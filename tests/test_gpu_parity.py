@@ -52,7 +52,7 @@ def check_grad(name, got, want, relu_outliers=1e-2, flip_outliers=1e-3, l2_scale
         assert rel_l2 < 1e-2 * l2_scale, (name, float(rel_l2))
 
 
-def build(spec_kw, B, T, L, seed=0, ragged=True, engine_seed=11):
+def build(spec_kw, B, T, L, seed=0, ragged=True, engine_seed=11, options=None):
     from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
     spec = NetSpec(**spec_kw)
     ospec = O.NetSpec(**spec.as_dict())
@@ -63,7 +63,7 @@ def build(spec_kw, B, T, L, seed=0, ragged=True, engine_seed=11):
             P[k] = 0.1 * rng.standard_normal(P[k].shape)
     sid = list(spec.channels)[0]
     batch = make_batch(ospec, B=B, T=T, L=L, seed=seed + 2, ragged=ragged, categorical=spec.aux_dist == 'categorical')
-    eng = Seq2SeqEngine(spec, device='cuda:0', seed=engine_seed)
+    eng = Seq2SeqEngine(spec, device='cuda:0', seed=engine_seed, options=options)
     eng.load_params(P)
     ws = eng.workspace(sid, B, T, L)
     eng.set_batch(ws, batch)
@@ -110,15 +110,16 @@ SPECS = {
 
 @pytest.mark.parametrize('name', list(SPECS) + ['cfg5_frontend+fused', 'mid+fused'])
 @pytest.mark.parametrize('ragged', [False, True])
-def test_forward_backward_parity(name, ragged, monkeypatch):
+def test_forward_backward_parity(name, ragged):
+    options = None
     if name.endswith('+fused'):          # the one-pass front-end (engine default only for HBM-sized batches) forced on
-        monkeypatch.setenv('E2T_FUSED_CONV', '1')
+        options = {'fused_conv': '1'}
         name = name[:-6]
     kw = SPECS[name]
     B, T, L = (40, 100, 8) if name == 'mid' else ((70, 26, 5) if name.endswith('_widths') else ((24, 100, 5) if name == 'cfg5_frontend' else (19, 26, 6)))
     if name == 'cfg4_widths' and not ragged:
         pytest.skip('one variant of the largest case is enough')
-    eng, ws, ospec, P, batch = build(kw, B, T, L, seed=4, ragged=ragged)
+    eng, ws, ospec, P, batch = build(kw, B, T, L, seed=4, ragged=ragged, options=options)
     train = kw['ff_dropout'] > 0 or kw['rnn_dropout'] > 0
     eng.forward(ws, train=train)
     eng.backward(ws, train=train)
@@ -336,14 +337,13 @@ def test_greedy_sequences_identical(name):
                                         # H = 1024: the kernels of csrc/lstm_big.hip (waves hold different weights, state shared through
                                         # LDS, flag hand-off); the decoder (H = 2048) stays on the launch-per-step kernels
                                         ('cfg4_widths', 70, 26, 5), ('cfg4_widths', 256, 40, 4), ('cfg4_widths', 130, 80, 4)])
-def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypatch):
+def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L):
     """The one-launch weight-stationary recurrences (in-launch exchange between CUs) against the launch-per-step
     kernels.  Forward: bit for bit (outputs, dropped outputs, saved cell states, losses).  Backward: the K = 4H sum
     is associated differently (4 quarters vs 2 halves), so gradients agree to fp32 round-off of bf16-rounded dG."""
     outs = {}
     for flag in ('0', 'fwd', '1'):
-        monkeypatch.setenv('E2T_PERSISTENT', flag)
-        eng, ws, ospec, P, batch = build(SPECS[name], B, T, L, seed=4, ragged=True)
+        eng, ws, ospec, P, batch = build(SPECS[name], B, T, L, seed=4, ragged=True, options={'persistent': flag})
         if flag != '0':
             assert all(lay.persistent_ok(B, eng.num_cus) for lay in eng.enc), 'case must exercise the persistent path'
             if name == 'cfg2_widths':
@@ -396,15 +396,14 @@ def test_persistent_recurrence_matches_the_per_step_path(name, B, T, L, monkeypa
     assert np.abs(gc - a['g']).max() <= 5e-3 * np.abs(a['g']).max()
 
 
-def test_persistent_bptt_saturates_huge_gate_gradients_without_stalling(monkeypatch):
+def test_persistent_bptt_saturates_huge_gate_gradients_without_stalling():
     """The recurrent hand-off of the persistent BPTT keeps a stamp in the top exponent bit of every bf16 (free for
     |x| < 2): gate gradients beyond that saturate in the exchange copy -- they must neither corrupt the stamp (an
     in-kernel timeout) nor leak into the dG written for the GEMMs.  Loss weights of 1e6 push |dG| far above 2."""
     kw = dict(SPECS['cfg2_widths'], dec_scale=1.0e6, aux_scale=1.0e6)
     outs = {}
     for flag in ('0', '1'):
-        monkeypatch.setenv('E2T_PERSISTENT', flag)
-        eng, ws, ospec, P, batch = build(kw, 70, 26, 5, seed=4, ragged=True)
+        eng, ws, ospec, P, batch = build(kw, 70, 26, 5, seed=4, ragged=True, options={'persistent': flag})
         for _ in range(3):
             eng.forward(ws, train=True)
             eng.backward(ws, train=True)

@@ -110,6 +110,24 @@ def test_model_sizes_are_recovered_from_a_tf_checkpoint(tmp_path):
     assert strides['401'] == [12] and ema
 
 
+def test_a_crashed_writers_temporaries_are_not_taken_for_an_epoch(tmp_path, monkeypatch):
+    """The trainer's restore scan keys on 'model.ckpt-<epoch>.index' (trainers.py:240-249): the temporary files of a writer that
+    died between writing and renaming must not match it."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    arrays = {'seq2seq/decoder_embedding_10_4_0/weights': np.zeros((10, 4), np.float32)}
+    T.write_checkpoint(str(tmp_path / 'model.ckpt-3'), arrays)
+    real = os.replace
+    monkeypatch.setattr(os, 'replace', lambda a, b: (_ for _ in ()).throw(OSError('killed before the rename')))
+    with pytest.raises(OSError):
+        T.write_checkpoint(str(tmp_path / 'model.ckpt-9'), arrays)
+    monkeypatch.setattr(os, 'replace', real)
+    left = [f for f in os.listdir(tmp_path) if '9' in f]
+    assert left and all(f.startswith('.tmp-') for f in left)
+    tr = MultiSubjectTrainer.__new__(MultiSubjectTrainer)
+    tr._checkpoint_dir, tr._restore_epoch = str(tmp_path), None
+    assert tr.restore_epoch == 3
+
+
 def test_backend_checkpoints_store_float32_variables(tmp_path):
     """the reference's TF1 Saver restores into float32 variables and rejects a dtype mismatch, so every
     variable SequenceNetwork._save writes must be DT_FLOAT (1), in the .index as well as in the .npz."""
