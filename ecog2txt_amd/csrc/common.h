@@ -17,7 +17,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 // two at once on the hardware converter (v_cvt_pk_bf16_f32): low half = bf16(a), high half = bf16(b).  Same bits as f2bf for
-// every fp32 pattern that is not a NaN (scripts/probes/cvt_bf16_probe.hip walks all 2^32 on the GPU: 0 mismatches); a NaN
+// every fp32 pattern that is not a NaN (a one-off probe walked all 2^32 patterns on the GPU in round 2: 0 mismatches); a NaN
 // stays a (quiet) NaN here, f2bf carries its upper bits along
 typedef float e2t_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 e2t_bf16x2 __attribute__((ext_vector_type(2)));

@@ -263,7 +263,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
     // them).  A tile is [64 k-rows][BM columns]; one DMA instruction moves 1 KiB = (2048 / BM) k-rows of BM*2 bytes, the
     // 16-B chunk position inside a row is XOR-swizzled with tn_swz(k-row) on the SOURCE side, rows k >= K come from a zero
     // page, columns beyond M/N are clamped (their products are never stored).  Fragments are then gathered with the
-    // transposing LDS read (ds_read_b64_tr_b16, lane mapping verified by scripts/probes/trread_probe.hip).
+    // transposing LDS read (ds_read_b64_tr_b16, lane mapping verified by a one-off probe in round 1 and, ever since, by every K-major GEMM test).
     // The 32 lanes of one read phase take 32 B from each of 8 k-rows (4 consecutive ones of two fq groups, 8 rows apart); a
     // k-row is a multiple of 256 B = the 64-bank window, so the swizzle must send those 8 rows to 8 different 32-B slots,
     // i.e. act on chunk bits 1..3 (SQ_LDS_BANK_CONFLICT: 50 % of the LDS cycles with the swizzle on bits 0..3 -> 0).
@@ -620,7 +620,7 @@ __device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z) 
 //    (64x2 ... 64x5, 32x2 ... 32x5, 1-3 splits, tiles of 64 utterances or of 64 steps of one utterance: 480-580 us).
 // k_conv_fwd_ws (wave-specialised form, the default): see below; cfg5 445 us (4.7 TB/s).
 // For scale: plain loads of the same access pattern with nothing else in the kernel read at 6.0-6.1 TB/s = 340 us
-// (scripts/probes/stream_pattern_probe.hip); the two-kernel path (e2t_conv_pack + GEMM) takes 894 us.
+// (a one-off streaming probe, round 2); the two-kernel path (e2t_conv_pack + GEMM) takes 894 us.
 // Epilogue = the GEMM's (bias, ReLU, dropout, rows beyond an utterance's decimated length zeroed).
 // ---------------------------------------------------------------------------------------------------------------------
 struct ConvFwdArgs {

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
 //     is stamped per value, so a torn 16-B read is simply seen as stale.  A buffer is only rewritten by a producer
 //     that has consumed the following step from EVERY cluster member, each of which had read the buffer before
 //     publishing, so nothing is overwritten early.  The protocol is placement-independent; clusters are laid on XCDs
-//     (workgroup id % 8 = XCC id, read back from HW_REG_XCC_ID by scripts/probes/xchg_probe.hip) only for speed;
+//     (workgroup id % 8 = XCC id, read back from HW_REG_XCC_ID by a one-off probe in round 1) only for speed;
 //   * everything that is not on the h_t -> h_{t+1} critical path (gate / cell saves, the Philox mask and the
 //     dropped copy for the next layer) is issued AFTER the exchange store and runs while the other workgroups' stores
 //     are in flight; Gx is prefetched two steps ahead, right after a step's state has landed.

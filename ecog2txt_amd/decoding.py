@@ -1,16 +1,12 @@
 """Decoding with the trained network (assessment: restore_and_assess, the online predictor): greedy search and beam search,
 one decoder step per token through the launch-per-step kernels.  Mixed into Seq2SeqEngine (engine.py)."""
-from dataclasses import dataclass, field, asdict   # noqa: F401
 import ctypes as C
-import os   # noqa: F401
 
-import numpy as np   # noqa: F401
 import torch
 
-from . import hip_lib as H
 from .hip_lib import lib
-from .params import *       # noqa: F401,F403
-from .layers import _bf, _f32, _i32   # noqa: F401
+from .params import EOS_ID, PAD_ID, STREAM_DEC_EMB, ceil_div, r8, rk
+from .layers import _bf, _f32, _i32
 
 
 class DecodingMixin:

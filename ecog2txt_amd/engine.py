@@ -14,12 +14,8 @@ _prepare_encoder_targets (798-799) -> decoder + losses -> Adam/EMA.
 Parameter naming follows the checkpoint grammar recovered by
 MultiSubjectTrainer.recover_model_sizes (trainers.py:444-554).
 """
-from dataclasses import dataclass, field, asdict
-from typing import Dict, List, Optional
 import contextlib
 import ctypes as C
-import gc
-import os
 import re
 
 import numpy as np
@@ -27,9 +23,10 @@ import torch
 
 from . import hip_lib as H
 from .hip_lib import lib
-from .params import *       # noqa: F401,F403  (NetSpec, ParamStore, layout helpers, stream ids: re-exported)
-from .params import _tf2int, _int2tf   # noqa: F401
-from .layers import _FFStack, _Lstm, _bf, _f32, _i32   # noqa: F401
+# (NetSpec, ParamStore and the layout helpers are part of this module's interface: callers import them from here)
+from .params import (NetSpec, ParamStore, EOS_ID, PAD_ID, OOV_ID, STREAM_AUX, STREAM_CONV, STREAM_CONV_PRE, STREAM_DEC_EMB,   # noqa: F401
+                     STREAM_DEC_OUT, STREAM_ENC, capture, ceil_div, conv_seg, conv_stack, conv_tf_name, r8, rk)
+from .layers import _FFStack, _Lstm, _bf, _f32, _i32
 from .packing import PackingMixin
 from .decoding import DecodingMixin
 

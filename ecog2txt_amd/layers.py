@@ -3,21 +3,13 @@
 sequences of their forward, BPTT, input-gradient and weight-gradient stages through the C ABI (include/ecog2txt_hip.h).
 Reference stages: _encode_sequences (ecog2txt/trainers.py:821-823), the encoder-target heads (786-799), the decoder RNN and
 its projection (513-529).  Host-side plumbing only: every FLOP runs in libecog2txt_hip.so."""
-from dataclasses import dataclass, field, asdict
-from typing import Dict, List, Optional
-import contextlib
 import ctypes as C
-import gc
-import os
-import re
 
-import numpy as np
 import torch
 
 from . import hip_lib as H
 from .hip_lib import lib
-from .params import *       # noqa: F401,F403  (layout helpers, stream ids)
-from .params import _tf2int, _int2tf   # noqa: F401
+from .params import ceil_div, r8, rk
 
 
 def _bf(*shape, device):

@@ -1,17 +1,11 @@
 """Operand packing of the engine: the bf16 images every kernel reads (K-contiguous and K-major GEMM operands, MFMA fragment
 images of the recurrent kernels) are rebuilt from the fp32 masters or the EMA shadows by e2t_pack_batch launches driven by
 device-resident descriptor tables.  Mixed into Seq2SeqEngine (engine.py)."""
-from dataclasses import dataclass, field, asdict   # noqa: F401
-import ctypes as C
-import os   # noqa: F401
-
-import numpy as np   # noqa: F401
 import torch
 
 from . import hip_lib as H
 from .hip_lib import lib
-from .params import *       # noqa: F401,F403
-from .layers import _bf, _f32, _i32   # noqa: F401
+from .params import ceil_div, conv_seg
 
 
 class PackingMixin:
