@@ -52,6 +52,8 @@ struct GemmArgs {
     long long a_bs, b_bs, c_bs; // batched launch: element strides of A, B, C between products
     int batch;                 // number of products in the launch (>= 1)
     int order;                 // 1: locality order of the flattened grid (default); 0: round-1 order (diagnostics)
+    int row0;                  // row index of this launch's row 0 within the product it is a part of (the rows of a product may leave
+                               // in two launches: gemm_launch); only the row-length mask and the dropout counter see it
 };
 // product z of a batched launch: operands, output and slabs moved to that product's
 __device__ __forceinline__ GemmArgs gemm_batch_view(const GemmArgs& in, int z) {
@@ -78,6 +80,7 @@ struct EpiCtx {
 // row m of the output is a real step of its utterance (rows beyond the decimated length are zeroed)
 __device__ __forceinline__ bool row_valid(const GemmArgs& p, int gm) {
     if (!p.lens) return true;
+    gm += p.row0;
     if (p.rowsG <= 1) return (gm / p.rowsB) < p.lens[gm % p.rowsB];
     const int tgb = gm / p.rowsG, g = gm - tgb * p.rowsG;
     return (tgb / p.rowsB) * p.rowsG + g < p.lens[tgb % p.rowsB];
@@ -127,7 +130,7 @@ __device__ __forceinline__ void epi_apply4(const GemmArgs& p, const EpiCtx& ec, 
         for (int r = 0; r < nv; ++r) v[r] = (ms[r] & 0x7FFF) != 0 ? v[r] : 0.f;    // kept & active
     }
     if (RICH && ec.dodrop) {
-        const unsigned long long e0 = (unsigned long long)gm * p.ld_logical + gn0;
+        const unsigned long long e0 = (unsigned long long)(gm + p.row0) * p.ld_logical + gn0;
         if ((e0 & 3ull) == 0) {
             unsigned rr[4];
             const unsigned long long ctr = e0 >> 2;
@@ -420,6 +423,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
         }
     };
 
+    // A wave whose whole sub-tile lies beyond M or N (the ragged edge of a product: dW_h is 400 x 1600 -- 3.125 x 12.5 tiles of
+    // 128, dW_x 801 x 3200 -- 6.26 tile rows) stages its share of the operands and meets the barriers, but reads no fragment and
+    // issues no MFMA: the LDS bandwidth and the MFMA pipe go to the other waves of the CU.
+    // (128 x 128 instances only: around the 128 accumulators of a 256 x 256 wave the branch costs hipcc 25 registers and spills.)
+    constexpr bool SKIP_DEAD = BM * BN <= 128 * 128;
+    const bool wave_dead = SKIP_DEAD && ((m0 + wm >= p.M) || (n0 + wn >= p.N));
     int cur = 0;
     {
     // NS stages: tiles t .. t+NS-2 are in flight while tile t is awaited; tile t+NS-1 goes into the stage tile t-1 was read
@@ -441,7 +450,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
         const int nxt = t + NS - 1;
         int nbuf = cur + NS - 1; if (nbuf >= NS) nbuf -= NS;
         if (DBG != 1 && !INTERLEAVE && nxt < t1) issue(nxt, nbuf);
-        if (DBG != 2) compute(cur, (DBG != 1 && INTERLEAVE && nxt < t1) ? nxt : -1, nbuf);
+        if (wave_dead) { if (DBG != 1 && INTERLEAVE && nxt < t1) issue(nxt, nbuf); }
+        else if (DBG != 2) compute(cur, (DBG != 1 && INTERLEAVE && nxt < t1) ? nxt : -1, nbuf);
         if (++cur == NS) cur = 0;
     }
     }
@@ -465,7 +475,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
             sb[swz(r, schunk)] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
         }
         __syncthreads();
-        compute(cur, -1, 0);
+        if (!wave_dead) compute(cur, -1, 0);
     }
 
     // epilogue.  MFMA roles are (B-tile fragment, A-tile fragment), so D[i][j]: column j = lane&15 is the
@@ -1016,7 +1026,7 @@ static int gemm_order() {
     return o;
 }
 // Which instance a product runs on, and its split count (shared by the launcher and e2t_gemm_plan).
-static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue* ep) {
+static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int want_tile = 0, int want_splits = 0) {
     // tile choice: 256x256 for large plain products, 128x128 otherwise; E2T_GEMM_TILE=128|256 overrides (diagnostics)
     static const int forced = e2t_dbg_int("E2T_GEMM_TILE", 0);
     // Split-K: requested by the caller (weight gradients: K = S*B, a few dozen output tiles) or chosen here when the
@@ -1040,12 +1050,18 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     if (big_tn) big = true;
     if (forced == 128) big = false;
     if (forced == 256 && !tn && !want_split && !rich) big = true;
+    if (want_tile == 128) big = false;                        // (the tail part of a product: gemm_launch)
     GemmPlan pl;
     pl.tile = big ? 256 : 128;
     pl.batch = (ep && ep->batch > 1) ? ep->batch : 1;
-    pl.want_split = want_split;
+    pl.want_split = want_split || (want_splits > 1 && have_ws);
     pl.splits = 1;
-    if (want_split) {
+    if (want_splits > 1 && have_ws) {
+        int s = std::min(want_splits, std::max(1, nfull / 16));
+        const size_t per = (size_t)M * N * sizeof(float) * pl.batch;
+        if ((size_t)s * per > ep->splitk_ws_bytes) s = (int)(ep->splitk_ws_bytes / per);
+        pl.splits = std::max(1, s);
+    } else if (want_split) {
         const int ntm = (M + pl.tile - 1) / pl.tile, ntn = (N + pl.tile - 1) / pl.tile;
         const int tiles = ntm * ntn * pl.batch;
         const int slots = 512;
@@ -1109,16 +1125,47 @@ static int gemm_make_args(bool tn, const void* A, int lda, const void* B, int ld
 }
 
 static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                       int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream) {
+                       int M, int N, int K, const e2t_gemm_epilogue* ep, void* stream,
+                       int row0 = 0, int want_tile = 0, int want_splits = 0) {
     GemmArgs p;
     if (int rc = gemm_make_args(tn, A, lda, B, ldb, C, ldc, M, N, K, ep, p)) return rc;
+    p.row0 = row0;
     if (M == 0 || N == 0) return E2T_OK;
     // the K-major instances store through the lean epilogue (alpha, bias, accumulate, row mask, bf16: 139 registers, which lets
     // a workgroup share a CU with the persistent BPTT): ReLU / dropout / the ReLU-backward mask exist on their split-K path
     // only, where the reduction applies the full epilogue
     const bool rich_ep = ep && ((ep->flags & (E2T_GEMM_RELU | E2T_GEMM_DROPOUT)) || ep->relu_bwd_src);
-    const GemmPlan pl = gemm_plan(tn, M, N, K, ep);
+    const GemmPlan pl = gemm_plan(tn, M, N, K, ep, want_tile, want_splits);
     const bool big = pl.tile == 256;
+    // The last round of a large K-contiguous product on the 128 x 128 instance.  Its tiles are dealt to the chip in rounds of 512
+    // resident workgroups; a few tiles beyond a whole number of rounds cost a whole round more -- cfg4's input gradient 8704 x 2048
+    // x 8192: 68 x 16 = 1088 tiles = 2.125 rounds, on the critical path of the backward pass.  The tile rows of the whole rounds
+    // leave as they are; the rows beyond them leave as a second launch that fills the chip once with short workgroups: K split over
+    // 512 / tiles workgroups per tile, the reduction applies the full epilogue.  A sub-range of M is a row offset of A, C and the
+    // epilogue's row-indexed operands; the row-length mask and the dropout counter get the offset as GemmArgs::row0.
+    // Measured (same box, cfg4): the product alone 329 -> 306 us; the step 8.65 -> 8.58 ms.  (The same cut for the 256 x 256 instance
+    // -- the rows beyond the whole rounds on 128 x 128 tiles: input projection 8704 x 8192 x 2112, 4.25 rounds of 256 -- is faster
+    // alone, 303 -> 279 us, and made the step SLOWER, 8.65 -> 8.73 ms: not in the tree.)
+    if (!tn && !big && row0 == 0 && want_tile == 0 && want_splits == 0 && pl.batch == 1 && pl.splits <= 1 && ep && !ep->last_col_out) {
+        const int slots = 512;
+        const int ntm_ = (M + 127) / 128, ntn_ = (N + 127) / 128;
+        const long tiles = (long)ntm_ * ntn_;
+        const long rem = tiles % slots;
+        if (tiles > slots && rem > 0 && rem * 10 <= slots * 3 && (tiles - rem) % ntn_ == 0 && K / BK >= 32 &&
+            ep->splitk_ws && ep->splitk_ws_bytes > 0 && !(ep->flags & E2T_GEMM_SPLITK)) {
+            const int rows_a = (int)((tiles - rem) / ntn_) * 128;           // rows of the whole rounds
+            const int rows_b = M - rows_a;
+            const int elt = (ep->flags & E2T_GEMM_OUT_BF16) ? 2 : 4;
+            const int splits_b = (int)std::min<long>(8, std::max<long>(1, slots / rem));
+            if (splits_b > 1 && (size_t)splits_b * rows_b * N * sizeof(float) <= ep->splitk_ws_bytes) {
+                e2t_gemm_epilogue eb = *ep;
+                if (ep->relu_bwd_src) eb.relu_bwd_src = (const char*)ep->relu_bwd_src + (size_t)rows_a * ep->ld_relu_bwd_src * 2;
+                if (int rc = gemm_launch(false, A, lda, B, ldb, C, ldc, rows_a, N, K, ep, stream, 0, 128, -1)) return rc;
+                return gemm_launch(false, (const bf16_t*)A + (size_t)rows_a * lda, lda, B, ldb, (char*)C + (size_t)rows_a * ldc * elt, ldc,
+                                   rows_b, N, K, &eb, stream, rows_a, 128, splits_b);
+            }
+        }
+    }
     // Ragged edge of a large K-major product.  The weight gradient of a layer with D inputs is [x | 1]^T . dG: M = D + 1, and with
     // D a multiple of 256 the ones column costs a whole extra row of 256 x 256 tiles (cfg4's dW_x, 2049 x 8192 x 8704: 9 x 32 tiles
     // = 288 on 256 CUs -- two rounds or three K splits; measured 429 us against 257 for 2048 rows).  The few rows (columns) beyond

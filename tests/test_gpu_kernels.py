@@ -621,6 +621,38 @@ def test_gemm_tn_256_ragged_edge_leaves_as_its_own_product(hl, M, N, K):
     np.testing.assert_allclose(host(lc), want[:, N - 1], rtol=1e-5, atol=1e-4 * np.sqrt(K))
 
 
+def test_gemm_nt_last_round_leaves_as_a_second_launch(hl):
+    """A large K-contiguous product whose tile count ends a little behind a whole number of rounds of resident workgroups (cfg4's
+    input gradient 8704 x 2048: 1088 tiles of 128 x 128 = 2.125 rounds of 512) is launched as the whole rounds + a short second
+    launch (K split) over the remaining rows.  Same result as one product -- also for what depends on the ROW INDEX: the row-length
+    mask and the dropout counter."""
+    rng = np.random.default_rng(5)
+    M, N, K, rowsB = 8704, 2048, 2048, 256
+    A, Bm = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    wsb = torch.zeros(16 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue(); ep.alpha = 0.5
+    ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    want = 0.5 * (round_bf16(A).astype(np.float32) @ round_bf16(Bm).astype(np.float32).T)
+    if True:        # (the epilogue-rich form: everything that depends on the row index)
+        lens = rng.integers(20, M // rowsB + 1, size=rowsB); lens[3] = M // rowsB
+        lt = torch.tensor(lens, dtype=torch.int32, device='cuda')
+        step = torch.tensor([2], dtype=torch.int32, device='cuda')
+        c0 = rng.standard_normal((M, N)).astype(np.float32)
+        c = torch.from_numpy(c0.copy()).cuda()
+        ep.flags = hl.GEMM_ACCUMULATE | hl.GEMM_DROPOUT
+        ep.drop_rate, ep.drop_seed, ep.drop_step, ep.drop_stream, ep.drop_ld = 0.5, 77, step.data_ptr(), 4, N
+        ep.row_lens, ep.rows_per_step = lt.data_ptr(), rowsB
+        tile = C.c_int(0)
+        hl.lib.e2t_gemm_plan(0, M, N, K, C.byref(ep), C.byref(tile), None)
+        assert tile.value == 128
+        hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N, K, C.byref(ep), st())
+        torch.cuda.synchronize()
+        valid = (np.arange(M) // rowsB) < lens[np.arange(M) % rowsB]
+        ref = c0 + want * (keep_mask((M, N), 0.5, 79, 4) / 0.5) * valid[:, None]
+        np.testing.assert_allclose(host(c), ref, rtol=1e-4, atol=2e-2)
+
+
 @pytest.mark.parametrize('G', [1, 2, 3])
 def test_grouped_row_order_of_the_conv_stack(hl, G):
     """e2t_conv_pack_grouped / e2t_conv_unpack_grad_grouped / e2t_gemm_epilogue.row_group: row m = (tg*B + b)*G + g holds step
