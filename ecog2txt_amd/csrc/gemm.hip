@@ -1045,7 +1045,10 @@ static GemmPlan gemm_plan(bool tn, int M, int N, int K, const e2t_gemm_epilogue*
     static const bool tn256_ok = e2t_dbg_int("E2T_TN256", 1) != 0;
     const int nbatch = (ep && ep->batch > 1) ? ep->batch : 1;
     static const int tn256_min = e2t_dbg_int("E2T_TN256_MIN", 1024);
-    static const int tn256_tiles = e2t_dbg_int("E2T_TN256_TILES", 64);
+    // (at least HALF a round of 256 x 256 workgroups: the vocabulary projection's weight gradient at cfg4, 1806 x 2049 x 2560 = 72 tiles,
+    //  took 75 us on this instance -- 64 tiles x 2 splits on 256 CUs -- against 38 us for the vendor BLAS; it now joins the head's grouped
+    //  128 x 128 launch)
+    static const int tn256_tiles = e2t_dbg_int("E2T_TN256_TILES", 128);
     const bool big_tn = tn && tn256_ok && !rich && have_ws && M >= tn256_min && N >= tn256_min && t256 * nbatch >= tn256_tiles && forced != 128;
     if (big_tn) big = true;
     if (forced == 128) big = false;

@@ -566,7 +566,7 @@ def test_fused_conv_forward_matches_pack_plus_gemm(hl, C_, F, N, T, B):
     assert torch.equal(E.view(torch.int16), E2.view(torch.int16))
 
 
-@pytest.mark.parametrize('M,N,K,nb', [(2049, 2050, 1100, 1), (1024, 2304, 2100, 2)])
+@pytest.mark.parametrize('M,N,K,nb', [(2049, 3586, 1100, 1), (1024, 4352, 2100, 2)])
 def test_gemm_tn_256_tile_instance(hl, M, N, K, nb):
     """The 256 x 256 K-major instance (both output dimensions >= 1024: cfg4's weight gradients), ragged edges, split-K
     slabs + reduction, batched: against NumPy on the bf16-rounded operands."""
@@ -593,7 +593,7 @@ def test_gemm_tn_256_tile_instance(hl, M, N, K, nb):
         assert np.all(got[z][:, N:] == 7.0)
 
 
-@pytest.mark.parametrize('M,N,K', [(2049, 1793, 1500), (1812, 2305, 1100), (2049, 2054, 1100)])
+@pytest.mark.parametrize('M,N,K', [(2049, 3841, 1500), (1812, 4353, 1100), (2049, 3846, 1100)])
 def test_gemm_tn_256_ragged_edge_leaves_as_its_own_product(hl, M, N, K):
     """A large K-major product whose M (N) ends a few rows (columns) behind a multiple of 256 -- [x | 1]^T . dG with the ones column
     -- is launched as the full tiles + an edge product: same result as one product, incl. the bias-column diversion
