@@ -321,6 +321,27 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
                      lstm_fwd_frac_of_mfma_peak=round(fl / (us_f * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                      lstm_bwd_frac_of_mfma_peak=round(fl / (us_b * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
         eng.check_sync()
+        # ---- decoding (BASELINE.json's metric also names decode WER; the sequences themselves are checked against the oracle in
+        #      tests/): greedy decode of the same batch with the EMA weights -- encoder + L decoder steps --, eager and as one
+        #      captured graph, and beam search of width 4 (eager, B x 4 hypothesis rows)
+        if inputs == 'fp32':
+            def timed(fn, reps=5):
+                fn(); torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t0_) / reps
+            try:
+                ms_e = timed(lambda: eng.greedy_decode(ws, which='ema'))
+                ms_g = timed(lambda: eng.greedy_decode(ws, which='ema', use_graph=True))
+                ms_b = timed(lambda: eng.beam_decode(ws, 4, which='ema'), reps=3)
+                extra['decode'] = dict(greedy_ms_per_batch_eager=round(ms_e, 3), greedy_ms_per_batch_graph=round(ms_g, 3),
+                                       greedy_utterances_per_s=round(B / (min(ms_e, ms_g) * 1e-3), 1), beam4_ms_per_batch=round(ms_b, 3),
+                                       max_tokens=L, weights='ema')
+            except Exception as e:                             # (never let the decode leg take the training line down)
+                extra['decode'] = dict(error=repr(e)[:200])
+            eng.pack('p')
 
     out = None
     if rank == 0:
@@ -338,7 +359,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
                                   spec.dec_rnn, spec.vocab, L), inputs=inputs, global_batch=B * world, parallelism='dp%d' % world,
                                hipgraph=not args.no_graph, exchange=(type(sync).__name__ if sync is not None else None)),
                    recurrent_gemm_tflops=round(rec, 3), recurrent_gemm_frac_of_peak=round(rec / MFMA_BF16_PEAK_TFLOPS / world, 5),
-                   final_loss=round(losses['total'], 4), recurrence=extra, roofline=roof,
+                   final_loss=round(losses['total'], 4), decode=extra.pop('decode', None), recurrence=extra, roofline=roof,
                    roofline_all_gemm_instances=groups)
     # release the engine's device memory before the next configuration (cfg5's workspace is ~9 GB)
     eng._ws.clear()

@@ -5,17 +5,34 @@ import ctypes as C
 import torch
 
 from .hip_lib import lib
-from .params import EOS_ID, PAD_ID, STREAM_DEC_EMB, ceil_div, r8, rk
+from .params import EOS_ID, PAD_ID, STREAM_DEC_EMB, capture, ceil_div, r8, rk
 from .layers import _bf, _f32, _i32
 
 
 class DecodingMixin:
     # ------------------------------------------------------------------ decode
-    def greedy_decode(self, ws, which='ema', max_len=None):
-        """beam_width 1 decoding (mocha-1_word_sequence.yaml:31); returns int32 [B, L] token ids."""
+    def greedy_decode(self, ws, which='ema', max_len=None, use_graph=False):
+        """beam_width 1 decoding (mocha-1_word_sequence.yaml:31); returns int32 [B, L] token ids.
+        use_graph: the whole decode of the batch staged in ws -- encoder + L decoder steps of about six launches each -- is
+        captured once per (weights, length, input form) and replayed (the shapes are static: every utterance runs all L steps,
+        finished ones emit padding); the eager form launches ~6 L + 20 kernels per batch."""
         s = self.spec
         if self._packed != which:
             self.pack(which)
+        if use_graph:
+            key = ('greedy', which, max_len, bool(ws.get('packed')))
+            g = ws['graph'].get(key)
+            if g is None:
+                self.greedy_decode(ws, which, max_len)                     # warm-up outside the capture
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with self.on_step_stream():
+                    with capture(g):
+                        self.greedy_decode(ws, which, max_len)
+                ws['graph'][key] = g
+            with self.on_step_stream():
+                g.replay()
+            return ws['hyp']
         src = getattr(self.store, which)
         B, L = ws['B'], ws['L']
         max_len = L if max_len is None else min(max_len, L)

@@ -39,7 +39,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   tn           weight gradients straight from the K-major activations (False: operand transposes + K-contiguous GEMM)
     #   group_gemms  the K-major products of a backward stage in one grouped launch (False: one launch per product)
     #   launch_stream  captured steps replayed from a stream of the engine's own (False: the caller's stream)
-    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True)
+    #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes (False: one graph per backward stage,
+    #                  the collectives issued between them -- also the automatic fallback when a capture is refused)
+    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=True)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -1154,7 +1156,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             self.adam_step(ws['sid'])
             return
         # the captured Adam launches bake in the trainable ranges and the gradient scale
-        one = not dp or (getattr(sync, 'capturable', False) and self.overlap and not ws['graph'].get('dp_staged'))
+        one = not dp or (getattr(sync, 'capturable', False) and self.overlap and self.options['dp_one_graph'] and not ws['graph'].get('dp_staged'))
         key = ('train_dp' if dp else 'train', gc, tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
                tuple(sorted(self.hyper.items())), bool(ws.get('packed')), one, id(sync) if (dp and one) else None)   # (captured collectives belong to THAT communicator)
         g = ws['graph'].get(key)

@@ -286,16 +286,19 @@ def test_staged_step_with_a_real_rccl_group():
         dist.destroy_process_group()
 
 
-def test_staged_step_with_direct_rccl_through_the_c_abi():
+@pytest.mark.parametrize('one_graph', [True, False], ids=['one_graph', 'graph_per_stage'])
+def test_data_parallel_step_with_direct_rccl_through_the_c_abi(one_graph):
     """The product's exchange: librccl called directly through e2t_comm_* (no torch.distributed anywhere in the step) on a
-    one-rank communicator -- collectives on the communicator's own stream, ordered by events behind the side stream's
-    graphs, the optimiser following the exchange ticket by ticket.  One real rank reported as two takes the engine down
-    the data-parallel path; the sum over one rank leaves the gradients unchanged, so the result must equal the
-    single-graph step.  Also: global-count loss normalisation equals local normalisation when the counts agree."""
+    one-rank communicator -- collectives on the communicator's own stream, ordered by events behind the stream that completes
+    their ranges, the optimiser following the exchange.  Both schedules: the step as ONE graph with the collectives as nodes
+    (the default) and one graph per backward stage with the collectives issued between them (option dp_one_graph=False, the
+    fallback).  One real rank reported as two takes the engine down the data-parallel path; the sum over one rank leaves the
+    gradients unchanged, so the result must equal the single-graph step.  Also: global-count loss normalisation equals local
+    normalisation when the counts agree."""
     from test_gpu_parity import build, SPECS
     from ecog2txt_amd.parallel import RcclSync
     eng, ws, _, _, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
-    eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
+    eng2, ws2, *_ = build(SPECS['small_dropout'], 19, 26, 6, seed=9, options={'dp_one_graph': one_graph})
     try:
         sync = RcclSync(eng2.store.g, 0, 1, RcclSync.unique_id(), 0, sum_of_global_means=True)
     except RuntimeError as e:
@@ -309,6 +312,7 @@ def test_staged_step_with_direct_rccl_through_the_c_abi():
             eng2.train_step(ws2, use_graph=True, sync=sync)
         torch.cuda.synchronize()
         assert int(eng2.sync_err[0].item()) == 0
+        assert any(k[0] == 'train_dp' and k[6] == one_graph for k in ws2['graph'] if isinstance(k, tuple))
         np.testing.assert_allclose(eng.store.p.cpu().numpy(), eng2.store.p.cpu().numpy(), atol=1e-5)
         assert eng.losses(ws)['total'] == pytest.approx(eng2.losses(ws2)['total'], rel=1e-5)
         # the small host-side exchanges of the sharded assessment, and the parameter broadcast

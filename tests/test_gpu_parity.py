@@ -329,6 +329,12 @@ def test_greedy_sequences_identical(name):
     diff = hyp[:, :margin.shape[1]] != want[:, :margin.shape[1]]
     assert not (diff & (margin > 5e-2)).any()
     assert diff.mean() < 0.02
+    # the whole decode replayed from one captured graph: the same tokens as the eager launches, also after the batch changed
+    for _ in range(2):
+        assert np.array_equal(eng.greedy_decode(ws, which='p', use_graph=True).cpu().numpy(), hyp)
+    ws['X'].mul_(-0.5)
+    again = eng.greedy_decode(ws, which='p').cpu().numpy()
+    assert np.array_equal(eng.greedy_decode(ws, which='p', use_graph=True).cpu().numpy(), again)
 
 
 @pytest.mark.parametrize('name,B,T,L', [('small_dropout', 70, 50, 6), ('cfg2_widths', 130, 40, 5), ('mid', 256, 100, 8),
