@@ -1005,7 +1005,11 @@ extern "C" int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, f
     if (n == 0) return E2T_OK;
     const uintptr_t a = (uintptr_t)p & 15;
     const int vec = (((uintptr_t)g & 15) == a && ((uintptr_t)m & 15) == a && ((uintptr_t)v & 15) == a && ((uintptr_t)ema & 15) == a && (a & 3) == 0) ? 1 : 0;
-    size_t blocks = ((vec ? n / 4 + 8 : n) + 255) / 256; if (blocks > 2048) blocks = 2048;
+    // Short workgroups (one 16-B group per thread, at most four): 2048 workgroups looping over the whole range held every slot of
+    // the chip for the kernel's whole duration, and a small kernel of the other branch -- the bottom stage's grouped reduction,
+    // 25 us of work -- then sat behind them until the update was over (cfg4: 689 us beside the 812-us early update).
+    size_t blocks = ((vec ? n / 4 + 8 : n) + 255) / 256; if (blocks > (1u << 18)) blocks = (blocks + 3) / 4;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
     hipLaunchKernelGGL(k_adam_ema, dim3((unsigned)blocks), dim3(256), 0, ST, p, g, m, v, ema, n, step, h->lr, h->beta1, h->beta2,
                        h->eps, h->ema_decay, h->grad_scale, h->step_offset, h->skip_if_nonzero, vec);
     E2T_LAUNCH_CHECK(); return E2T_OK;
