@@ -291,13 +291,67 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
                                 achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                                 # the same launches INSIDE the step share the chip with the other stream: fraction from the committed
                                 # rocprofv3 row of the round (in-step average duration of this kernel), beside the isolated `frac`
-                                frac_in_step=(round(flops / len(recs) / (in_step_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if in_step_us else None),
-                                in_step_us_per_launch=in_step_us, in_step_source=ref.get('in_step_source'),
+                                frac_in_step_profile=(round(flops / len(recs) / (in_step_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if in_step_us else None),
+                                in_step_profile_us_per_launch=in_step_us, in_step_source=ref.get('in_step_source'),
                                 traffic=ref.get('hbm_bytes_per_launch'), traffic_source=ref.get('traffic_source'),
                                 us_per_launch=round(us / len(recs), 2), flops_per_launch=int(flops / len(recs)),
                                 algorithmic_hbm_bytes_per_launch=int(sum(r['in_bytes'] + r['out_bytes'] for r in recs) / len(recs)),
                                 us_per_step=round(us, 1), includes_splitk_reduce=any(r['splits'] != 1 for r in recs),
                                 largest=(big.get('desc') or 'M=%d N=%d K=%d x%d (splits %d)' % (big['M'], big['N'], big['K'], big['batch'], big['splits'])))
+        # ---- the same launches INSIDE the step, measured live: with the stamp hook on (e2t_gemm_stamps) every GEMM launch of a freshly
+        #      captured step records [first workgroup start, last workgroup end] on the chip-wide 100-MHz clock; ten replays, the
+        #      stamps read and reset after each: in-step average duration per instance = what `rocprofv3 --kernel-trace --stats` of
+        #      this command reports for the kernel row (profiles/: the committed summary of the same command)
+        live = {}
+        try:
+            NSL = 512
+            stamps = torch.empty(2 * NSL, dtype=torch.int64, device=device)
+            blank = torch.tensor([-1, 0] * NSL, dtype=torch.int64, device=device)       # ~0 / 0 as unsigned words
+            saved = [w['graph'] for w in wss]
+            for w in wss:
+                w['graph'] = {}
+            lib_ = __import__('ecog2txt_amd.hip_lib', fromlist=['lib']).lib
+            lib_.e2t_gemm_stamps(stamps.data_ptr(), NSL)
+            import ctypes as C_
+            names = {0: 'tn128g', 1: 'tn128', 2: 'tn256', 3: 'nt128', 4: 'nt256'}
+            acc = {}
+            with eng.on_step_stream():
+                for _ in range(2 * len(wss)):
+                    step()                                  # eager warm-up + capture with stamp slots, one replay
+                torch.cuda.synchronize()
+                for _ in range(10):
+                    stamps.copy_(blank)
+                    eng.train_step(wss[0], use_graph=not args.no_graph, sync=sync)
+                    torch.cuda.synchronize()
+                    kinds = (C_.c_int * NSL)()
+                    lib_.e2t_gemm_stamp_kinds(kinds, NSL)
+                    st_ = stamps.cpu().numpy().view(np.uint64).reshape(NSL, 2)
+                    for k in range(NSL):
+                        if kinds[k] >= 0 and st_[k, 1] > 0 and st_[k, 0] != np.uint64(0xFFFFFFFFFFFFFFFF):
+                            acc.setdefault(names[kinds[k]], []).append((int(st_[k, 1]) - int(st_[k, 0])) * 0.01)     # 100 MHz -> us
+            lib_.e2t_gemm_stamps(None, 0)
+            for w, g_ in zip(wss, saved):
+                w['graph'] = {}                              # (graphs captured with stamp slots must not outlive the buffer)
+            live = {k: (float(np.mean(v)), len(v) // 10) for k, v in acc.items()}
+        except Exception as e:
+            print('bench: live in-step timing unavailable (%r)' % (e,), file=sys.stderr)
+            try:
+                __import__('ecog2txt_amd.hip_lib', fromlist=['lib']).lib.e2t_gemm_stamps(None, 0)
+            except Exception:
+                pass
+        for inst, (us_l, n_l) in live.items():
+            if inst in groups:
+                gq = groups[inst]
+                # a product the library cuts into two launches (ragged edge, last round) counts as two stamped launches of one
+                # logged product: the in-step time of the instance per step is what matters
+                us_step = us_l * n_l
+                gq['in_step_live_us_per_step'] = round(us_step, 1)
+                gq['in_step_live_us_per_launch'] = round(us_step / gq['launches_per_step'], 2)
+                tf_l = gq['flops_per_launch'] * gq['launches_per_step'] / (us_step * 1e-6) / 1e12
+                # `achieved` / `frac` = IN-STEP, measured live (they agree with the kernel row of the committed rocprofv3 summary of
+                # this command: `frac_in_step_profile`); the isolated replay keeps its own names
+                gq.update(achieved_isolated=gq['achieved'], frac_isolated=gq['frac'], achieved=round(tf_l, 2),
+                          frac=round(tf_l / MFMA_BF16_PEAK_TFLOPS, 4), measured='in-step, live (e2t_gemm_stamps: first workgroup start .. last workgroup end of every launch of 10 replayed steps)')
         if args.gemm_detail:
             for r in log:
                 us1 = time_graph(lambda: eng.gemm_replay(r), 10)
@@ -432,11 +486,13 @@ def main():
                 dom = o['roofline'] or {}
                 block[c] = dict(workload=o['config']['workload'], ms_per_step=o['ms_per_step'], value=o['value'], unit=o['unit'],
                                 steps=20, warmup=10, recurrent_gemm_frac_of_peak=o['recurrent_gemm_frac_of_peak'],
-                                dominant=dict(instance=dom.get('instance'), kernel=dom.get('kernel'), frac=dom.get('frac'),
-                                              frac_in_step=dom.get('frac_in_step'), in_step_source=dom.get('in_step_source'),
+                                dominant=dict(instance=dom.get('instance'), kernel=dom.get('kernel'), frac=dom.get('frac'), measured=dom.get('measured'),
+                                              frac_isolated=dom.get('frac_isolated'), frac_in_step_profile=dom.get('frac_in_step_profile'), in_step_source=dom.get('in_step_source'),
+                                              in_step_live_us_per_launch=dom.get('in_step_live_us_per_launch'),
                                               us_per_launch=dom.get('us_per_launch'), flops_per_launch=dom.get('flops_per_launch'),
                                               largest=dom.get('largest')),
-                                gemm_instances={k: dict(frac=v['frac'], frac_in_step=v['frac_in_step'], us_per_step=v['us_per_step'])
+                                gemm_instances={k: dict(frac=v['frac'], frac_isolated=v.get('frac_isolated'), us_per_step_isolated=v['us_per_step'],
+                                                        us_per_step_in_step=v.get('in_step_live_us_per_step'))
                                                 for k, v in o['roofline_all_gemm_instances'].items()},
                                 recurrence=o['recurrence'], final_loss=o['final_loss'], wall_s=round(time.perf_counter() - t0, 1))
             out['configs'] = block

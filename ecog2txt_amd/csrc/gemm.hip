@@ -52,6 +52,7 @@ struct GemmArgs {
     long long a_bs, b_bs, c_bs; // batched launch: element strides of A, B, C between products
     int batch;                 // number of products in the launch (>= 1)
     int order;                 // 1: locality order of the flattened grid (default); 0: round-1 order (diagnostics)
+    unsigned long long* stamp; // measurement hook (e2t_gemm_stamps): [first workgroup start, last workgroup end] of this launch, 100-MHz clock; null otherwise
     int row0;                  // row index of this launch's row 0 within the product it is a part of (the rows of a product may leave
                                // in two launches: gemm_launch); only the row-length mask and the dropout counter see it
 };
@@ -544,9 +545,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
     }
 }
 
+// Measurement hook (bench.py, e2t_gemm_stamps): the earliest workgroup start and the latest workgroup end of a launch on the
+// chip-wide 100-MHz clock -- what a kernel trace reports as the launch's duration, readable INSIDE a replayed graph.
+__device__ __forceinline__ unsigned long long stamp_begin(const unsigned long long* st) { return (st && threadIdx.x == 0) ? wall_clock64() : 0ull; }
+__device__ __forceinline__ void stamp_end(unsigned long long* st, unsigned long long t0) {
+    if (st && threadIdx.x == 0) { atomicMin(st, t0); atomicMax(st + 1, (unsigned long long)wall_clock64()); }
+}
 template <int BM, int BN, int WM, int WN, bool RICH, bool TN, int KT = 64, int NS = 2, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void k_gemm_nt(GemmArgs p_in) {
+    const unsigned long long t0 = stamp_begin(p_in.stamp);
     gemm_body<BM, BN, WM, WN, RICH, TN, KT, NS, DBG>(p_in, blockIdx.x);
+    stamp_end(p_in.stamp, t0);
 }
 
 // Several K-major products in ONE launch (the weight gradients of a backward stage: dW_x and dW_h of a layer; projection,
@@ -557,14 +566,16 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_wgs_per_cu(BM, BN, KT, NS)) void
 // filled by the next product's head.  Product i owns workgroups [first[i], first[i+1]) (multiples of 8, so that the
 // XCD-locality order inside a product still sees workgroup L on XCD L % 8; the few padding workgroups exit at once).
 #define E2T_GEMM_GROUP_MAX 8
-struct GemmGroupArgs { int n; int first[E2T_GEMM_GROUP_MAX + 1]; int count[E2T_GEMM_GROUP_MAX]; GemmArgs p[E2T_GEMM_GROUP_MAX]; };
+struct GemmGroupArgs { int n; int first[E2T_GEMM_GROUP_MAX + 1]; int count[E2T_GEMM_GROUP_MAX]; GemmArgs p[E2T_GEMM_GROUP_MAX]; unsigned long long* stamp; };
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_group(GemmGroupArgs g) {
+    const unsigned long long t0 = stamp_begin(g.stamp);
     int i = 0;
 #pragma unroll
     for (int j = 1; j < E2T_GEMM_GROUP_MAX; ++j) if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
     const int L = (int)blockIdx.x - g.first[i];
     if (L >= g.count[i]) return;
     gemm_body<128, 128, 2, 2, false, true, 64, 2, 0>(g.p[i], L);
+    stamp_end(g.stamp, t0);
 }
 
 // C[m][n] (+)= epilogue(sum_s slab[s][m][n]) in fixed split order (deterministic); 4 consecutive columns per thread so
@@ -1020,6 +1031,29 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
     return E2T_OK;
 }
 
+// ---- measurement hook: per-launch [start, end] stamps of the GEMM kernels (bench.py measures the IN-STEP duration of the launches
+// of a replayed graph with it; null = off, the normal state) ----
+static unsigned long long* g_stamp_buf = nullptr;
+static int g_stamp_slots = 0, g_stamp_seq = 0;
+static int g_stamp_kind[E2T_GEMM_STAMP_MAX];
+static unsigned long long* next_stamp(int kind) {
+    if (!g_stamp_buf || g_stamp_slots <= 0) return nullptr;
+    const int slot = g_stamp_seq++ % g_stamp_slots;
+    g_stamp_kind[slot] = kind;
+    return g_stamp_buf + 2 * slot;
+}
+extern "C" int e2t_gemm_stamps(void* buf, int slots) {
+    E2T_CHECK_ARG(slots >= 0 && slots <= E2T_GEMM_STAMP_MAX && (buf || slots == 0));
+    g_stamp_buf = (unsigned long long*)buf; g_stamp_slots = buf ? slots : 0; g_stamp_seq = 0;
+    for (int i = 0; i < E2T_GEMM_STAMP_MAX; ++i) g_stamp_kind[i] = -1;
+    return E2T_OK;
+}
+extern "C" int e2t_gemm_stamp_kinds(int* kinds, int n) {
+    E2T_CHECK_ARG(kinds && n >= 0 && n <= E2T_GEMM_STAMP_MAX);
+    for (int i = 0; i < n; ++i) kinds[i] = g_stamp_kind[i];
+    return E2T_OK;
+}
+
 struct GemmPlan { int tile, splits, batch; bool want_split; };
 static int gemm_order() {
     static const int o = e2t_dbg_int("E2T_GEMM_ORDER", 1) == 0 ? 0 : 1;
@@ -1198,6 +1232,7 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     E2T_CHECK_ARG(!(tn && rich_ep && p.splits <= 1));
     const dim3 grid((unsigned)(ntm * ntn * p.splits * batch));
     const hipStream_t st = (hipStream_t)stream;
+    p.stamp = next_stamp(tn ? (big ? E2T_GEMM_KIND_TN256 : E2T_GEMM_KIND_TN128) : (big ? E2T_GEMM_KIND_NT256 : E2T_GEMM_KIND_NT128));
     // every instance asks for its LDS explicitly (above the 64-KiB default for most of them)
 #define E2T_GEMM_GO(BM_, BN_, WM_, WN_, RICH_, TN_, KT_, NS_, D_)                                                           \
     do {                                                                                                                    \
@@ -1312,6 +1347,7 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
     }
     g.first[m] = first;
     g.n = m;
+    g.stamp = next_stamp(E2T_GEMM_KIND_TN128G);
     static const hipError_t rc_ = hipFuncSetAttribute((const void*)k_gemm_tn_group, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(128, 128, 64, 2));
     if (rc_ != hipSuccess) { e2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(rc_)); return E2T_ERR_HIP; }
     hipLaunchKernelGGL(k_gemm_tn_group, dim3((unsigned)first), dim3(256), gemm_lds_bytes(128, 128, 64, 2), (hipStream_t)stream, g);

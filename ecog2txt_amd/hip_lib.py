@@ -75,6 +75,8 @@ SIGNATURES = {
     'e2t_gemm_tn_bf16': [_p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     'e2t_gemm_tn_group_bf16': [_i, C.POINTER(GemmCall), _p],
     'e2t_gemm_plan': [_i, _i, _i, _i, C.POINTER(GemmEpilogue), C.POINTER(_i), C.POINTER(_i)],
+    'e2t_gemm_stamps': [_p, _i],
+    'e2t_gemm_stamp_kinds': [C.POINTER(_i), _i],
     'e2t_transpose_bf16': [_p, _i, _i, _i, _p, _i, _p],
     'e2t_cast_pack': [_p, _l, _l, _i, _i, _p, _i, _p],
     'e2t_pack_frag': [_p, _l, _l, _i, _i, _p, _p],

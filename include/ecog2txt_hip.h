@@ -146,6 +146,16 @@ int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls /* host array */, v
 /* which instance e2t_gemm_{nt,tn}_bf16 would run this product on: *tile = 128 or 256 (square tiles), *splits = K splits
  * (1: none).  For profiling tools that attribute time to kernel instances (bench.py). */
 int e2t_gemm_plan(int tn, int M, int N, int K, const e2t_gemm_epilogue* ep, int* tile, int* splits);
+/* ABI 6 -- measurement hook (bench.py's `roofline`): with a device buffer of 2 * slots unsigned 64-bit words set, the k-th GEMM launch
+ * issued afterwards (slot k % slots; a grouped launch counts once, a product the library cuts into two launches twice) records
+ * stamp[2*slot] = min over its workgroups of the start time, stamp[2*slot + 1] = max of the end time, on the chip-wide 100-MHz clock
+ * -- the duration a kernel trace reports for the launch, readable inside a replayed hipGraph (the caller resets the words to
+ * ~0 / 0 between replays).  e2t_gemm_stamp_kinds returns the instance of each slot (E2T_GEMM_KIND_*, -1 = unused).
+ * buf = NULL switches the hook off (the default: the kernels then execute one scalar compare more). */
+#define E2T_GEMM_STAMP_MAX 512
+enum { E2T_GEMM_KIND_TN128G = 0, E2T_GEMM_KIND_TN128 = 1, E2T_GEMM_KIND_TN256 = 2, E2T_GEMM_KIND_NT128 = 3, E2T_GEMM_KIND_NT256 = 4 };
+int e2t_gemm_stamps(void* buf, int slots);
+int e2t_gemm_stamp_kinds(int* kinds, int n);
 /* a5+a6 in ONE pass over x: E[(t',b)][n] = epilogue(sum_{w,c} bf16(x[b][len-1-(t'*N+w)][c]) * WT[n][w*C+c]),
  * WT bf16 [F][ldw] K-contiguous (the conv image of e2t_pack_batch), E bf16 [S*B][lde]; ep: bias, flags (OUT_BF16 required,
  * RELU, DROPOUT), row_lens / rows_per_step (decimated lengths: rows beyond them are zeroed), dropout fields, splitk_ws

@@ -653,6 +653,36 @@ def test_gemm_nt_last_round_leaves_as_a_second_launch(hl):
         np.testing.assert_allclose(host(c), ref, rtol=1e-4, atol=2e-2)
 
 
+def test_gemm_stamp_hook_times_every_launch(hl):
+    """e2t_gemm_stamps (bench.py's live in-step timing): with a buffer set, every GEMM launch records [first workgroup start, last
+    workgroup end] on the 100-MHz clock in the next slot, tagged with its instance; off again, nothing is written."""
+    rng = np.random.default_rng(1)
+    M, N, K = 300, 260, 512
+    a, b = dev_bf16(rng.standard_normal((M, K))), dev_bf16(rng.standard_normal((N, K)))
+    c = torch.zeros(M, N, dtype=torch.float32, device='cuda')
+    stamps = torch.tensor([-1, 0] * 8, dtype=torch.int64, device='cuda')
+    hl.lib.e2t_gemm_stamps(stamps.data_ptr(), 8)
+    try:
+        for _ in range(3):
+            hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N, K, None, st())
+        torch.cuda.synchronize()
+        kinds = (C.c_int * 8)()
+        hl.lib.e2t_gemm_stamp_kinds(kinds, 8)
+    finally:
+        hl.lib.e2t_gemm_stamps(None, 0)
+    sv = stamps.cpu().numpy().view(np.uint64).reshape(8, 2)
+    assert list(kinds)[:3] == [3, 3, 3] and list(kinds)[3:] == [-1] * 5              # E2T_GEMM_KIND_NT128
+    for k in range(3):
+        us = (int(sv[k, 1]) - int(sv[k, 0])) * 0.01
+        assert 0.5 < us < 500.0, us
+    assert sv[0, 0] <= sv[1, 0] <= sv[2, 0]                                            # launches of one stream, in order
+    assert np.all(sv[3:, 1] == 0)
+    before = stamps.clone()
+    hl.lib.e2t_gemm_nt_bf16(a.data_ptr(), K, b.data_ptr(), K, c.data_ptr(), N, M, N, K, None, st())
+    torch.cuda.synchronize()
+    assert torch.equal(before, stamps)
+
+
 @pytest.mark.parametrize('G', [1, 2, 3])
 def test_grouped_row_order_of_the_conv_stack(hl, G):
     """e2t_conv_pack_grouped / e2t_conv_unpack_grad_grouped / e2t_gemm_epilogue.row_group: row m = (tg*B + b)*G + g holds step
