@@ -1169,6 +1169,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 # data parallel: the single graph with the collectives as nodes; should the runtime refuse to record a
                 # collective, the step falls back to one graph per stage with the collectives issued between them
                 try:
+                    if hasattr(sync, 'warm_up'):
+                        # every collective shape of the step once OUTSIDE the capture (RCCL's lazy set-up must not run inside one)
+                        sync.warm_up([b - a for (_, _, rr) in self.backward_stages(ws) for a, b in rr])
                     g = self._capture_step(ws, sync, gc)
                 except RuntimeError as e:
                     print('ecog2txt_amd: the data-parallel step could not be captured as one graph (%s); using one graph per '

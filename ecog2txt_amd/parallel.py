@@ -173,6 +173,27 @@ class RcclSync:
         self.pending_ranges = []
         self._flag_pending = False
 
+    def warm_up(self, sizes):
+        """One eager all-reduce per message size the captured step will issue (fp32 ranges of `sizes` elements, the int32 flag
+        word), on scratch memory, and a device synchronisation: RCCL sets a collective's channels, protocols and peer connections
+        up when it first runs one of that shape -- allocations and IPC exchanges that must not happen while a stream is being
+        captured.  Called once per communicator before the first capture."""
+        if getattr(self, '_warm', None) is None:
+            self._warm = set()
+        todo = sorted(set(int(n) for n in sizes if n > 0) - self._warm)
+        if not todo and 'flag' in self._warm:
+            return
+        st = torch.cuda.current_stream().cuda_stream
+        scratch = torch.zeros(max(todo + [1]), dtype=torch.float32, device=self.g.device)
+        for n in todo:
+            self.lib.e2t_comm_allreduce_f32(self.comm, scratch.data_ptr(), n, st, None)
+            self._warm.add(n)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.g.device)
+        self.lib.e2t_comm_allreduce_i32(self.comm, flag.data_ptr(), 1, st, None)
+        self._warm.add('flag')
+        self.lib.e2t_comm_wait(self.comm, -1, st)
+        torch.cuda.current_stream().synchronize()
+
     def attach(self):
         """The communicator's stream is ordered behind the current stream's work so far and issues nothing: a captured step
         calls this on its main stream before anything else, so that the communicator's stream enters the capture from the
