@@ -10,8 +10,17 @@ on one batch of synthetic ECoG already resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); weak scaling:
-every rank steps its own B utterances, gradients are all-reduced every step.
-Prints ONE JSON line on rank 0.
+every rank steps its own B utterances, gradients are all-reduced every step (the collectives
+are nodes of the step's one hipGraph).  Prints ONE JSON line on rank 0:
+  value / ms_per_step   whole-job utterances/s and step time over the timed region;
+  roofline              the dominant rocprof row (K-major grouped GEMM): `frac` / `achieved` IN-STEP, measured live through
+                        the kernels' stamp hook over ten replays of a stamped step graph; `frac_isolated` = the same launches
+                        replayed alone between HIP events; `frac_in_step_profile` = priced at the committed rocprofv3 row;
+                        `traffic` = HBM bytes per launch of the committed PMC pass; roofline_all_gemm_instances: every instance;
+  recurrence / recurrent_gemm_frac_of_peak   per-step time of the persistent recurrences, the north-star fraction;
+  decode                greedy (eager / graph-replayed) and beam-4 decode of the batch, ms per batch;
+  configs               cfg3 / cfg4 / cfg5 (fp32 and bf16-staged inputs) measured in the same process (N = 1 only);
+  cpu_baseline          the torch-CPU port of the same step on the box's host cores (N = 1 only).
 """
 import argparse
 import json
