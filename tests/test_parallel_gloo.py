@@ -49,6 +49,11 @@ def _worker(rank, world, port, q):
     for nm in names:
         a, b = store.seg_range(nm)
         sync.allreduce_range(a, b)
+    # the ranks' "this step is invalid" words are summed with the gradients: rank 1 raises it, every rank must see it
+    flag = torch.tensor([7 if rank == 1 else 0], dtype=torch.int32)
+    sync.allreduce_flag(flag)
+    sync.wait_flag()
+    assert int(flag.item()) == 7, int(flag.item())
     sync.wait()
     store.g.mul_(sync.grad_scale)
     out = store.export_tf('g')
