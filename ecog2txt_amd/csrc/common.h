@@ -105,6 +105,14 @@ __device__ __forceinline__ void dma16_to_lds_sc1(const void* gsrc, unsigned lds_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(m) : "memory");
 }
+// same, non-temporal: data that is read exactly once (the input projections a recurrence streams) should not displace the lines
+// the hand-off lives on (the exchange buffers in the XCD's L2)
+__device__ __forceinline__ void dma16_to_lds_nt(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(m) : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void dma_wait_all_but2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 // at most N vector-memory operations of this wave still outstanding (they retire in issue order)

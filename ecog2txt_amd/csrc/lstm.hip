@@ -247,6 +247,7 @@ struct LstmFwdArgs {
     float forget_bias;
     DropCfg drop;
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
+    int gx_nt;              // persistent kernels: prefetch Gx with the non-temporal policy (set by the launcher for long sequences)
 };
 
 __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
@@ -474,7 +475,14 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
         const bf16_t* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (u0 < H ? u0 : 0)) * 4;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) dma16_to_lds(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
+        // Gx is read exactly once.  Where a layer's Gx exceeds the infinity cache (cfg5: 273 MB) the stream goes out non-temporal:
+        // with the default policy it displaced what the step lives on and the whole train step was 4 % slower (6.94 -> 6.65 ms same
+        // box; the recurrence ALONE measures the same either way); where Gx is cache-resident (cfg2: 55 MB, written by the
+        // projection GEMM just before) the default policy is the faster one (2.70 vs 3.43 us per step alone, step equal)
+        for (int r = 0; r < 2; ++r) {
+            if (p.gx_nt) dma16_to_lds_nt(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
+            else dma16_to_lds(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
+        }
     };
     gx_load(0);
     if (S > 1) gx_load(1);
@@ -729,7 +737,14 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
         const int tt = act ? (dir ? (len - 1 - s) : s) : 0;
         const bf16_t* q = p.Gx + (((size_t)tt * B + bc) * NH + dir * H + (own ? u0 : 0)) * 4;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) dma16_to_lds(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
+        // Gx is read exactly once.  Where a layer's Gx exceeds the infinity cache (cfg5: 273 MB) the stream goes out non-temporal:
+        // with the default policy it displaced what the step lives on and the whole train step was 4 % slower (6.94 -> 6.65 ms same
+        // box; the recurrence ALONE measures the same either way); where Gx is cache-resident (cfg2: 55 MB, written by the
+        // projection GEMM just before) the default policy is the faster one (2.70 vs 3.43 us per step alone, step equal)
+        for (int r = 0; r < 2; ++r) {
+            if (p.gx_nt) dma16_to_lds_nt(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
+            else dma16_to_lds(q + r * 8, lds_addr_of(gxl + ((s % 3) * 2 + r) * 64));
+        }
     };
     gx_load(0);
     if (S > 1) gx_load(1);
@@ -1448,6 +1463,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* G
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     pa.hx = (bf16_t*)hx; pa.err = err;
     p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
+    p.gx_nt = (size_t)d->S * d->B * d->ndir * d->H * 4 * sizeof(bf16_t) > ((size_t)128 << 20);     // beyond half the 256-MB infinity cache
     if (p.KB > 13 && p.KB <= 26 && d->H % 8 == 0) {
         // wide layer: 32 x 32 workgroups, K halves in the accumulation order of k_lstm_step_fwd (its LDS chunk geometry)
         LstmPersistWideArgs pw{};
@@ -1546,6 +1562,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
+    // (the BPTT's prefetch of the saved gates / cells / dY with the non-temporal policy was measured at cfg5: no difference)
     pa.dgx = (bf16_t*)dgx; pa.flags = flags; pa.err = err;
     const int RT = (d->B + 15) / 16;
     const int kq = (p.KB4 + 3) / 4;
