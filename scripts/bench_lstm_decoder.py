@@ -1,4 +1,5 @@
-"""Micro-benchmark: decoder recurrences (H=800, L steps) -- persistent wide kernels vs launch-per-step."""
+"""Micro-benchmark: decoder recurrences (cfg2: H = 800; cfg4: H = 2048), L steps -- persistent wide kernels vs launch-per-step.
+    python scripts/bench_lstm_decoder.py [cfg2|cfg4]"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +9,8 @@ import torch
 import bench
 from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
 from ecog2txt_amd.hip_lib import lib
-kw, B, T, L = bench.CONFIGS['cfg2']
+CFG = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+kw, B, T, L = bench.CONFIGS[CFG]
 eng = Seq2SeqEngine(NetSpec(**kw), seed=1)
 eng.init_params(0)
 ws = eng.workspace(401, B, T, L)
@@ -30,11 +32,11 @@ def timeit(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 x = ws['e'].data_ptr()
-for mode in ('1', '0'):
+for mode in (('1', '0') if lay.H <= 832 else ('0',)):
     eng.persistent_fwd = eng.persistent_bwd = mode == '1'
     f = timeit(lambda: lay.fwd(lw, x, ws['dlens'], eng.store.p, True, c0=ws['c0'], steps=(0, S)))
     b = timeit(lambda: lay.bwd_rec(lw, x, ws['dlens'], ws['dHd'].data_ptr(), lay.ldy, True, None, 0, c0=ws['c0'], dh0=ws['dh0'], dc0=ws['dc0']))
-    print('decoder S=%d persistent=%s: fwd %.1f us (%.2f us/step)   bwd %.1f us (%.2f us/step incl. pseudo-step)' % (S, mode, f, f / S, b, b / (S + 1)))
+    print(CFG + ' decoder S=%d persistent=%s: fwd %.1f us (%.2f us/step)   bwd %.1f us (%.2f us/step incl. pseudo-step)' % (S, mode, f, f / S, b, b / (S + 1)))
 assert int(eng.sync_err[0].item()) == 0
 if os.environ.get('TIMELINE'):
     # per-wave phase stamps of the persistent BPTT (wide instance) at step S/2

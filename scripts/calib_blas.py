@@ -44,6 +44,8 @@ SHAPES = {
              ('dW_x l0 (K-major)', 'tn', 101, 8192, 8704, 1), ('proj dW (K-major)', 'tn', 1806, 2049, 2560, 1),
              ('Gx (NT)', 'nt', 8704, 8192, 2112, 1), ('dIn (NT)', 'nt', 8704, 2112, 8192, 1), ('Gx l0 (NT)', 'nt', 8704, 8192, 128, 1),
              ('Gx dec (NT)', 'nt', 2560, 8192, 192, 1), ('proj (NT)', 'nt', 2560, 1806, 2112, 1)],
+    # the H_d = 2048 decoder's recurrent products of ONE time step as plain GEMMs (cfg4): what a GEMM + cell-kernel step would cost
+    'dec4': [('dec rec fwd, one step (NT)', 'nt', 256, 8192, 2048, 1), ('dec rec bwd, one step (NT)', 'nt', 256, 2048, 8192, 1)],
     'cfg5': [('dW_x (K-major)', 'tn', 801, 3200, 42752, 1), ('dW_h x2 (K-major)', 'tn', 400, 1600, 42752, 2),
              ('conv dW (K-major)', 'tn', 12289, 100, 42752, 1), ('Gx (NT)', 'nt', 42752, 3200, 832, 1), ('dIn (NT)', 'nt', 42752, 832, 3200, 1),
              ('aux fwd (NT)', 'nt', 42752, 225, 832, 1)],
