@@ -319,13 +319,16 @@ __device__ __forceinline__ int pack_units(const e2t_pack_desc& d) {
         case 0: return d.d0 * ((d.d1 + 255) / 256);
         case 3: return d.d0 * ((d.d1 + 1023) / 1024);
         case 2: case 4: return ((d.d0 + 63) / 64) * ((d.d1 + 63) / 64);
-        case 5: return ((NT + 3) / 4) * d.ld;
-        case 6: return NT * d.ld;
+        case 5: return ((NT + 3) / 4) * ((d.ld + 1) / 2);
+        case 6: return NT * ((d.ld + 1) / 2);
         default: return (NT * d.ld + 3) / 4;
     }
 }
-__device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, const float* src, bf16_t* dst);
+__device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, const float* src, bf16_t* dst, float* lds);
 __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, int ndesc, const float* base) {
+    // ONE staging buffer for every kind that goes through LDS (a 64 x 64 transpose tile, or two [32 k][64 n] blocks): the kinds
+    // used to declare their own arrays -- 50 KB of LDS together, three workgroups per CU for a kernel that lives on loads in flight
+    __shared__ __attribute__((aligned(16))) float pk_lds[64 * 68];
     // binary search for the descriptor that owns this workgroup (uniform)
     int lo = 0, hi = ndesc - 1;
     const int bid = blockIdx.x;
@@ -365,9 +368,14 @@ __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, 
             ok[j] = f < NT * KB;
             const int nt = f / KB, kb = f - nt * KB;
             const int n = nt * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 8;
+            // (out-of-range pieces load the source's first 16 B and are zeroed afterwards: `cond ? *p : zero` made hipcc select
+            //  between p and a zero kept in SCRATCH and load through flat addressing)
+            const bool va = ok[j] && n < d.d0 && k0 < d.d1, vb = ok[j] && n < d.d0 && k0 + 4 < d.d1;
             const float* sp = src + (size_t)n * d.s0 + k0;
-            a[j] = (ok[j] && n < d.d0 && k0 < d.d1) ? *(const float4*)sp : z;
-            b2[j] = (ok[j] && n < d.d0 && k0 + 4 < d.d1) ? *(const float4*)(sp + 4) : z;
+            a[j] = *(const float4*)(va ? sp : src);
+            b2[j] = *(const float4*)(vb ? sp + 4 : src);
+            if (!va) a[j] = z;
+            if (!vb) b2[j] = z;
         }
 #pragma unroll
         for (int j = 0; j < E2T_PACK_UNITS; ++j) {
@@ -382,12 +390,56 @@ __global__ __launch_bounds__(256) void k_pack_batch(const e2t_pack_desc* descs, 
     }
     const int G = (d.kind == 1) ? E2T_PACK_UNITS : 1;
     const int u0 = (bid - d.first_block) * G;
-    for (int u = u0; u < min(units, u0 + G); ++u) pack_unit(d, u, src, dst);
+    if (d.kind == 5 || d.kind == 6) {
+        // fragment images of sources contiguous along n.  Kind 6: the four per-gate images of a gate-interleaved LSTM kernel (TF
+        // layout [k][unit*4 + gate]) from ONE pass over the source; kind 5: four n tiles.  A workgroup takes TWO k-blocks: two
+        // [32 k][64 columns] blocks staged with 16-B loads (256 B contiguous per k-row), all four loads of a thread in flight
+        // together (one block per workgroup moved 8 KiB per launch-and-round-trip: 0.7 TB/s); wave g then emits the fragments of
+        // gate g (kind 6) / n tile ntq*4 + g (kind 5) of both k-blocks: 2 KiB contiguous.  d0 = units (kind 6) or n (kind 5),
+        // d1 = K, s1 = k stride, ld = KB; kind 6: image g starts at fragment g*UT*KB.
+        const int lb = bid - d.first_block;
+        const int KB = d.ld, KBG = (KB + 1) >> 1, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int NT = (d.d0 + 15) / 16;
+        const int ut = lb / KBG, kb0 = (lb - ut * KBG) * 2;
+        const int n4 = (threadIdx.x & 15) * 4;
+        const int ncols = d.kind == 6 ? 4 * d.d0 : d.d0;
+        float4 v[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kl = (threadIdx.x >> 4) + 16 * i;
+                const int np = ut * 64 + n4, k = (kb0 + u) * 32 + kl;
+                const bool in = np < ncols && k < d.d1;
+                v[u][i] = *(const float4*)(in ? src + (size_t)np + (size_t)k * d.s1 : src);
+                if (!in) v[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *(float4*)&pk_lds[(u * 32 + (threadIdx.x >> 4) + 16 * i) * 68 + n4] = v[u][i];
+        __syncthreads();
+        const int nt = ut * 4 + g;
+        if (d.kind == 5 && nt >= NT) return;
+        const int col = d.kind == 6 ? (lane & 15) * 4 + g : g * 16 + (lane & 15);
+        const size_t f0 = d.kind == 6 ? ((size_t)g * NT + ut) * KB + kb0 : (size_t)nt * KB + kb0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (kb0 + u >= KB) break;
+            const float* b = &pk_lds[(u * 32 + (lane >> 4) * 8) * 68 + col];
+            uint4 o;
+            o.x = f2bf(b[0]) | ((unsigned)f2bf(b[68]) << 16); o.y = f2bf(b[2 * 68]) | ((unsigned)f2bf(b[3 * 68]) << 16);
+            o.z = f2bf(b[4 * 68]) | ((unsigned)f2bf(b[5 * 68]) << 16); o.w = f2bf(b[6 * 68]) | ((unsigned)f2bf(b[7 * 68]) << 16);
+            ((uint4*)dst)[(f0 + u) * 64 + lane] = o;
+        }
+        return;
+    }
+    for (int u = u0; u < min(units, u0 + G); ++u) pack_unit(d, u, src, dst, pk_lds);
 }
-__device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, const float* src, bf16_t* dst) {
+__device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, const float* src, bf16_t* dst, float* lds) {
     if (d.kind == 4) {
         // kind 2 with 16-B loads along the source's contiguous direction and 8-B stores (d0 % 4 == 0, d1 % 4 == 0, s1 % 4 == 0)
-        __shared__ float tile[64][65];                      // tile[c][r]
+        float (*tile)[65] = (float (*)[65])lds;              // tile[c][r]
         const int tcn = (d.d1 + 63) / 64;
         const int tr = lb / tcn, tc = lb - tr * tcn;
         const int a4 = (threadIdx.x & 15) * 4, b = threadIdx.x >> 4;
@@ -408,7 +460,7 @@ __device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, 
                                                                          f2bf(tile[a4 + 2][b + 16 * i]), f2bf(tile[a4 + 3][b + 16 * i]));
         }
     } else if (d.kind == 2) {
-        __shared__ float tile[64][65];
+        float (*tile)[65] = (float (*)[65])lds;
         const int tcn = (d.d1 + 63) / 64;
         const int tr = lb / tcn, tc = lb - tr * tcn;
         const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -427,57 +479,6 @@ __device__ __forceinline__ void pack_unit(const e2t_pack_desc& d, const int lb, 
         const int cb = (d.d1 + 255) / 256;                 // column blocks per row
         const int r = lb / cb, c = (lb - r * cb) * 256 + threadIdx.x;
         if (r < d.d0 && c < d.d1) dst[(size_t)r * d.ld + c] = f2bf(src[(size_t)r * d.s0 + (size_t)c * d.s1]);
-    } else if (d.kind == 6) {
-        // the four per-gate fragment images of a gate-interleaved LSTM kernel (TF layout [k][unit*4 + gate]) from ONE pass
-        // over the source: a [32 k][16 units x 4 gates] block is staged with 16-B loads (256 B contiguous per k-row), wave g
-        // emits the fragment of gate g.  d0 = units, d1 = K, s1 = k stride, ld = KB; image g starts at fragment g*UT*KB.
-        __shared__ float blk[32][68];
-        const int KB = d.ld, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-        const int UT = (d.d0 + 15) / 16;
-        const int ut = lb / KB, kb = lb - ut * KB;
-        const int n4 = (threadIdx.x & 15) * 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kl = (threadIdx.x >> 4) + 16 * i;
-            const int np = ut * 64 + n4, k = kb * 32 + kl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (np < 4 * d.d0 && k < d.d1) v = *(const float4*)(src + (size_t)np + (size_t)k * d.s1);
-            *(float4*)&blk[kl][n4] = v;
-        }
-        __syncthreads();
-        bf16_t o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(blk[(lane >> 4) * 8 + j][(lane & 15) * 4 + g]);
-        uint4 v;
-        v.x = o[0] | ((unsigned)o[1] << 16); v.y = o[2] | ((unsigned)o[3] << 16);
-        v.z = o[4] | ((unsigned)o[5] << 16); v.w = o[6] | ((unsigned)o[7] << 16);
-        ((uint4*)dst)[(((size_t)g * UT + ut) * KB + kb) * 64 + lane] = v;
-    } else if (d.kind == 5) {
-        // kind 1 for sources contiguous along n (s0 == 1): a workgroup stages a [32 k][64 n] block with 16-B loads (256 B
-        // contiguous per k-row) and each wave emits one of the 4 fragments (caller: s1, src_off, d0 multiples of 4)
-        __shared__ float blk[32][68];
-        const int KB = d.ld, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const int NT = (d.d0 + 15) / 16;
-        const int ntq = lb / KB, kb = lb - ntq * KB;
-        const int n4 = (threadIdx.x & 15) * 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kl = (threadIdx.x >> 4) + 16 * i;
-            const int n = ntq * 64 + n4, k = kb * 32 + kl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < d.d0 && k < d.d1) v = *(const float4*)(src + (size_t)n + (size_t)k * d.s1);
-            *(float4*)&blk[kl][n4] = v;
-        }
-        __syncthreads();
-        const int nt = ntq * 4 + w;
-        if (nt >= NT) return;
-        bf16_t o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(blk[(lane >> 4) * 8 + j][w * 16 + (lane & 15)]);
-        uint4 v;
-        v.x = o[0] | ((unsigned)o[1] << 16); v.y = o[2] | ((unsigned)o[3] << 16);
-        v.z = o[4] | ((unsigned)o[5] << 16); v.w = o[6] | ((unsigned)o[7] << 16);
-        ((uint4*)dst)[((size_t)nt * KB + kb) * 64 + lane] = v;
     } else {
         const int KB = d.ld, lane = threadIdx.x & 63;
         const int f = lb * 4 + (threadIdx.x >> 6);          // fragment index nt*KB + kb

@@ -122,9 +122,9 @@ class PackingMixin:
                     d.kind, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld = (6 if four else 5 if tiled else 1), off, ns, ks, Nn, Kk, KB
                     d.dst = dst.data_ptr()
                     if four:
-                        units = ceil_div(Nn, 16) * KB
+                        units = ceil_div(Nn, 16) * ceil_div(KB, 2)           # (kinds 5 and 6: two k-blocks per workgroup)
                     else:
-                        units = ceil_div(ceil_div(Nn, 16), 4) * KB if tiled else ceil_div(ceil_div(Nn, 16) * KB, 4)
+                        units = ceil_div(ceil_div(Nn, 16), 4) * ceil_div(KB, 2) if tiled else ceil_div(ceil_div(Nn, 16) * KB, 4)
                     nblk += ceil_div(units, 1 if (tiled or four) else H.PACK_UNITS)
             raw = bytes(descs)
             return (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(ops), nblk)

@@ -183,10 +183,10 @@ typedef struct e2t_pack_desc {
                                d0*ceil(d1/1024) workgroups
                             4: as 2 with 16-B loads / 8-B stores (d0, d1, s1, src_off, ld multiples of 4; dst 8-B aligned)
                             5: as 1 for s0 == 1 (contiguous along n; d0, s1, src_off multiples of 4): [32 k][64 n] blocks
-                               through LDS, ceil(ceil(d0/16)/4) * ceil(d1/32) workgroups
+                               through LDS, two k-blocks per workgroup: ceil(ceil(d0/16)/4) * ceil(ceil(d1/32)/2) workgroups
                             6: the four per-gate fragment images [4][ceil(d0/16)][ld] (contiguous at dst) of a gate-interleaved
                                source Bn_g[n][k] = src[(n*4 + g) + k*s1], n < d0 units, k < d1 (s1, src_off multiples of 4):
-                               one pass over the source, ceil(d0/16) * ceil(d1/32) workgroups */
+                               one pass over the source, two k-blocks per workgroup: ceil(d0/16) * ceil(ceil(d1/32)/2) workgroups */
     int first_block;     /* first 256-thread workgroup of this descriptor (exclusive prefix, ascending) */
     long long src_off;   /* element offset into the fp32 base */
     long long s0, s1;

@@ -427,7 +427,7 @@ def test_pack_batch_all_kinds(hl):
     fr = lambda off, s0, s1, d0, d1, ld: ('frag', np.array([[base[off + n * s0 + k * s1] for k in range(d1)] for n in range(d0)]))
     cases.append((1, 7, 3, 61, 20, 40, 2, -(-(2 * 2) // 4), fr))                      # scalar path
     cases.append((1, 12, 100, 1, 36, 72, 3, -(-(3 * 3) // 4), fr))                    # k-contiguous: 16-B loads
-    cases.append((5, 20, 1, 44, 40, 70, 3, -(-3 // 4) * 3, fr))                        # n-contiguous via LDS
+    cases.append((5, 20, 1, 44, 40, 70, 3, -(-3 // 4) * -(-3 // 2), fr))                # n-contiguous via LDS: 2 k-blocks per workgroup, odd count
     descs = (hl.PackDesc * (len(cases) + 1))()
     outs, nblk = [], 0
     for i, (kind, off, s0, s1, d0, d1, ld, units, _) in enumerate(cases):
@@ -438,13 +438,13 @@ def test_pack_batch_all_kinds(hl):
         d.kind, d.first_block, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld, d.dst = kind, nblk, off, s0, s1, d0, d1, ld, o.data_ptr()
         nblk += -(-units // U) if kind in (1, 3) else units
     # 6: four gate images from a gate-interleaved source [k][unit*4 + gate]
-    Hh, Kk, s1 = 24, 40, 4 * 24
+    Hh, Kk, s1 = 24, 72, 4 * 24                      # 3 k-blocks: two per workgroup, the last workgroup of a unit tile half empty
     off6 = 100000
     UT, KB = -(-Hh // 16), -(-Kk // 32)
     o6 = torch.full((4 * UT * KB * 512 + 64,), 7.0, dtype=torch.bfloat16, device='cuda')
     d = descs[len(cases)]
     d.kind, d.first_block, d.src_off, d.s0, d.s1, d.d0, d.d1, d.ld, d.dst = 6, nblk, off6, 4, s1, Hh, Kk, KB, o6.data_ptr()
-    nblk += UT * KB
+    nblk += UT * -(-KB // 2)
     dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to('cuda')
     hl.lib.e2t_pack_batch(dev.data_ptr(), len(cases) + 1, nblk, bt.data_ptr(), st())
     torch.cuda.synchronize()
