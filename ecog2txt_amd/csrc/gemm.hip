@@ -464,16 +464,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p_in, const int L /* w
         const bool kin = kk < p.K;
         uint4* sa = smem + cur * STAGE;
         uint4* sb = sa + BM * 8;
-        const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < BM / (NT / 8); ++i) {
             const int r = srow + (NT / 8) * i, gm = m0 + r;
-            sa[swz(r, schunk)] = (kin && gm < p.M) ? *(const uint4*)(p.A + (size_t)gm * p.lda + kk) : zero4;
+            // (`cond ? *p : zero` makes hipcc select between p and a zero kept in SCRATCH and load through flat addressing: the
+            //  out-of-range lanes load the operand's first 16 B instead and are masked to zero)
+            const bool in = kin && gm < p.M;
+            uint4 v = *(const uint4*)(in ? p.A + (size_t)gm * p.lda + kk : p.A);
+            const unsigned mk = in ? 0xFFFFFFFFu : 0u;
+            sa[swz(r, schunk)] = make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
         }
 #pragma unroll
         for (int i = 0; i < BN / (NT / 8); ++i) {
             const int r = srow + (NT / 8) * i, gn = n0 + r;
-            sb[swz(r, schunk)] = (kin && gn < p.N) ? *(const uint4*)(p.B + (size_t)gn * p.ldb + kk) : zero4;
+            const bool in = kin && gn < p.N;
+            uint4 v = *(const uint4*)(in ? p.B + (size_t)gn * p.ldb + kk : p.B);
+            const unsigned mk = in ? 0xFFFFFFFFu : 0u;
+            sb[swz(r, schunk)] = make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
         }
         __syncthreads();
         if (!wave_dead) compute(cur, -1, 0);
