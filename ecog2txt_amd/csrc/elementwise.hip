@@ -762,13 +762,23 @@ __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, floa
     for (size_t i = tail0 + tid; i < n; i += nthr) adam_ema_1(p[i], g[i], m[i], v[i], ema[i], lr_t, b1, b2, eps, decay, gscale);
     float4* p4 = (float4*)(p + head); const float4* g4 = (const float4*)(g + head);
     float4* m4 = (float4*)(m + head); float4* v4 = (float4*)(v + head); float4* e4 = (float4*)(ema + head);
+    // g, m, v and the EMA shadow are touched exactly once per step: non-temporal loads and stores (they do not displace what the
+    // concurrent weight-gradient GEMMs live on: cfg2 1.601 -> 1.585 ms, cfg4 8.43 -> 8.36 ms same box; alone 633 -> 615 us for
+    // 98 M parameters = 5.7 TB/s).  p is re-read by the re-pack right behind the update: default policy.
+    typedef float f4 __attribute__((ext_vector_type(4)));
     for (size_t i = tid; i < n4; i += nthr) {
-        float4 pp = p4[i], mm = m4[i], vv = v4[i], ee = e4[i]; const float4 gg = g4[i];
-        adam_ema_1(pp.x, gg.x, mm.x, vv.x, ee.x, lr_t, b1, b2, eps, decay, gscale);
-        adam_ema_1(pp.y, gg.y, mm.y, vv.y, ee.y, lr_t, b1, b2, eps, decay, gscale);
-        adam_ema_1(pp.z, gg.z, mm.z, vv.z, ee.z, lr_t, b1, b2, eps, decay, gscale);
-        adam_ema_1(pp.w, gg.w, mm.w, vv.w, ee.w, lr_t, b1, b2, eps, decay, gscale);
-        m4[i] = mm; v4[i] = vv; p4[i] = pp; e4[i] = ee;
+        const f4 pv = ((f4*)p4)[i];
+        const f4 mv = __builtin_nontemporal_load((f4*)m4 + i), vv_ = __builtin_nontemporal_load((f4*)v4 + i);
+        const f4 ev = __builtin_nontemporal_load((f4*)e4 + i);
+        const f4 gg = __builtin_nontemporal_load((const f4*)g4 + i);
+        float P[4] = {pv.x, pv.y, pv.z, pv.w}, Mv[4] = {mv.x, mv.y, mv.z, mv.w}, V[4] = {vv_.x, vv_.y, vv_.z, vv_.w}, E[4] = {ev.x, ev.y, ev.z, ev.w};
+        const float G[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adam_ema_1(P[k], G[k], Mv[k], V[k], E[k], lr_t, b1, b2, eps, decay, gscale);
+        const f4 pp = {P[0], P[1], P[2], P[3]}, mm = {Mv[0], Mv[1], Mv[2], Mv[3]}, vv = {V[0], V[1], V[2], V[3]}, ee = {E[0], E[1], E[2], E[3]};
+        __builtin_nontemporal_store(mm, (f4*)m4 + i); __builtin_nontemporal_store(vv, (f4*)v4 + i);
+        ((f4*)p4)[i] = pp;
+        __builtin_nontemporal_store(ee, (f4*)e4 + i);
     }
 }
 
