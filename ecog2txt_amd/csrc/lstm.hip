@@ -105,6 +105,9 @@ __device__ __forceinline__ float4 gates_unpack(unsigned ij, unsigned fo) {
 }
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store_u4(void* p, uint4 v) { __builtin_nontemporal_store(*(u32x4_t*)&v, (u32x4_t*)p); }
+// (the cell-state saves are next read by the BPTT, a whole forward and half a backward pass later: at cfg5, where a layer's saves
+//  exceed the infinity cache, the non-temporal store is worth 1 % of the step -- 6.54 -> 6.48 ms same box; cfg2 / cfg4 unchanged)
+__device__ __forceinline__ void nt_store_f2(float* p, float a, float b) { typedef float f2_t __attribute__((ext_vector_type(2))); __builtin_nontemporal_store((f2_t){a, b}, (f2_t*)p); }
 __device__ __forceinline__ void nt_store_u2(void* p, uint2 v) { __builtin_nontemporal_store(*(unsigned long long*)&v, (unsigned long long*)p); }
 __device__ __forceinline__ float4 ld4(const float* p, bool vec, int n) {
     if (vec) return *(const float4*)p;
@@ -632,8 +635,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                     const uint2 a = gates_pack(gi[2 * rp], gj[2 * rp], gf[2 * rp], go[2 * rp]), c = gates_pack(gi[2 * rp + 1], gj[2 * rp + 1], gf[2 * rp + 1], go[2 * rp + 1]);
                     nt_store_u4(p.Gs + ((tile * 2 + rp) * 64 + lane) * 8, make_uint4(a.x, a.y, c.x, c.y));
                 }
-                ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
-                ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
+                nt_store_f2(p.Cs + ((tile * 2 + 0) * 64 + lane) * 2, cst[0], cst[1]);
+                nt_store_f2(p.Cs + ((tile * 2 + 1) * 64 + lane) * 2, cst[2], cst[3]);
                 if (p.Ydrop) {
                     float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
                     if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
@@ -893,8 +896,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist_wide(LstmPersistWi
                     const uint2 a = gates_pack(gi[2 * rp], gj[2 * rp], gf[2 * rp], go[2 * rp]), c = gates_pack(gi[2 * rp + 1], gj[2 * rp + 1], gf[2 * rp + 1], go[2 * rp + 1]);
                     nt_store_u4(p.Gs + ((tile * 2 + rp) * 64 + lane) * 8, make_uint4(a.x, a.y, c.x, c.y));
                 }
-                ((float2*)p.Cs)[(tile * 2 + 0) * 64 + lane] = make_float2(cst[0], cst[1]);
-                ((float2*)p.Cs)[(tile * 2 + 1) * 64 + lane] = make_float2(cst[2], cst[3]);
+                nt_store_f2(p.Cs + ((tile * 2 + 0) * 64 + lane) * 2, cst[0], cst[1]);
+                nt_store_f2(p.Cs + ((tile * 2 + 1) * 64 + lane) * 2, cst[2], cst[3]);
                 if (p.Ydrop) {
                     float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
                     if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
@@ -1562,7 +1565,8 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
-    // (the BPTT's prefetch of the saved gates / cells / dY with the non-temporal policy was measured at cfg5: no difference)
+    // (the BPTT's prefetch of the saved gates / cells / dY with the non-temporal policy, and its row-major dG stores, were measured
+    //  at cfg5: no difference)
     pa.dgx = (bf16_t*)dgx; pa.flags = flags; pa.err = err;
     const int RT = (d->B + 15) / 16;
     const int kq = (p.KB4 + 3) / 4;
