@@ -586,46 +586,103 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_group(GemmGroupArgs g) {
 }
 
 // C[m][n] (+)= epilogue(sum_s slab[s][m][n]) in fixed split order (deterministic); 4 consecutive columns per thread so
-// the dropout mask is the GEMM kernel's (one Philox counter per aligned group of 4)
-__device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z);
-__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) { splitk_reduce_body(p_in, blockIdx.y); }
+// the dropout mask is the GEMM kernel's (one Philox counter per aligned group of 4).
+// A thread keeps EIGHT slab loads (16 B each) in flight whatever the split count: with 2 splits it reduces four groups of
+// columns, with 3-4 splits two, beyond that one.  (One group per thread left a 2-split reduction with two loads in flight per
+// lane; next to a BPTT kernel that holds 456 registers a CU has room for ONE such wave per SIMD, and cfg4's reductions --
+// 100 MB each -- ran at 0.8 TB/s: 117-150 us on the weight-gradient branch that ends the step.)  Group j of thread i is
+// element i + j * stride, stride = splitk_reduce_stride(): every access of a wave stays contiguous.
+__host__ __device__ inline size_t splitk_reduce_stride_g(int M, int N, int groups) {
+    const size_t total = (size_t)M * ((N + 3) >> 2), G = (size_t)groups;
+    return ((total + G - 1) / G + 255) / 256 * 256;                // threads (= 256 x workgroups) the reduction of one product needs
+}
+// PLAIN: nothing between the sum and a 16-B fp32 store (the weight gradients); else the full epilogue of the GEMM kernel
+template <int G, bool PLAIN> __device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z);
+__host__ __device__ inline bool splitk_reduce_plain(const GemmArgs& p) {
+    return !p.bias && !p.lens && !p.mask_src && !p.last_col_out && (p.flags & ~E2T_GEMM_SPLITK) == 0 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
+}
+__host__ __device__ inline int splitk_reduce_groups(const GemmArgs& p) { return !splitk_reduce_plain(p) ? 1 : p.splits <= 2 ? 4 : p.splits <= 4 ? 2 : 1; }
+__device__ __forceinline__ void splitk_reduce_any(const GemmArgs& p, int z) {
+    if (!splitk_reduce_plain(p)) splitk_reduce_body<1, false>(p, z);
+    else if (p.splits <= 2) splitk_reduce_body<4, true>(p, z);
+    else if (p.splits <= 4) splitk_reduce_body<2, true>(p, z);
+    else splitk_reduce_body<1, true>(p, z);
+}
+// (56 registers: what a CU has left per SIMD lane beside a 456-register BPTT workgroup of lstm_big.hip)
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) { splitk_reduce_any(p_in, blockIdx.y); }
 // the reductions of a grouped launch: blockIdx.y = product, blockIdx.z = batch member
 __global__ __launch_bounds__(256) void k_splitk_reduce_group(GemmGroupArgs g) {
     if ((int)blockIdx.y >= g.n) return;
     const GemmArgs& p = g.p[blockIdx.y];
     if (p.splits <= 1 || (int)blockIdx.z >= p.batch) return;
-    splitk_reduce_body(p, blockIdx.z);
+    splitk_reduce_any(p, blockIdx.z);
 }
+template <int G, bool PLAIN>
 __device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z) {
+    constexpr int MS = 8 / G;                                       // slabs in flight per group
     const GemmArgs p = gemm_batch_view(p_in, z);
     const int N4 = (p.N + 3) >> 2;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)p.M * N4) return;
-    const int gm = (int)(idx / N4), gn0 = (int)(idx - (size_t)gm * N4) * 4;
-    const int nn = min(4, p.N - gn0);
-    const EpiCtx ec = epi_ctx(p);
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = (p.N & 3) == 0;
+    const size_t total = (size_t)p.M * N4, stride = splitk_reduce_stride_g(p.M, p.N, G);
+    const size_t idx0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx0 >= stride) return;
     const size_t sstride = (size_t)p.M * p.N;
-    const float* c0 = p.slab + (size_t)gm * p.N + gn0;
-    auto ld4 = [&](int s) {
-        const float* c = c0 + (size_t)s * sstride;
-        if (vec) return *(const float4*)c;
-        return make_float4(c[0], nn > 1 ? c[1] : 0.f, nn > 2 ? c[2] : 0.f, nn > 3 ? c[3] : 0.f);
-    };
-    // 8 slabs in flight at a time (a dependent chain of 22 loads cost 36 us on a 3-block reduction); the sum keeps the
-    // split order
-    for (int s = 0; s < p.splits; s += 8) {
-        float4 t[8];
+    if constexpr (PLAIN) {
+        // (a slab and C are < 4 GB: uniform bases + 32-bit lane offsets, and nothing else kept per group -- the kernel has to fit
+        //  the 56 registers a CU has left per SIMD lane beside a 456-register BPTT workgroup)
+        unsigned off[G], coff[G];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (s + u < p.splits) ? ld4(s + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < G; ++j) {
+            const size_t idx = idx0 + (size_t)j * stride;
+            const bool ok = idx < total;
+            const int gm = ok ? (int)(idx / N4) : 0, gn0 = ok ? (int)(idx - (size_t)gm * N4) * 4 : 0;
+            off[j] = ok ? (unsigned)(((size_t)gm * p.N + gn0) * sizeof(float)) : 0xFFFFFFFFu;
+            coff[j] = (unsigned)(((size_t)gm * p.ldc + gn0) * sizeof(float));
+        }
+        float4 v[G];
+        for (int s = 0; s < p.splits; s += MS) {
+            float4 t[G][MS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (s + u < p.splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+            for (int u = 0; u < MS; ++u) {
+                const char* sb = (const char*)(p.slab + (size_t)min(s + u, p.splits - 1) * sstride);      // (a slab beyond the last: re-read, not added)
+#pragma unroll
+                for (int j = 0; j < G; ++j) t[j][u] = *(const float4*)(sb + (off[j] != 0xFFFFFFFFu ? off[j] : 0u));
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int u = 0; u < MS; ++u) {
+                    if (s == 0 && u == 0) { v[j] = t[j][0]; continue; }
+                    if (s + u < p.splits) { v[j].x += t[j][u].x; v[j].y += t[j][u].y; v[j].z += t[j][u].z; v[j].w += t[j][u].w; }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) if (off[j] != 0xFFFFFFFFu) *(float4*)((char*)p.C + coff[j]) = v[j];
+        return;
+    } else {
+        static_assert(G == 1, "the full epilogue takes one group per thread");
+        if (idx0 >= total) return;
+        const int gm = (int)(idx0 / N4), gn0 = (int)(idx0 - (size_t)gm * N4) * 4;
+        const int nn = min(4, p.N - gn0);
+        const EpiCtx ec = epi_ctx(p);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool vec = (p.N & 3) == 0;
+        const float* c0 = p.slab + (size_t)gm * p.N + gn0;
+        auto ld4 = [&](int s) {
+            const float* c = c0 + (size_t)s * sstride;
+            if (vec) return *(const float4*)c;
+            return make_float4(c[0], nn > 1 ? c[1] : 0.f, nn > 2 ? c[2] : 0.f, nn > 3 ? c[3] : 0.f);
+        };
+        // 8 slabs in flight at a time (a dependent chain of 22 loads cost 36 us on a 3-block reduction); the sum keeps the split order
+        for (int s = 0; s < p.splits; s += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (s + u < p.splits) ? ld4(s + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (s + u < p.splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+        }
+        if (p.bias) for (int r = 0; r < nn; ++r) if (gn0 + r < ec.Nst) v[r] += p.bias[gn0 + r];
+        epi_store4<true>(p, ec, gm, gn0, v, row_valid(p, gm));
     }
-    if (p.bias) for (int r = 0; r < nn; ++r) if (gn0 + r < ec.Nst) v[r] += p.bias[gn0 + r];
-    bool rowvalid = true;
-    rowvalid = row_valid(p, gm);
-    epi_store4<true>(p, ec, gm, gn0, v, rowvalid);
 }
 
 
@@ -1032,7 +1089,7 @@ extern "C" int e2t_conv_fwd_fused(const float* x, const int32_t* lens, int B, in
 #undef E2T_CONV_GO
     if (p.splits > 1) {
         const size_t n = (size_t)a.M * ((F + 3) / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256), 1), dim3(256), 0, st, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
@@ -1270,7 +1327,7 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
 #undef E2T_GEMM_GO
     if (p.splits > 1) {
         const size_t n = (size_t)M * ((N + 3) / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256), batch), dim3(256), 0, (hipStream_t)stream, p);
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
@@ -1345,7 +1402,7 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
             p.slab = (float*)((char*)ep0->splitk_ws + off);
             off += (need + 255) / 256 * 256;
             any_split = true;
-            max_red = std::max(max_red, (unsigned)(((size_t)p.M * ((p.N + 3) / 4) + 255) / 256));
+            max_red = std::max(max_red, (unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256));
             max_batch = std::max(max_batch, p.batch);
         }
         g.first[i] = first;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_big(BigFwdArgs p) {
                         const unsigned long long g = (unsigned long long)f2bf_pk(gi[rt][a], gj[rt][a]) | ((unsigned long long)f2bf_pk(gf[rt][a], go[rt][a]) << 32);
                         __builtin_nontemporal_store(g, (unsigned long long*)(p.Gs + (((tile * 2 + (fq >> 1)) * 64 + ln) * 2 + (fq & 1)) * 4));
                     }
-                    p.Cs[((tile * 2 + (fq >> 1)) * 64 + ln) * 2 + (fq & 1)] = cst[rt][a];
+                    __builtin_nontemporal_store(cst[rt][a], &p.Cs[((tile * 2 + (fq >> 1)) * 64 + ln) * 2 + (fq & 1)]);    // (next read by the BPTT)
                 }
             }
         }
