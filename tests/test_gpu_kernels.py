@@ -121,6 +121,32 @@ def test_gemm_tn_k_major_operands(hl, M, N, K):
         assert np.all(host(c)[:, N:] == 7.0)
 
 
+@pytest.mark.parametrize('M,N,K,want_splits', [(130, 132, 2048, 2), (130, 132, 4096, 4), (128, 128, 8704, 8), (130, 130, 2048, 2), (5, 8, 2048, 2)])
+def test_splitk_reduction_group_counts(hl, M, N, K, want_splits):
+    """The reduction of a weight gradient (nothing between the sum and the fp32 store, N % 4 == 0) takes 4 / 2 / 1 column groups per
+    thread for <= 2 / <= 4 / more slabs, with a ragged last group; any other product goes through the full epilogue, one group
+    per thread.  Same sums in the same split order either way."""
+    rng = np.random.default_rng(M + N + K)
+    lda, ldb = r8(M) + 8, r8(N)
+    A = np.zeros((K, lda)); A[:, :M] = rng.standard_normal((K, M))
+    Bm = np.zeros((K, ldb)); Bm[:, :N] = rng.standard_normal((K, N))
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    want = round_bf16(A[:, :M]).T @ round_bf16(Bm[:, :N])
+    wsb = torch.zeros(4 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    ldc = r8(N) + 4
+    c = torch.full((M, ldc), 7.0, dtype=torch.float32, device='cuda')
+    ep = hl.GemmEpilogue(); ep.alpha = 1.0
+    ep.flags = hl.GEMM_SPLITK
+    ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+    tile, splits = C.c_int(0), C.c_int(0)
+    hl.lib.e2t_gemm_plan(1, M, N, K, C.byref(ep), C.byref(tile), C.byref(splits))
+    assert splits.value == want_splits
+    hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc, M, N, K, C.byref(ep), st())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(c)[:, :N], want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+    assert np.all(host(c)[:, N:] == 7.0)
+
+
 @pytest.mark.parametrize('split', [False, True])
 def test_gemm_batched_products_in_one_launch(hl, split):
     """epilogue.batch: z-th product reads A + z*a_stride, B + z*b_stride and writes C + z*c_stride (the two directions
