@@ -20,7 +20,8 @@ are nodes of the step's one hipGraph).  Prints ONE JSON line on rank 0:
   recurrence / recurrent_gemm_frac_of_peak   per-step time of the persistent recurrences, the north-star fraction;
   decode                greedy (eager / graph-replayed) and beam-4 decode of the batch, ms per batch;
   configs               cfg3 / cfg4 / cfg5 (fp32 and bf16-staged inputs) measured in the same process (N = 1 only);
-  cpu_baseline          the torch-CPU port of the same step on the box's host cores (N = 1 only).
+  cpu_baseline          the same train step on the box's host cores (N = 1 only): the C++17 / OpenMP fp32 restatement
+                        (oracle/cpu_step.cpp); `torch_port` = the torch-CPU model beside it (d5 (ii)).
 """
 import argparse
 import json
@@ -84,7 +85,38 @@ def recurrent_flops_fwd(spec_kw, S, L):
     return f + L * 2 * Hd * 4 * Hd
 
 
-def cpu_baseline(spec_kw, B, T, L, timed=5):
+def cpu_baseline_cxx(cfg, batch_override, timed=5):
+    """oracle/cpu_step.cpp -- this repository's C++17 / OpenMP fp32 implementation of the identical train step
+    (pinned against the NumPy oracle by tests/test_cpu_step.py) -- built with g++ -march=native ON this box and timed in a process
+    of its own (its OpenMP pool does not share the cores with torch's): warm-up, one step at each of nproc/4, nproc/2, nproc
+    threads, then `timed` steps at the best count, median.  None if it cannot be built or run here."""
+    import subprocess
+    if batch_override:
+        return None
+    try:
+        r = subprocess.run([sys.executable, '-m', 'oracle.cpu_step', cfg, str(timed)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+        return json.loads(line)
+    except Exception as e:                     # no g++, a build failure, a time-out: the torch port alone is reported
+        sys.stderr.write('cpu_baseline: the C++ step did not run (%r)\n' % (e,))
+        return None
+
+
+def cpu_baseline(spec_kw, B, T, L, timed=5, cfg=None, batch_override=None):
+    cxx = cpu_baseline_cxx(cfg, batch_override) if cfg else None
+    port = cpu_baseline_torch(spec_kw, B, T, L, timed=2 if cxx else timed, counts=(16,) if cxx else (8, 16, 32, 64))
+    if not cxx:
+        return port
+    return dict(value=cxx['value'], unit='utterances/s', cores=int(cxx['cores']), kind='port',
+                sample='C++17/OpenMP fp32 restatement of the train step (oracle/cpu_step.cpp: packed-panel SGEMM, per-step recurrent GEMMs, '
+                       'manual reverse mode, Adam+EMA, dropout on), g++ -O3 -march=native on this box, B=%d T=%d; thread sweep (threads: s/step): %s; '
+                       'then %d timed steps at %d threads, median %.3f s/step (min %.3f, max %.3f); usable hardware threads (affinity mask capped by the cgroup quota) %d of %d listed.  torch_port: %s'
+                       % (cxx['B'], cxx['T'], ', '.join('%d: %.3f' % (n, t) for n, t in cxx['sweep']), timed, cxx['cores'], cxx['s_per_step'],
+                          cxx['min'], cxx['max'], cxx['nproc'], cxx.get('listed', cxx['nproc']), port['sample']),
+                torch_port=dict(value=port['value'], cores=port['cores']))
+
+
+def cpu_baseline_torch(spec_kw, B, T, L, timed=5, counts=(8, 16, 32, 64)):
     """the CPU number timed beside the GPU run.  The reference's own CPU path (TF1.x + un-vendored
     packages) cannot run here, so this is `oracle/torch_model.py` -- the independent torch-CPU implementation of the
     same architecture (torch.nn.LSTM oneDNN/MKL kernels, fp32, autograd, Adam + EMA, dropout on) -- on the SAME batch
@@ -99,7 +131,7 @@ def cpu_baseline(spec_kw, B, T, L, timed=5):
     kw1 = dict(spec_kw, channels={sid: spec_kw['channels'][sid]})
     step, _ = train_step_fn(O.NetSpec(**kw1), synth_batch(kw1, B, T, L, seed=1))
     ncpu = os.cpu_count() or 1
-    counts = [n for n in (8, 16, 32, 64) if n <= ncpu] or [ncpu]
+    counts = [n for n in counts if n <= ncpu] or [ncpu]
     torch.set_num_threads(counts[min(1, len(counts) - 1)])
     step()                                        # warm-up (allocations, oneDNN primitive caches)
     sweep = []
@@ -507,7 +539,7 @@ def main():
             out['configs'] = block
         if world == 1 and not args.no_cpu_baseline:
             spec_kw, B, T, L = CONFIGS[args.config]
-            out['cpu_baseline'] = cpu_baseline(spec_kw, args.batch or B, T, L)
+            out['cpu_baseline'] = cpu_baseline(spec_kw, args.batch or B, T, L, cfg=args.config, batch_override=args.batch)
         print(json.dumps(out))
     if sync is not None and hasattr(sync, 'close'):
         sync.barrier()
