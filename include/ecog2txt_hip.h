@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 6
+#define E2T_ABI_VERSION 7
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -172,7 +172,8 @@ int e2t_cast_pack(const float* src, long row_stride, long col_stride, int R, int
 int e2t_pack_frag(const float* src, long n_stride, long k_stride, int Nn, int Kk, void* dst, void* stream);
 /* every image in one launch: device table of descriptors (src = base + src_off).  A descriptor's work is cut into units
  * (the workgroup counts quoted per kind below); for kinds 1 and 3 a workgroup processes E2T_PACK_UNITS consecutive
- * units (all their loads in flight at once), so such a descriptor owns ceil(units / E2T_PACK_UNITS) workgroups. */
+ * units (all their loads in flight at once), so such a descriptor owns ceil(units / E2T_PACK_UNITS) workgroups.
+ * ABI 7: a workgroup of kinds 5 and 6 takes TWO k-blocks (the workgroup counts below), and all kinds share one LDS staging buffer. */
 #define E2T_PACK_UNITS 4
 typedef struct e2t_pack_desc {
     int kind;            /* 0: dst[r][c] = bf16(src[r*s0 + c*s1]), r < d0, c < d1, leading dim ld
