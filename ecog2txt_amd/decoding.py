@@ -1,11 +1,9 @@
 """Decoding with the trained network (assessment: restore_and_assess, the online predictor): greedy search and beam search,
-one decoder step per token through the launch-per-step kernels.  Mixed into Seq2SeqEngine (engine.py)."""
-import ctypes as C
-
+one decoder step per token through the launch-per-step kernels; the input projection of a token is a row of a table made once per call.  Mixed into Seq2SeqEngine (engine.py)."""
 import torch
 
 from .hip_lib import lib
-from .params import EOS_ID, PAD_ID, STREAM_DEC_EMB, capture, ceil_div, r8, rk
+from .params import EOS_ID, PAD_ID, capture, ceil_div, r8, rk
 from .layers import _bf, _f32, _i32
 
 
@@ -43,15 +41,13 @@ class DecodingMixin:
         lib.e2t_fill_u32(ws['U'].data_ptr(), B, EOS_ID, st)
         lib.e2t_fill_u32(ws['dlens'].data_ptr(), B, L, st)
         dw = ws['dec']
-        dr = self._dropout(0.0, STREAM_DEC_EMB)
         pw = ws['proj']
+        table = self._token_projection_table(src)
         for l in range(max_len):
-            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, ws['U'].data_ptr(), l * B, B, s.dec_embed, ws['e'].data_ptr(),
-                              self.E8, C.byref(dr), st)
-            # input projection for this step's rows only
-            self.gemm(ws['e'].data_ptr() + 2 * l * B * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
-                      dw['Gx'].data_ptr() + 2 * l * B * self.dec.N4, self.dec.N4, B, self.dec.N4, self.E8,
-                      bias=self.dec.bias_ptr(src), out_bf16=True)
+            # input projection of this step's tokens: rows of the table (embedding and projection of a token are the same for every
+            # utterance and step -- decoding applies no dropout: the embedding lookup + a 256-row GEMM per step were two launches)
+            lib.e2t_gather_rows_u32(table.data_ptr(), ws['U'].data_ptr() + 4 * l * B, B, B, self.dec.N4 // 2,
+                                    dw['Gx'].data_ptr() + 2 * l * B * self.dec.N4, st)
             self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
             # logits for this step: run the projection stack on rows [l*B, (l+1)*B) of the ext array (t+1 block)
             self._proj_rows(ws, src, l)
@@ -97,16 +93,13 @@ class DecodingMixin:
         lib.e2t_fill_u32(wb['U'].data_ptr(), BW, EOS_ID, st)
         lib.e2t_fill_u32(wb['dlens'].data_ptr(), BW, L, st)
         dw, pw = wb['dec'], wb['proj']
-        dr = self._dropout(0.0, STREAM_DEC_EMB)
+        table = self._token_projection_table(src)
         RT, UT = ceil_div(BW, 16), ceil_div(s.dec_rnn, 16)
         cs_step = RT * UT * 2 * 64 * 2                            # floats of one step's lane-native cell save
         cur = 0
         for l in range(max_len):
-            lib.e2t_embed_fwd(self.emb.data_ptr(), self.E8, wb['U'].data_ptr(), l * BW, BW, s.dec_embed, wb['e'].data_ptr(),
-                              self.E8, C.byref(dr), st)
-            self.gemm(wb['e'].data_ptr() + 2 * l * BW * self.E8, self.E8, self.dec.WxT.data_ptr(), self.E8,
-                      dw['Gx'].data_ptr() + 2 * l * BW * self.dec.N4, self.dec.N4, BW, self.dec.N4, self.E8,
-                      bias=self.dec.bias_ptr(src), out_bf16=True)
+            lib.e2t_gather_rows_u32(table.data_ptr(), wb['U'].data_ptr() + 4 * l * BW, BW, BW, self.dec.N4 // 2,
+                                    dw['Gx'].data_ptr() + 2 * l * BW * self.dec.N4, st)
             self.dec.fwd(dw, None, wb['dlens'], src, False, c0=wb['c0'], steps=(l, l + 1))
             self._proj_rows(wb, src, l)
             nxt = wb['U'].data_ptr() + 4 * (l + 1) * BW if l + 1 < L else None
@@ -121,6 +114,17 @@ class DecodingMixin:
                                      bm['tmp_h'].data_ptr(), bm['tmp_c'].data_ptr(), st)
         hyp = bm['hyp'][cur].view(B, W, L)[:, 0, :].contiguous()  # survivors are kept best first
         return hyp, bm['score'][cur].view(B, W)
+
+    def _token_projection_table(self, src):
+        """bf16 [V][4 H_d]: the decoder's input projection of every token, W_x . embedding[v] + b, from the images packed last
+        (one 1806-row GEMM per decode call; the same kernel, operands and K order as the per-step product it replaces, so the
+        rows are bit-identical to what that product wrote)."""
+        s = self.spec
+        if self._dec_table is None:
+            self._dec_table = _bf(s.vocab, self.dec.N4, device=self.device)
+        self.gemm(self.emb.data_ptr(), self.E8, self.dec.WxT.data_ptr(), self.E8, self._dec_table.data_ptr(), self.dec.N4,
+                  s.vocab, self.dec.N4, self.E8, bias=self.dec.bias_ptr(src), out_bf16=True)
+        return self._dec_table
 
     def _beam_workspace(self, sid, B, W, L):
         """The decoder-side arrays of B x W hypothesis rows, and nothing else: a full training workspace of B x W rows would

@@ -142,6 +142,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         self._wstream = None
         self._ustream = None          # data parallel: the early optimiser update's stream inside the captured step
         self._lstream = None
+        self._dec_table = None          # decoding: the decoder's input projection of every token (decoding.py)
         self.launch_stream_on = bool(opt['launch_stream'])
         # (measured and dropped in rounds 1-2, DESIGN.md appendix: weight gradients on TWO side streams, the BPTT chain alone
         #  on the chip with all weight gradients behind it, per-stage joins)
