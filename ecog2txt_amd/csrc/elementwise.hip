@@ -639,6 +639,37 @@ __global__ void k_greedy_update(const int* pred, int B, int l, int Lmax, int eos
     if (next_tok) next_tok[b] = tok;
 }
 
+// the same in one launch straight from the logits: greedy search needs the arg-max only (lowest index on ties, as k_softmax_ce and
+// numpy), not the normalised probabilities -- one wave per utterance
+__global__ __launch_bounds__(256) void k_greedy_step(const float* logits, int ldl, int B, int V, int l, int Lmax, int eos, int pad, int* done,
+                                                     int* out, int* next_tok) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* row = logits + (size_t)b * ldl;
+    float mx = -INFINITY; int arg = 0;
+    if (V <= 32 * 64) {                                  // the row in registers: all loads in flight together (k_softmax_ce does the same)
+        float xr[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const int v = lane + 64 * i; xr[i] = (v < V) ? row[v] : -INFINITY; }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) if (xr[i] > mx) { mx = xr[i]; arg = lane + 64 * i; }
+    } else {
+        for (int v = lane; v < V; v += 64) { const float x = row[v]; if (x > mx) { mx = x; arg = v; } }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float omx = __shfl_xor(mx, o, 64); const int oarg = __shfl_xor(arg, o, 64);
+        if (omx > mx || (omx == mx && oarg < arg)) { mx = omx; arg = oarg; }
+    }
+    if (lane == 0) {
+        const int dn = done[b];
+        out[(size_t)b * Lmax + l] = dn ? pad : arg;
+        done[b] = dn | (arg == eos);
+        if (next_tok) next_tok[b] = arg;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a9, beam_width > 1 (mocha-1_word_sequence.yaml:31; temperature :82): one step of beam search for utterance b = blockIdx.x.
 // Rows b*W + w of `logits` are the W live hypotheses.  Candidates: for a live beam w every token v, scored
@@ -985,6 +1016,12 @@ extern "C" int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, in
                                  int32_t* next_tok, void* stream) {
     E2T_CHECK_ARG(pred && done && out && B > 0 && l >= 0 && l < Lmax);
     hipLaunchKernelGGL(k_greedy_update, dim3((B + 255) / 256), dim3(256), 0, ST, pred, B, l, Lmax, eos, pad, done, out, next_tok);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_greedy_step(const float* logits, int ldl, int B, int V, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
+                               int32_t* next_tok, void* stream) {
+    E2T_CHECK_ARG(logits && done && out && B > 0 && V > 0 && ldl >= V && l >= 0 && l < Lmax);
+    hipLaunchKernelGGL(k_greedy_step, dim3((B + 3) / 4), dim3(256), 0, ST, logits, ldl, B, V, l, Lmax, eos, pad, done, out, next_tok);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_beam_step(const float* logits, int ldl, int B, int W, int V, float temperature, int l, int Lmax, int eos, int pad,

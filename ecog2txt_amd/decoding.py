@@ -51,11 +51,9 @@ class DecodingMixin:
             self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
             # logits for this step: run the projection stack on rows [l*B, (l+1)*B) of the ext array (t+1 block)
             self._proj_rows(ws, src, l)
-            lib.e2t_softmax_ce(pw['out'].data_ptr() + 4 * l * B * s.vocab, s.vocab, B, s.vocab, None, None, 1, None, 0.0,
-                               None, ws['pred'].data_ptr(), None, None, 0, st)
             nxt = ws['U'].data_ptr() + 4 * (l + 1) * B if l + 1 < L else None
-            lib.e2t_greedy_update(ws['pred'].data_ptr(), B, l, L, EOS_ID, PAD_ID, ws['done'].data_ptr(),
-                                  ws['hyp'].data_ptr(), nxt, st)
+            lib.e2t_greedy_step(pw['out'].data_ptr() + 4 * l * B * s.vocab, s.vocab, B, s.vocab, l, L, EOS_ID, PAD_ID,
+                                ws['done'].data_ptr(), ws['hyp'].data_ptr(), nxt, st)
         return ws['hyp']
 
     def beam_decode(self, ws, beam_width, temperature=1.0, which='ema', max_len=None):

@@ -92,6 +92,7 @@ SIGNATURES = {
     'e2t_embed_bwd': [_p, _i, _p, _i, _i, _p, _i, C.POINTER(Dropout), _p],
     'e2t_softmax_ce': [_p, _i, _i, _i, _p, _p, _i, _p, _f, _p, _p, _p, _p, _i, _p],
     'e2t_greedy_update': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    'e2t_greedy_step': [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     'e2t_beam_step': [_p, _i, _i, _i, _i, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'e2t_beam_reorder': [_p, _i, _p, _i, _i, _p, _p, _p, _p],
     'e2t_mse': [_p, _i, _p, _i, _i, _p, _i, _p, _f, _p, _p, _i, _p],

@@ -273,6 +273,9 @@ int e2t_softmax_ce(const float* logits, int ldl, int M, int V, const int32_t* tg
                    int lddl, void* stream);
 int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
                       int32_t* next_tok, void* stream);
+/* ABI 7: arg-max of the step's logits (lowest index on ties) + the bookkeeping of e2t_greedy_update, one launch */
+int e2t_greedy_step(const float* logits, int ldl, int B, int V, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
+                    int32_t* next_tok, void* stream);
 /* Beam search (beam_width > 1, mocha-1_word_sequence.yaml:31; temperature :82): one step for B utterances x W hypotheses
  * (rows b*W + w of logits [B*W][ldl]).  A live hypothesis continues with every token, scored
  * score + log softmax(logits / temperature); a finished one (it has emitted <EOS>) only as itself; the W best survive (ties:

@@ -760,3 +760,27 @@ def test_grouped_row_order_of_the_conv_stack(hl, G):
     torch.cuda.synchronize()
     ref = Gr @ round_bf16(W).T * (tp < (-(-lens // N))[b])[:, None]
     np.testing.assert_allclose(host(out), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_greedy_step_argmax_and_bookkeeping(hl):
+    """e2t_greedy_step: arg-max of each row's logits (lowest index on ties, as numpy), token recorded unless the utterance is done,
+    <EOS> latches `done`, the token is the next step's input."""
+    rng = np.random.default_rng(9)
+    B, V, L, l = 37, 1806, 7, 3
+    lg = rng.standard_normal((B, V)).astype(np.float32)
+    lg[5, 100] = lg[5, 900] = 9.0                      # a tie: the lower index wins
+    lg[6, 1] = 50.0                                    # <EOS>
+    done0 = (rng.random(B) < 0.3).astype(np.int32)
+    done0[6] = 0
+    lt = torch.tensor(lg, device='cuda')
+    done = torch.tensor(done0, device='cuda')
+    out = torch.full((B, L), -5, dtype=torch.int32, device='cuda')
+    nxt = torch.full((B,), -5, dtype=torch.int32, device='cuda')
+    hl.lib.e2t_greedy_step(lt.data_ptr(), V, B, V, l, L, 1, 0, done.data_ptr(), out.data_ptr(), nxt.data_ptr(), st())
+    torch.cuda.synchronize()
+    arg = lg.argmax(1)
+    assert arg[5] == 100
+    np.testing.assert_array_equal(host(nxt), arg)
+    np.testing.assert_array_equal(host(out)[:, l], np.where(done0 != 0, 0, arg))
+    assert np.all(np.delete(host(out), l, axis=1) == -5)
+    np.testing.assert_array_equal(host(done), done0 | (arg == 1))
