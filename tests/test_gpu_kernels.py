@@ -762,11 +762,12 @@ def test_grouped_row_order_of_the_conv_stack(hl, G):
     np.testing.assert_allclose(host(out), ref, rtol=1e-5, atol=1e-4)
 
 
-def test_greedy_step_argmax_and_bookkeeping(hl):
+@pytest.mark.parametrize('V', [1806, 2500, 950])
+def test_greedy_step_argmax_and_bookkeeping(hl, V):
     """e2t_greedy_step: arg-max of each row's logits (lowest index on ties, as numpy), token recorded unless the utterance is done,
-    <EOS> latches `done`, the token is the next step's input."""
+    <EOS> latches `done`, the token is the next step's input.  Rows that fit the registers (V <= 2048) and longer ones."""
     rng = np.random.default_rng(9)
-    B, V, L, l = 37, 1806, 7, 3
+    B, L, l = 37, 7, 3
     lg = rng.standard_normal((B, V)).astype(np.float32)
     lg[5, 100] = lg[5, 900] = 9.0                      # a tie: the lower index wins
     lg[6, 1] = 50.0                                    # <EOS>
