@@ -1,6 +1,7 @@
 """oracle/cpu_step.cpp (the C++ / OpenMP fp32 CPU train step timed as `cpu_baseline`) against the NumPy
 oracle: losses, every gradient, and the parameters after two Adam + EMA steps, on ragged batches with dropout off."""
 import copy
+import shutil
 
 import numpy as np
 import pytest
@@ -26,6 +27,9 @@ def _batch(rng, spec, sid, B, T, L):
     for b in range(B):
         A[b, lens[b]:] = 0
     return dict(subnet_id=sid, encoder_inputs=X, decoder_targets=Y, encoder_targets=A)
+
+
+pytestmark = pytest.mark.skipif(shutil.which('g++') is None, reason='the CPU step is built with g++ on the box that runs it')
 
 
 @pytest.mark.parametrize('aux_layer,enc', [(1, [6, 10]), (0, [8]), (2, [4, 6, 8])])
