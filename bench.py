@@ -452,7 +452,9 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
                                   'inputs resident in HBM as bf16 im2row rows, staged once from fp32 in %.1f ms' % staging_ms,
                                   B, spec.enc_embed, len(spec.enc_rnn), spec.enc_rnn[0],
                                   spec.dec_rnn, spec.vocab, L), inputs=inputs, global_batch=B * world, parallelism='dp%d' % world,
-                               hipgraph=not args.no_graph, exchange=(type(sync).__name__ if sync is not None else None)),
+                               hipgraph=not args.no_graph, exchange=(type(sync).__name__ if sync is not None else None),
+                               # how many ranks the communicator itself saw (e2t_comm_size; torch.distributed's world for the other transport)
+                               communicator_ranks=(int(sync.lib.e2t_comm_size(sync.comm)) if hasattr(sync, 'comm') else getattr(sync, 'world', 1))),
                    recurrent_gemm_tflops=round(rec, 3), recurrent_gemm_frac_of_peak=round(rec / MFMA_BF16_PEAK_TFLOPS / world, 5),
                    final_loss=round(losses['total'], 4), decode=extra.pop('decode', None), recurrence=extra, roofline=roof,
                    roofline_all_gemm_instances=groups)
@@ -463,6 +465,10 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev_index, sync_factory,
     _gc.collect()
     torch.cuda.empty_cache()
     return out, sync
+
+
+def _opt_true(opts, name):
+    return any(kv.split('=', 1)[0] == name and kv.split('=', 1)[1].lower() in ('1', 'true') for kv in opts)
 
 
 def main():
@@ -486,10 +492,24 @@ def main():
     import torch
     from ecog2txt_amd import parallel
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU) -- and fail rather than report
+        # one GPU N times when the box has fewer (E2T_BENCH_BACKEND=gloo: the control-flow diagnostic with several ranks per GPU)
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and os.environ.get('E2T_BENCH_BACKEND') != 'gloo':
+            sys.exit('bench.py: --gpus %d, but %d GPU(s) are visible' % (args.gpus, ndev))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d, but the launcher started %d rank(s) (torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus))
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)        # (diagnostics: several ranks on one GPU with E2T_BENCH_BACKEND=gloo)
     torch.cuda.set_device(dev_index)
@@ -509,8 +529,46 @@ def main():
             dist.init_process_group(backend, **({'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}))
         return parallel.make_sync(eng.store.g)
 
+    if world > 1 and ndev < world and os.environ.get('E2T_BENCH_BACKEND') != 'gloo':
+        sys.exit('bench.py: %d ranks, but %d GPU(s) are visible' % (world, ndev))
     out, sync = measure(args.config, args, args.steps, args.warmup, rank, world, dev_index, sync_factory if world > 1 else None,
                         roofline=not args.no_roofline, batch=args.batch, inputs=args.inputs)
+    if world > 1 and rank == 0:
+        out['config']['schedule'] = 'dp_one_graph' if _opt_true(args.engine_option, 'dp_one_graph') else 'graph per backward stage, eager collectives'
+    if world > 1 and not args.no_graph and not any(kv.startswith('dp_one_graph=') for kv in args.engine_option) \
+            and getattr(sync, 'capturable', False) and os.environ.get('E2T_BENCH_ONE_GRAPH', '1') == '1':
+        # The data-parallel step as ONE graph with the RCCL collectives as nodes (engine option dp_one_graph; 10 % faster than the
+        # graph-per-stage schedule on a one-rank communicator) has never run with real peers on the builder's side.  The line above
+        # is safe; this second measurement runs under a watchdog: should a replay of captured collectives hang, rank 0 prints the
+        # line it has and every rank leaves.  If it completes, the line carries both schedules and `value` is the faster one.
+        import threading
+        first = out
+        done = threading.Event()
+        limit = float(os.environ.get('E2T_BENCH_WATCHDOG_S', '300'))
+
+        def watchdog():
+            if not done.wait(limit if rank == 0 else limit + 20.0):          # (rank 0 prints before the others leave)
+                if rank == 0:
+                    first['config']['dp_one_graph'] = 'no result within %.0f s (watchdog); the line is the graph-per-stage schedule' % limit
+                    print(json.dumps(first), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        sync.barrier()
+        sync.close()
+        args.engine_option = list(args.engine_option) + ['dp_one_graph=True']
+        try:
+            out2, sync = measure(args.config, args, args.steps, args.warmup, rank, world, dev_index, sync_factory, roofline=False,
+                                 batch=args.batch, inputs=args.inputs)
+        finally:
+            done.set()
+        if rank == 0:
+            both = dict(graph_per_stage_ms=first['ms_per_step'], one_graph_ms=out2['ms_per_step'])
+            if out2['ms_per_step'] < first['ms_per_step']:
+                for k in ('value', 'ms_per_step', 'recurrent_gemm_tflops', 'recurrent_gemm_frac_of_peak', 'final_loss'):
+                    first[k] = out2[k]
+                first['config']['schedule'] = 'dp_one_graph'
+            first['config']['schedules_measured'] = both
+            out = first
     if rank == 0:
         # The other BASELINE.json configurations, measured in the SAME process on one GPU (10 warm-up + 20 timed steps each,
         # synthetic inputs generated on the device): cfg3 (4 participants in turn), cfg4 (wide model), cfg5 (long / wide input).

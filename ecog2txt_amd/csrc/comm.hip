@@ -170,6 +170,18 @@ extern "C" int e2t_comm_allreduce_i32(e2t_comm* c, int32_t* buf, size_t n, void*
     return ticket(c, ticket_out);
 }
 
+// ABI 8: the 'this step is invalid' word of the persistent recurrences is agreed on by MAX, not by SUM -- the word is only cleared
+// when the host looks at it (once per epoch), a sum taken at every step in between multiplies a raised word by the number of ranks
+// per step (and wraps to zero after 32 / log2(ranks) steps: the optimiser would silently resume); the maximum is idempotent and keeps
+// the code of the error.
+extern "C" int e2t_comm_allreduce_max_i32(e2t_comm* c, int32_t* buf, size_t n, void* after_stream, int* ticket_out) {
+    E2T_CHECK_ARG(c && (buf || n == 0));
+    if (int rc = order_after(c, after_stream)) return rc;
+    if (n) E2T_NCCL(g_rccl.AllReduce(buf, buf, n, ncclInt32, ncclMax, c->comm, c->stream));
+    one_rank_marker(c);
+    return ticket(c, ticket_out);
+}
+
 extern "C" int e2t_comm_broadcast(e2t_comm* c, void* buf, size_t bytes, int root, void* after_stream, int* ticket_out) {
     E2T_CHECK_ARG(c && (buf || bytes == 0) && root >= 0 && root < c->nranks);
     if (int rc = order_after(c, after_stream)) return rc;

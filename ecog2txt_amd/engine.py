@@ -39,9 +39,10 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   tn           weight gradients straight from the K-major activations (False: operand transposes + K-contiguous GEMM)
     #   group_gemms  the K-major products of a backward stage in one grouped launch (False: one launch per product)
     #   launch_stream  captured steps replayed from a stream of the engine's own (False: the caller's stream)
-    #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes (False: one graph per backward stage,
-    #                  the collectives issued between them -- also the automatic fallback when a capture is refused)
-    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=True)
+    #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes; False (the default until that schedule has
+    #                  run with more than one RCCL rank): one graph per backward stage, the collectives issued eagerly between them --
+    #                  also the fallback ALL ranks take together when any rank's capture is refused
+    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -1168,16 +1169,23 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             torch.cuda.synchronize(self.device)
             if one and dp:
                 # data parallel: the single graph with the collectives as nodes; should the runtime refuse to record a
-                # collective, the step falls back to one graph per stage with the collectives issued between them
+                # collective on ANY rank, every rank falls back to one graph per stage with the collectives issued between them
+                # (the decision is collective: a rank replaying captured collectives and a rank issuing eager ones would not
+                # even agree on the order of their all-reduces)
+                why = None
                 try:
                     if hasattr(sync, 'warm_up'):
                         # every collective shape of the step once OUTSIDE the capture (RCCL's lazy set-up must not run inside one)
                         sync.warm_up([b - a for (_, _, rr) in self.backward_stages(ws) for a, b in rr])
                     g = self._capture_step(ws, sync, gc)
                 except RuntimeError as e:
-                    print('ecog2txt_amd: the data-parallel step could not be captured as one graph (%s); using one graph per '
-                          'backward stage' % (str(e).splitlines()[0][:200],))
+                    why, g = str(e).splitlines()[0][:200], None
                     torch.cuda.synchronize(self.device)
+                refused = int(sync.allreduce_numpy(np.array([0 if why is None else 1], np.int32))[0])
+                if refused:
+                    print('ecog2txt_amd: the data-parallel step could not be captured as one graph on %d rank(s)%s; every rank uses '
+                          'one graph per backward stage' % (refused, ' (here: %s)' % why if why else ''))
+                    g = None
                     ws['graph']['dp_staged'] = True
                     return self._train_step(ws, use_graph, sync)
             elif dp:
@@ -1209,7 +1217,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
 
         sync (a transport whose collectives can be captured: parallel.RcclSync): the data-parallel step is the SAME graph
         plus collective nodes -- the all-reduce of a stage's gradient ranges is recorded on the communicator's stream behind
-        the work that completes them (side stream: weight gradients; main stream: the bottom layer's), the sum of the ranks'
+        the work that completes them (side stream: weight gradients; main stream: the bottom layer's), the maximum of the ranks'
         `sync_err` words behind the last recurrence, and each optimiser launch waits for the collectives issued before it."""
         # parameters whose gradients are final two stages before the end (head, decoder, top encoder layers, an
         # auxiliary head above the bottom layers) are updated on the side stream under the remaining stages
@@ -1230,7 +1238,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
 
                 def early_fn(er=er):
                     if dp:
-                        sync.wait_flag()         # the sync_err sum and, collectives being ordered, every all-reduce issued before it
+                        sync.wait_flag()         # the sync_err maximum and, collectives being ordered, every all-reduce issued before it
                                                  # (these ranges'; not the bottom layer's, which follows)
                     self.adam_ranges(er, step_offset=1)
                     self.pack_ranges(er)
@@ -1314,7 +1322,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                             self._exchange(sync, ranges)     # the collective orders itself behind the side stream
                 gm.replay()
                 if exchange and i == len(g[0]) - 2:
-                    # the last kernel that can raise sync_err (the bottom layer's BPTT) has been enqueued: the word's sum over the
+                    # the last kernel that can raise sync_err (the bottom layer's BPTT) has been enqueued: the word's maximum over the
                     # ranks makes a step that one rank must skip a step that every rank skips (the replicas cannot drift apart)
                     sync.allreduce_flag(self.sync_err[0:1])
                 if gs is None and exchange:
@@ -1360,7 +1368,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 if er:
                     self.adam_ranges(er, step_offset=1)
             # (no update may read sync_err before the whole main chain -- the bottom layer's BPTT is its last writer -- and the
-            #  sum of the ranks' words are done: a step is applied on every range and every rank, or on none)
+            #  maximum of the ranks' words are done: a step is applied on every range and every rank, or on none)
             evm = torch.cuda.Event()
             evm.record(cur)
             side_stream.wait_event(evm)
@@ -1397,11 +1405,11 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 for k in ('hx', 'dgx', 'counters', 'flagsb', 'flagsbb', 'dgxb'):
                     if k in lw:
                         lw[k].zero_()
-        # (data parallel: word 0 is the SUM of the ranks' words -- every rank raises, none has updated)
+        # (data parallel: word 0 is the MAXIMUM of the ranks' words -- every rank raises, none has updated; the other words are this rank's)
         if info[0] == 7:
             raise RuntimeError('persistent BPTT: a recurrent gate gradient was NaN or infinite (results of this step are invalid, '
                                'the weights were not updated: no parameter range, on no rank) %r' % (info,))
-        raise RuntimeError('persistent recurrence: an in-kernel wait timed out or, data parallel, several ranks raised the word '
+        raise RuntimeError('persistent recurrence: an in-kernel wait timed out (data parallel: on this or another rank) '
                            '(results of this step are invalid, the weights were not updated: no parameter range, on no rank) %r' % (info,))
 
     def saturation_events(self, reset=True):

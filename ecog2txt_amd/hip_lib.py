@@ -104,6 +104,7 @@ SIGNATURES = {
     'e2t_comm_order_after': [_p, _p],
     'e2t_comm_allreduce_f32': [_p, _p, _z, _p, C.POINTER(_i)],
     'e2t_comm_allreduce_i32': [_p, _p, _z, _p, C.POINTER(_i)],
+    'e2t_comm_allreduce_max_i32': [_p, _p, _z, _p, C.POINTER(_i)],
     'e2t_comm_broadcast': [_p, _p, _z, _i, _p, C.POINTER(_i)],
     'e2t_comm_wait': [_p, _i, _p],
 }

@@ -85,10 +85,13 @@ class GradSync:
         self.pending_ranges = []
 
     def allreduce_flag(self, word):
-        """Sum a one-element int32 device tensor over the ranks (the 'this step is invalid' word of the persistent recurrences:
-        a rank that must skip its update makes every rank skip it, so the replicas cannot drift apart)."""
+        """MAXIMUM of a one-element int32 device tensor over the ranks, in place (the 'this step is invalid' word of the persistent
+        recurrences: a rank that must skip its update makes every rank skip it, so the replicas cannot drift apart).  The word
+        stays raised until the host looks at it -- once per epoch -- and is reduced again at every step in between: the maximum is
+        idempotent and keeps the error's code (a SUM would multiply a raised word by the number of ranks per step and wrap an
+        int32 to zero after 32 / log2(world) steps, upon which the optimiser would silently resume)."""
         if self.world > 1:
-            self._flag = dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._flag = dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
             self.pending.append(self._flag)
 
     def wait_flag(self):
@@ -189,7 +192,7 @@ class RcclSync:
             self.lib.e2t_comm_allreduce_f32(self.comm, scratch.data_ptr(), n, st, None)
             self._warm.add(n)
         flag = torch.zeros(1, dtype=torch.int32, device=self.g.device)
-        self.lib.e2t_comm_allreduce_i32(self.comm, flag.data_ptr(), 1, st, None)
+        self.lib.e2t_comm_allreduce_max_i32(self.comm, flag.data_ptr(), 1, st, None)
         self._warm.add('flag')
         self.lib.e2t_comm_wait(self.comm, -1, st)
         torch.cuda.current_stream().synchronize()
@@ -206,10 +209,11 @@ class RcclSync:
         self.lib.e2t_comm_wait(self.comm, -1, torch.cuda.current_stream().cuda_stream)
 
     def allreduce_flag(self, word):
-        """Sum a one-element int32 device tensor over the ranks, ordered behind the current stream's work so far (the 'this
-        step is invalid' word of the persistent recurrences: a rank that must skip its update makes every rank skip it)."""
+        """MAXIMUM of a one-element int32 device tensor over the ranks, in place, ordered behind the current stream's work so far
+        (the 'this step is invalid' word of the persistent recurrences: a rank that must skip its update makes every rank skip
+        it; idempotent from step to step and code-preserving, see GradSync.allreduce_flag)."""
         t = C.c_int(-1)
-        self.lib.e2t_comm_allreduce_i32(self.comm, word.data_ptr(), 1, torch.cuda.current_stream().cuda_stream, C.byref(t))
+        self.lib.e2t_comm_allreduce_max_i32(self.comm, word.data_ptr(), 1, torch.cuda.current_stream().cuda_stream, C.byref(t))
         self._flag_pending = _Ticket(self, t.value)
 
     def wait_flag(self):

@@ -69,6 +69,16 @@ def load_checkpoint_arrays(prefix, names=None):
     return _Arrays(tf_checkpoint.read_checkpoint(prefix, names=names))
 
 
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except OSError:                      # (EPERM: it exists and belongs to someone else)
+        return True
+    return True
+
+
 class SequenceNetwork:
     @auto_attribute(CHECK_MANIFEST=True)
     def __init__(self, manifest, EOS_token='<EOS>', pad_token='<pad>', OOV_token='<OOV>', training_GPUs=(0,),
@@ -230,7 +240,16 @@ class SequenceNetwork:
             return None
         dev = self._resident(eng, data)
         if dev is not None:
-            data['packed'] = eng.pack_inputs(sid, dev['X'])
+            # the packed rows are kept BESIDE the resident fp32 partition (the assessments read x): 1.5x its bytes in all, which
+            # must fit the residency budget too; a partition that does not, or an allocation the device refuses, stays fp32-staged
+            import torch
+            pa_bytes = data['X'].shape[0] * (-(-data['T'] // eng.spec.decimation)) * (eng.spec.decimation * data['X'].shape[2] + 64) * 2
+            if data['X'].nbytes + pa_bytes <= float(os.environ.get('E2T_RESIDENT_GB', '64')) * 2 ** 30:
+                try:
+                    data['packed'] = eng.pack_inputs(sid, dev['X'])
+                except torch.OutOfMemoryError:
+                    data['packed'] = None
+                    torch.cuda.empty_cache()
         return data['packed']
 
     def _load_batch(self, eng, ws, data, idx, idx_dev=None, packed=None):
@@ -580,8 +599,9 @@ class SequenceNetwork:
             arrays['__step'] = eng.step_t.cpu().numpy()
             ckdir = os.path.dirname(self.checkpoint_path) or '.'
             os.makedirs(ckdir, exist_ok=True)
-            for f in os.listdir(ckdir):                        # temporaries a crashed writer left behind
-                if f.startswith('.tmp-'):
+            for f in os.listdir(ckdir):                        # temporaries a crashed writer left behind -- not those of a LIVE
+                m = re.match(r'\.tmp-(\d+)-', f)               # process writing into the same directory (another fit or assessment)
+                if m and (int(m.group(1)) == os.getpid() or not _pid_alive(int(m.group(1)))):
                     try:
                         os.remove(os.path.join(ckdir, f))
                     except OSError:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 7
+#define E2T_ABI_VERSION 8
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -322,6 +322,8 @@ int e2t_comm_order_after(e2t_comm* c, void* after_stream);
 /* in-place sum over ranks of buf[0..n) (a contiguous range of the flat gradient buffer) */
 int e2t_comm_allreduce_f32(e2t_comm* c, float* buf, size_t n, void* after_stream, int* ticket);
 int e2t_comm_allreduce_i32(e2t_comm* c, int32_t* buf, size_t n, void* after_stream, int* ticket);   /* token ids / counts */
+/* ABI 8: element-wise MAXIMUM over the ranks (the persistent recurrences' error word: idempotent from step to step, keeps the code) */
+int e2t_comm_allreduce_max_i32(e2t_comm* c, int32_t* buf, size_t n, void* after_stream, int* ticket);
 int e2t_comm_broadcast(e2t_comm* c, void* buf, size_t bytes, int root, void* after_stream, int* ticket);
 /* `stream` waits for collective `ticket` (-1: for every collective issued so far) */
 int e2t_comm_wait(e2t_comm* c, int ticket, void* stream);

@@ -11,7 +11,7 @@ from ecog2txt_amd.parallel import RcclSync
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 kw, B, T, L = bench.CONFIGS[cfg]
-eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=3)
+eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=3, options={'dp_one_graph': True})
 eng.init_params(seed=0)
 ws = eng.workspace(list(kw['channels'])[0], B, T, L)
 batch = bench.synth_batch(kw, B, T, L, seed=5)

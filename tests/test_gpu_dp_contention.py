@@ -83,7 +83,7 @@ def test_dp_step_with_cus_taken_away_where_the_allreduces_run(name, usec):
     from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
     occ = _occupy_lib()
     kw, B, T, L = bench.CONFIGS[name]
-    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=3)
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=3, options={'dp_one_graph': True})
     assert eng.persistent_fwd and eng.persistent_bwd
     eng.init_params(seed=0)
     ws = eng.workspace(401, B, T, L)

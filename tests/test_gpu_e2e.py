@@ -291,8 +291,8 @@ def test_data_parallel_step_with_direct_rccl_through_the_c_abi(one_graph):
     """The product's exchange: librccl called directly through e2t_comm_* (no torch.distributed anywhere in the step) on a
     one-rank communicator -- collectives on the communicator's own stream, ordered by events behind the stream that completes
     their ranges, the optimiser following the exchange.  Both schedules: the step as ONE graph with the collectives as nodes
-    (the default) and one graph per backward stage with the collectives issued between them (option dp_one_graph=False, the
-    fallback).  One real rank reported as two takes the engine down the data-parallel path; the sum over one rank leaves the
+    (option dp_one_graph=True) and one graph per backward stage with the collectives issued between them (the default until the
+    one-graph schedule has run with more than one RCCL rank, and the fallback all ranks take together).  One real rank reported as two takes the engine down the data-parallel path; the sum over one rank leaves the
     gradients unchanged, so the result must equal the single-graph step.  Also: global-count loss normalisation equals local
     normalisation when the counts agree."""
     from test_gpu_parity import build, SPECS
@@ -354,11 +354,11 @@ def test_error_word_raised_inside_the_step_leaves_every_range_untouched(dp):
     """the error word is raised INSIDE a captured step (non-finite gate gradients make the persistent BPTT raise code 7
     -- at the earliest by the top layer, i.e. after the head's gradients are complete) and the early optimiser update on the side
     stream must still see it: masters, Adam state, EMA shadows and the step counter of EVERY range stay as they were -- also in
-    the data-parallel graph, where the word is summed over the ranks before any update reads it."""
+    the data-parallel graph, where the ranks agree on the word (maximum) before any update reads it."""
     from test_gpu_parity import build, SPECS
     from ecog2txt_amd.parallel import RcclSync
     kw = dict(SPECS['cfg2_widths'], enc_rnn=[400, 400])         # persistent recurrences (H = 400), two layers: an early update exists
-    eng, ws, _, _, batch = build(kw, 64, 40, 5, seed=3)
+    eng, ws, _, _, batch = build(kw, 64, 40, 5, seed=3, options={'dp_one_graph': True})
     assert eng.persistent_bwd and eng.enc[0].persistent_bwd_ok(64, eng.num_cus)
     sync = None
     if dp:

@@ -145,7 +145,7 @@ def test_cfg2_graph_against_bf16_emulating_oracle(train):
     """The same cfg2 graph (3 x 400 bidirectional, decoder 800, V = 1806, T = 400 -> 34 steps, K = 3072 conv) at B = 16 against the
     NumPy oracle with the device's rounding points: the tight tolerances of test_gpu_parity.py.  train=True: FF dropout 0.1 and
     RNN dropout 0.5 on, Philox masks on both sides."""
-    from test_gpu_parity import check_grad, LOSS_RTOL
+    from test_gpu_parity import check_grad, relu_class, LOSS_RTOL
     from ecog2txt_amd.engine import NetSpec
     kw, _, T, L = bench.CONFIGS['cfg2']
     B = 16
@@ -174,11 +174,12 @@ def test_cfg2_graph_against_bf16_emulating_oracle(train):
             check_grad(k, G[k], WG[k], relu_outliers=4e-2, flip_outliers=3e-3)
             continue
         # dropout on (scripts/diag_fullsize_dropout.py): every kept activation carries 1 / keep = 2x, so a 1-ulp bf16 flip or a
-        # flipped ReLU unit of the 225-wide auxiliary layer weighs twice as much in everything below the tapped layer -- relative
-        # L2 error of the layer-0 / layer-1 gradients 7e-3 .. 1.0e-2 (5e-3 .. 7e-3 with dropout off; the top layer and the
-        # decoder, which no ReLU feeds, stay at 1e-3), 1.8 % of a bias gradient's entries beyond 5e-3.  Two checks: the bands of
-        # test_gpu_parity.py widened by that factor (largest error still < 2e-2 / 5e-2), and the HIP path must be CLOSER to the
-        # bf16-emulating oracle than 0.6 of that oracle's own distance from the exact fp64 spec (measured: 0.2 .. 0.46)
-        check_grad(k, G[k], WG[k], relu_outliers=1e-1, flip_outliers=3e-2, l2_scale=1.5)
+        # flipped ReLU unit of the 225-wide auxiliary layer weighs twice as much in everything below the tapped layer, and the
+        # share of entries beyond a fixed 5e-3 grows with it.  No outlier allowance is made for that (round 5): THE assertion is
+        # relative to the oracle's own band -- the HIP path must be CLOSER to the bf16-emulating oracle than 0.6 of that oracle's
+        # distance from the exact fp64 spec (measured: 0.2 .. 0.46) -- plus the hard ceilings of test_gpu_parity.py on the single
+        # worst entry (2e-2 of the tensor's maximum; 5e-2 behind a ReLU mask of the tensor's own layer)
         band = rl2(XG[k], WG[k])
         assert rl2(G[k], WG[k]) <= max(0.6 * band, 2e-3), (k, rl2(G[k], WG[k]), band)
+        worst = float(np.abs(G[k] - WG[k]).max() / (np.abs(WG[k]).max() + 1e-12))
+        assert worst < (5e-2 if relu_class(k) else 2e-2), (k, worst)

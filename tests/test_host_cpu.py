@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(hip_lib.SIGNATURES) | set(hip_lib.PLAIN)
-    assert lib.e2t_abi_version() == 7
+    assert lib.e2t_abi_version() == 8
     # the ctypes mirrors of the boundary structs have the C layouts' sizes
     for which, cls in enumerate([hip_lib.GemmEpilogue, hip_lib.LstmDesc, hip_lib.PackDesc, hip_lib.AdamHyper, hip_lib.Dropout]):
         assert lib.e2t_sizeof(which) == ctypes.sizeof(cls), cls.__name__
@@ -234,3 +234,17 @@ def test_register_budgets_of_the_co_resident_kernels():
     for k, v in by_name.items():
         if 'k_lstm' in k:
             assert v.get('ScratchSize', 0) == 0, k
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself -- and must FAIL, not report one GPU N times, on a box
+    with fewer GPUs (missing 3)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'E2T_BENCH_BACKEND')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '2', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0 and 'GPU(s) are visible' in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]

@@ -49,11 +49,14 @@ def _worker(rank, world, port, q):
     for nm in names:
         a, b = store.seg_range(nm)
         sync.allreduce_range(a, b)
-    # the ranks' "this step is invalid" words are summed with the gradients: rank 1 raises it, every rank must see it
+    # the ranks' "this step is invalid" words are agreed on with the gradients: rank 1 raises it, every rank must see it -- WITH its
+    # code, and it must stay what it is however many steps pass before the host looks (the word is reduced in place at every step
+    # and only cleared by check_sync once per epoch: a sum would double it per step and wrap an int32 to 0 after 32 steps)
     flag = torch.tensor([7 if rank == 1 else 0], dtype=torch.int32)
-    sync.allreduce_flag(flag)
-    sync.wait_flag()
-    assert int(flag.item()) == 7, int(flag.item())
+    for _ in range(40):
+        sync.allreduce_flag(flag)
+        sync.wait_flag()
+        assert int(flag.item()) == 7, int(flag.item())
     sync.wait()
     store.g.mul_(sync.grad_scale)
     out = store.export_tf('g')

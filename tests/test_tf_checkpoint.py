@@ -153,3 +153,39 @@ def test_backend_checkpoints_store_float32_variables(tmp_path):
     back = T.read_checkpoint(prefix)
     k = 'seq2seq/decoder_rnn/cell_0/kernel'
     assert back[k].dtype == np.float32 and np.array_equal(back[k], store.export_tf('p')[k].astype(np.float32))
+
+
+def test_save_removes_a_dead_writers_temporaries_and_leaves_a_live_writers_alone(tmp_path):
+    """the clean-up in front of a checkpoint write must not delete the in-flight temporaries of ANOTHER live process
+    writing into the same directory (its os.replace would fail) -- only those whose writer is gone, or this process's own."""
+    import subprocess
+    import sys
+    import types
+    import torch
+    from oracle import seq2seq as O
+    from helpers import tiny_spec
+    from ecog2txt_amd.engine import ParamStore, NetSpec
+    from ecog2txt_amd.sequence_network import SequenceNetwork
+    ospec = tiny_spec()
+    spec = NetSpec(**{k: getattr(ospec, k) for k in NetSpec.__dataclass_fields__})
+    store = ParamStore(spec, 'cpu')
+    store.import_tf(O.init_params(ospec, seed=2))
+    eng = types.SimpleNamespace(store=store, step_t=torch.zeros(1, dtype=torch.int32))
+    net = SequenceNetwork.__new__(SequenceNetwork)
+    net.checkpoint_path = str(tmp_path / 'model.ckpt')
+    gone = subprocess.Popen([sys.executable, '-c', 'pass'])
+    gone.wait()
+    live = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)'])
+    try:
+        names = {'dead': '.tmp-%d-model.ckpt-7.npz' % gone.pid, 'live': '.tmp-%d-model.ckpt-8.npz' % live.pid,
+                 'own': '.tmp-%d-model.ckpt-1.npz' % os.getpid(), 'other': 'notes.txt'}
+        for f in names.values():
+            (tmp_path / f).write_bytes(b'x')
+        net._save(eng, 3)
+        left = set(os.listdir(tmp_path))
+        assert names['live'] in left and names['other'] in left
+        assert names['dead'] not in left and names['own'] not in left
+        assert 'model.ckpt-3.index' in left and 'model.ckpt-3.npz' in left
+    finally:
+        live.kill()
+        live.wait()
