@@ -772,12 +772,15 @@ __global__ void k_inc_step(int* step, const int* skip) { if (threadIdx.x == 0 &&
 // Per element the arithmetic is the scalar form's, operation for operation.
 __device__ __forceinline__ void adam_ema_1(float& p, float g, float& m, float& v, float& e, float lr_t, float b1, float b2, float eps,
                                            float decay, float gscale) {
+    // (contraction off, the fused multiply-adds spelled out: this function is inlined into two kernels -- k_adam_ema and k_adam_pack --
+    //  whose results must agree bit for bit, and the compiler forms a*b + c into an fma or not depending on the code around it)
+#pragma clang fp contract(off)
     const float gi = g * gscale;
-    const float mi = b1 * m + (1.f - b1) * gi;
-    const float vi = b2 * v + (1.f - b2) * gi * gi;
-    const float pi = p - lr_t * mi / (sqrtf(vi) + eps);
+    const float mi = fmaf(b1, m, (1.f - b1) * gi);
+    const float vi = fmaf(b2, v, ((1.f - b2) * gi) * gi);
+    const float pi = p - (lr_t * mi) / (sqrtf(vi) + eps);
     m = mi; v = vi; p = pi;
-    e = decay * e + (1.f - decay) * pi;
+    e = fmaf(decay, e, (1.f - decay) * pi);
 }
 __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n,
                                                    const int* step, float lr, float b1, float b2, float eps, float decay,
@@ -810,6 +813,126 @@ __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, floa
         __builtin_nontemporal_store(mm, (f4*)m4 + i); __builtin_nontemporal_store(vv, (f4*)v4 + i);
         ((f4*)p4)[i] = pp;
         __builtin_nontemporal_store(ee, (f4*)e4 + i);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a10 + operand images in one pass (ABI 8, include/ecog2txt_hip.h e2t_adam_pack_batch): the HBM-bound tail of the train step.
+// k_adam_ema writes the masters (36 B per parameter moved) and k_pack_batch reads them again once per image (2 x 6 B); here a
+// workgroup owns a 64 x 64 tile of a parameter matrix, updates it with adam_ema_1 -- the same expression, so the same bits --
+// and emits the tile's share of every image from the values it holds: 40 B per parameter.  The tile goes through LDS as fp32
+// [64][65] (both the row-wise and the column-wise reads below are conflict-free or 2-way); fragments are written as whole 1-KiB
+// wave transactions.
+// ---------------------------------------------------------------------------
+struct AdamPackArgs { const int* step; const int* skip; float lr, b1, b2, eps, decay, gscale; int step_offset; int update; };
+__global__ __launch_bounds__(256) void k_adam_pack(const e2t_tile_desc* descs, int ndesc, float* p, const float* g, float* m, float* v,
+                                                    float* ema, AdamPackArgs a) {
+    // the tile as bf16 (the images' own precision) [64][66]: 8.3 KB -- three workgroups fit beside two resident GEMM workgroups of the
+    // other branch (2 x 64 KB of LDS); as fp32 (16.6 KB) one did, and the update crawled while a GEMM was on the chip
+    __shared__ bf16_t tile[64][66];
+    if (a.update && a.skip && *a.skip != 0) return;      // invalid gradients: no update, and the images of the old masters stay
+    int lo = 0, hi = ndesc - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1; }
+    // (scalar fields only: a local copy of the descriptor, indexed by the image loop below, would live in scratch)
+    struct { int R, C, nimg; long long src_off, s0; } d = {descs[lo].R, descs[lo].C, descs[lo].nimg, descs[lo].src_off, descs[lo].s0};
+    const int lb = bid - descs[lo].first_block;
+    const int tcn = (d.C + 63) >> 6;
+    const int tr = lb / tcn, tc = lb - tr * tcn;
+    if (tr >= ((d.R + 63) >> 6)) return;
+    const int b = threadIdx.x >> 4, a4 = (threadIdx.x & 15) * 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float lr_t = 0.f;
+    if (a.update) {
+        const float t = (float)(*a.step + a.step_offset);
+        lr_t = a.lr * sqrtf(1.f - powf(a.b2, t)) / (1.f - powf(a.b1, t));
+    }
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // One 16-B group of each buffer per thread and pass, four passes, NOT unrolled: like k_adam_ema the kernel lives on the number of
+    // workgroups in flight, not on loads in flight per thread (unrolled, 20 groups per thread cost 172 registers = two workgroups
+    // per CU: 3.9 TB/s against the 6.1 of the separate kernels)
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        const int r = tr * 64 + b + 16 * i, c = tc * 64 + a4;
+        const bool in = r < d.R && c < d.C;                    // (C % 4 == 0: a 16-B group is inside or outside as a whole)
+        const size_t idx = in ? (size_t)d.src_off + (size_t)r * (size_t)d.s0 + c : 0;      // (outside: the buffers' first 16 B, zeroed below)
+        f4 pv = *(const f4*)(p + idx);
+        if (a.update) {
+            const f4 gv = __builtin_nontemporal_load((const f4*)(g + idx));
+            const f4 mv = __builtin_nontemporal_load((const f4*)(m + idx));
+            const f4 vv = __builtin_nontemporal_load((const f4*)(v + idx));
+            const f4 ev = __builtin_nontemporal_load((const f4*)(ema + idx));
+            if (in) {
+                float P[4] = {pv.x, pv.y, pv.z, pv.w}, Mv[4] = {mv.x, mv.y, mv.z, mv.w}, V[4] = {vv.x, vv.y, vv.z, vv.w}, E[4] = {ev.x, ev.y, ev.z, ev.w};
+                const float G[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) adam_ema_1(P[k], G[k], Mv[k], V[k], E[k], lr_t, a.b1, a.b2, a.eps, a.decay, a.gscale);
+                pv = (f4){P[0], P[1], P[2], P[3]};
+                const f4 mm = {Mv[0], Mv[1], Mv[2], Mv[3]}, v2 = {V[0], V[1], V[2], V[3]}, ee = {E[0], E[1], E[2], E[3]};
+                __builtin_nontemporal_store(mm, (f4*)(m + idx)); __builtin_nontemporal_store(v2, (f4*)(v + idx));
+                *(f4*)(p + idx) = pv;
+                __builtin_nontemporal_store(ee, (f4*)(ema + idx));
+            }
+        }
+        if (!in) pv = z4;
+        unsigned* t = (unsigned*)&tile[b + 16 * i][a4];           // (row stride 132 B, a4 multiple of 4: 4-B aligned pairs)
+        t[0] = f2bf(pv.x) | ((unsigned)f2bf(pv.y) << 16); t[1] = f2bf(pv.z) | ((unsigned)f2bf(pv.w) << 16);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, q = lane >> 4;
+    for (int ii = 0; ii < d.nimg; ++ii) {
+        const e2t_tile_img im = descs[lo].img[ii];
+        bf16_t* dst = (bf16_t*)im.dst;
+        if (im.kind == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = tr * 64 + b + 16 * i, c = tc * 64 + a4;
+                if (r >= d.R || c >= d.C) continue;
+                const unsigned* t = (const unsigned*)&tile[b + 16 * i][a4];
+                *(uint2*)(dst + (size_t)r * im.ld + c) = make_uint2(t[0], t[1]);
+            }
+        } else if (im.kind == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tc * 64 + b + 16 * i, r = tr * 64 + a4;           // output row = matrix column c, 4 consecutive matrix rows
+                if (c >= d.C || r >= d.R) continue;
+                const bf16_t o0 = tile[a4][b + 16 * i], o1 = tile[a4 + 1][b + 16 * i], o2 = tile[a4 + 2][b + 16 * i], o3 = tile[a4 + 3][b + 16 * i];
+                bf16_t* o = dst + (size_t)c * im.ld + r;
+                if (r + 3 < d.R) *(ushort4*)o = make_ushort4(o0, o1, o2, o3);
+                else { o[0] = o0; if (r + 1 < d.R) o[1] = o1; if (r + 2 < d.R) o[2] = o2; }
+            }
+        } else {
+            // fragment images: wave w emits two fragments (k-blocks kbl = 0, 1 of the tile) of its n tile / gate
+            const int KB = im.ld;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                bf16_t x[8];
+                size_t f;
+                if (im.kind == 3) {                            // n = row, k = column
+                    const int nt = tr * 4 + w, kb = tc * 2 + kbl;
+                    if (nt >= ((d.R + 15) >> 4) || kb >= KB) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = tile[w * 16 + l15][kbl * 32 + q * 8 + j];
+                    f = (size_t)nt * KB + kb;
+                } else if (im.kind == 4) {                     // n = column, k = row
+                    const int nt = tc * 4 + w, kb = tr * 2 + kbl;
+                    if (nt >= ((d.C + 15) >> 4) || kb >= KB) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = tile[kbl * 32 + q * 8 + j][w * 16 + l15];
+                    f = (size_t)nt * KB + kb;
+                } else {                                       // gate-interleaved: wave = gate, unit tile = tile column
+                    const int UT = ((d.C >> 2) + 15) >> 4, kb = tr * 2 + kbl;
+                    if (tc >= UT || kb >= KB) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = tile[kbl * 32 + q * 8 + j][l15 * 4 + w];
+                    f = ((size_t)w * UT + tc) * KB + kb;
+                }
+                uint4 o;
+                o.x = x[0] | ((unsigned)x[1] << 16); o.y = x[2] | ((unsigned)x[3] << 16);
+                o.z = x[4] | ((unsigned)x[5] << 16); o.w = x[6] | ((unsigned)x[7] << 16);
+                ((uint4*)dst)[f * 64 + lane] = o;
+            }
+        }
     }
 }
 
@@ -1045,6 +1168,19 @@ extern "C" int e2t_beam_reorder(void* Yblk, int ldy, float* Cs_step, int rows, i
 extern "C" int e2t_inc_step(int32_t* step, const int32_t* skip_if_nonzero, void* stream) {
     E2T_CHECK_ARG(step);
     hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(64), 0, ST, step, skip_if_nonzero);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_adam_pack_batch(const e2t_tile_desc* descs_dev, int ndesc, int total_blocks, float* p, const float* g, float* m, float* v,
+                                   float* ema, const int32_t* step, const e2t_adam_hyper* h, void* stream) {
+    E2T_CHECK_ARG(descs_dev && p && ndesc > 0 && total_blocks > 0);
+    E2T_CHECK_ARG(!h || (g && m && v && ema && step));
+    E2T_CHECK_ARG(((uintptr_t)p & 15) == 0 && (!h || ((((uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) == 0)));
+    AdamPackArgs a{};
+    if (h) {
+        a.step = step; a.skip = h->skip_if_nonzero; a.lr = h->lr; a.b1 = h->beta1; a.b2 = h->beta2; a.eps = h->eps; a.decay = h->ema_decay;
+        a.gscale = h->grad_scale; a.step_offset = h->step_offset; a.update = 1;
+    }
+    hipLaunchKernelGGL(k_adam_pack, dim3(total_blocks), dim3(256), 0, ST, descs_dev, ndesc, p, g, m, v, ema, a);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,

@@ -1118,6 +1118,50 @@ extern "C" int e2t_gemm_stamp_kinds(int* kinds, int n) {
     return E2T_OK;
 }
 
+// Column sums of a K-major bf16 matrix: out[n] = alpha * sum_k B[k][n] (+ out[n]).  The bias row of a weight gradient [x | 1]^T . dG
+// whose ones column would otherwise cost a product of its own (E2T_GEMM_LAST_ROW_ONES, gemm_launch): one pass over dG at the HBM
+// rate, one launch, no slabs and no reduction kernel behind it (that reduction -- 8 workgroups -- sat 145 us behind a 256 x 256
+// GEMM of the other branch that held every register of the chip, on the branch that ends cfg4's step).  A workgroup of 1024
+// threads owns 32 columns (64 B of every row) and all K rows: thread = (8-column group, row lane), rows k = lane, lane + 256, ...
+// summed in that order; 16 row lanes meet by wave shuffles, the 16 waves through LDS: a fixed order, the same bits every run.
+__global__ __launch_bounds__(1024) void k_colsum_bf16(const bf16_t* B, int ldb, int K, int N, float* out, float alpha, int accumulate) {
+    __shared__ float part[16][32];
+    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int c0 = blockIdx.x * 32 + cg * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < N) {                                          // (ldb % 8 == 0 and the row is readable up to ldb: a group is loaded whole)
+        const bf16_t* q = B + c0;
+#pragma unroll 8
+        for (int k = rl; k < K; k += 256) {
+            const uint4 v = *(const uint4*)(q + (size_t)k * ldb);
+            acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xFFFF0000u);
+            acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+            acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xFFFF0000u);
+            acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xFFFF0000u);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = blockIdx.x * 32 + threadIdx.x;
+        if (c < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += part[w][threadIdx.x];
+            s *= alpha;
+            out[c] = accumulate ? out[c] + s : s;
+        }
+    }
+}
+
 struct GemmPlan { int tile, splits, batch; bool want_split; };
 static int gemm_order() {
     static const int o = e2t_dbg_int("E2T_GEMM_ORDER", 1) == 0 ? 0 : 1;
@@ -1275,6 +1319,16 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     if (tn && big && pl.batch == 1 && !rich_ep && !(ep && ep->row_lens) && !p.lens) {
         const int rm = M % 256, rn = N % 256;
         const int elt = (ep && (ep->flags & E2T_GEMM_OUT_BF16)) ? 2 : 4;
+        if (rm == 1 && M > 256 && (ep->flags & E2T_GEMM_LAST_ROW_ONES) && !ep->bias && !ep->last_col_out && elt == 4 && ldb % 8 == 0 &&
+            (((uintptr_t)B) & 15) == 0) {
+            // the one row beyond the last full tile is the ones column's: column sums of B, one pass, no slabs
+            e2t_gemm_epilogue e0 = *ep;
+            if (int rc = gemm_launch(true, A, lda, B, ldb, C, ldc, M - 1, N, K, &e0, stream)) return rc;
+            hipLaunchKernelGGL(k_colsum_bf16, dim3((unsigned)((N + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)B, ldb, K, N,
+                               (float*)C + (size_t)(M - 1) * ldc, ep->alpha, (ep->flags & E2T_GEMM_ACCUMULATE) ? 1 : 0);
+            E2T_LAUNCH_CHECK();
+            return E2T_OK;
+        }
         if (rm > 0 && rm <= 32 && M > 256) {
             e2t_gemm_epilogue e0 = *ep, e1 = *ep;
             if (ep->last_col_out) e1.last_col_out = ep->last_col_out + (M - rm);

@@ -24,6 +24,7 @@ extern "C" int e2t_sizeof(int which) {
         case 3: return (int)sizeof(e2t_adam_hyper);
         case 4: return (int)sizeof(e2t_dropout);
         case 5: return (int)sizeof(e2t_gemm_call);
+        case 6: return (int)sizeof(e2t_tile_desc);
         default: return -1;
     }
 }

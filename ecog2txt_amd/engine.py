@@ -39,10 +39,12 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   tn           weight gradients straight from the K-major activations (False: operand transposes + K-contiguous GEMM)
     #   group_gemms  the K-major products of a backward stage in one grouped launch (False: one launch per product)
     #   launch_stream  captured steps replayed from a stream of the engine's own (False: the caller's stream)
+    #   fused_tail     the captured step's early optimiser update and the re-pack of its images as ONE pass over the weight matrices
+    #                  (e2t_adam_pack_batch; False: e2t_adam_ema_step, then e2t_pack_batch -- the same bits)
     #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes; False (the default until that schedule has
     #                  run with more than one RCCL rank): one graph per backward stage, the collectives issued eagerly between them --
     #                  also the fallback ALL ranks take together when any rank's capture is refused
-    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False)
+    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -113,6 +115,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             ax.ones_col_set = self.enc[hx['layer']].ldy > 2 * self.enc[hx['layer']].H8
         self._pack_table = None
         self._pack_ops, self._pack_sub = None, {}
+        self._fused_plans = {}        # element ranges -> tables of e2t_adam_pack_batch (packing._fused_update_plan)
         self._img_early = None        # 'all' after a full pack of the masters, else the ranges the last replay re-packed itself
         self._gemm_log = None         # a list while bench.py records the step's products (instance, shape, flops)
         self._in_group = False
@@ -187,7 +190,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
 
     def gemm(self, A, lda, B, ldb, Cp, ldc, M, N, K, bias=None, relu=False, out_bf16=False, accumulate=False,
              drop=None, mask_src=None, row_lens=None, alpha=1.0, splitk=False, last_col_out=None, tn=False, batch=None, alg=None,
-             row_group=1):
+             row_group=1, ones_last_row=False):
         """batch = (n, a_stride, b_stride, c_stride): n products of the same shape in one launch (element strides).
         alg = (M, N, K) of the product WITHOUT layout padding, for flop accounting in the launch log (bench.py)."""
         ep = H.GemmEpilogue()
@@ -199,6 +202,8 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         flags = (H.GEMM_RELU if relu else 0) | (H.GEMM_OUT_BF16 if out_bf16 else 0) | (H.GEMM_ACCUMULATE if accumulate else 0)
         if splitk:
             flags |= H.GEMM_SPLITK
+        if ones_last_row:              # (K-major products: A's column M-1 is the ones column -- row M-1 of the product = column sums of B)
+            flags |= H.GEMM_LAST_ROW_ONES
         # the workspace is always offered: the library also splits K on its own when a product has too few tiles
         wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
         ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
@@ -1042,15 +1047,19 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         """Adam + EMA on [a,b) element ranges of the flat buffers (step_offset=1: before this step's e2t_inc_step)."""
         store = self.store
         st = self.stream
-        h = H.AdamHyper()
-        h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
-        h.ema_decay, h.grad_scale, h.step_offset = self.hyper['ema_decay'], self.grad_scale, step_offset
-        h.skip_if_nonzero = self.sync_err.data_ptr()      # a step whose in-kernel wait timed out must not reach the weights
+        h = self._adam_hyper(step_offset)
         for a, b in ranges:
             o = 4 * a
             lib.e2t_adam_ema_step(store.p.data_ptr() + o, store.g.data_ptr() + o, store.m.data_ptr() + o,
                                   store.v.data_ptr() + o, store.ema.data_ptr() + o, b - a, self.step_t.data_ptr(),
                                   C.byref(h), st)
+
+    def _adam_hyper(self, step_offset=0):
+        h = H.AdamHyper()
+        h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
+        h.ema_decay, h.grad_scale, h.step_offset = self.hyper['ema_decay'], self.grad_scale, step_offset
+        h.skip_if_nonzero = self.sync_err.data_ptr()      # a step whose in-kernel wait timed out must not reach the weights
+        return h
 
     def adam_step(self, sid=None, repack=True, skip_below=0):
         """Adam + EMA on the shared body and (if given) subject `sid`'s conv; then re-pack operands (repack=False: the
@@ -1240,12 +1249,17 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                     if dp:
                         sync.wait_flag()         # the sync_err maximum and, collectives being ordered, every all-reduce issued before it
                                                  # (these ranges'; not the bottom layer's, which follows)
-                    self.adam_ranges(er, step_offset=1)
-                    self.pack_ranges(er)
+                    if self.options['fused_tail']:
+                        self.adam_pack_ranges(er, step_offset=1)     # update + images in one pass over the weight matrices
+                    else:
+                        self.adam_ranges(er, step_offset=1)
+                        self.pack_ranges(er)
                 early = (nl, early_fn)
         g1 = torch.cuda.CUDAGraph()
         if packed_early:
             self._pack_subtable(tuple(packed_early))          # descriptor tables are built outside the capture
+            if self.options['fused_tail']:
+                self._fused_update_plan(tuple(packed_early))
             self._pack_subtable(('skip',) + tuple(packed_early))
         tail = [(max(a, early_end), b) for a, b in tr if b > early_end]
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel-variant switches and the phase-stamp buffers exist; the product library has none of them
 LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip_dbg.so' if os.environ.get('E2T_DEBUG_LIB') == '1' else 'libecog2txt_hip.so')
 
-GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK = 1, 2, 4, 8, 16
+GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK, GEMM_LAST_ROW_ONES = 1, 2, 4, 8, 16, 32
 PACK_UNITS = 4            # E2T_PACK_UNITS (include/ecog2txt_hip.h): work units of a pack descriptor per workgroup
 
 
@@ -44,6 +44,19 @@ class LstmDesc(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [('kind', C.c_int), ('first_block', C.c_int), ('src_off', C.c_longlong), ('s0', C.c_longlong),
                 ('s1', C.c_longlong), ('d0', C.c_int), ('d1', C.c_int), ('ld', C.c_int), ('pad_', C.c_int), ('dst', C.c_void_p)]
+
+
+class TileImg(C.Structure):
+    _fields_ = [('dst', C.c_void_p), ('kind', C.c_int), ('ld', C.c_int)]
+
+
+TILE_IMG_MAX = 3          # E2T_TILE_IMG_MAX
+TILE_CAST, TILE_CAST_T, TILE_FRAG_NK, TILE_FRAG_KN, TILE_FRAG4_KN = 1, 2, 3, 4, 5
+
+
+class TileDesc(C.Structure):
+    _fields_ = [('first_block', C.c_int), ('R', C.c_int), ('C', C.c_int), ('nimg', C.c_int), ('src_off', C.c_longlong),
+                ('s0', C.c_longlong), ('img', TileImg * TILE_IMG_MAX)]
 
 
 class AdamHyper(C.Structure):
@@ -98,6 +111,7 @@ SIGNATURES = {
     'e2t_mse': [_p, _i, _p, _i, _i, _p, _i, _p, _f, _p, _p, _i, _p],
     'e2t_inc_step': [_p, _p, _p],
     'e2t_adam_ema_step': [_p, _p, _p, _p, _p, _z, _p, C.POINTER(AdamHyper), _p],
+    'e2t_adam_pack_batch': [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.POINTER(AdamHyper), _p],
     'e2t_comm_unique_id': [_p],
     'e2t_comm_init': [C.POINTER(_p), _i, _i, _p, _i],
     'e2t_comm_destroy': [_p],

@@ -134,7 +134,7 @@ class _FFStack:
                     e.gemm(d, ldd, xp, xld, st.ptr('%s%d.WT' % (self.prefix, i), st.g), fin, fout, fin + 1, M, splitk=True,
                            last_col_out=st.ptr('%s%d.b' % (self.prefix, i), st.g), tn=True)
                 else:         # [dW; db] = [x | 1]^T . d  [in + 1][out]
-                    e.gemm(xp, xld, d, ldd, st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, M, splitk=True, tn=True)
+                    e.gemm(xp, xld, d, ldd, st.ptr('%s%d.W' % (self.prefix, i), st.g), fout, fin + 1, fout, M, splitk=True, tn=True, ones_last_row=True)
                 continue
             # transposes (K-contiguous operands for the NT weight-gradient GEMM)
             lib.e2t_transpose_bf16(d, ldd, M, fout, ws['dT'][i].data_ptr(), Mk, e.stream)
@@ -386,7 +386,7 @@ class _Lstm:
             # (inside Seq2SeqEngine.gemm_group() both products -- and the caller's other K-major products of the stage --
             #  leave in one grouped launch)
             e.gemm(x_ptr, self.in_ld, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wx', st.g), self.N4,
-                   self.D + 1, self.N4, M, splitk=True, tn=True)
+                   self.D + 1, self.N4, M, splitk=True, tn=True, ones_last_row=True)
             # h_{t-1} in processing order: ext block t (forward) / t+2 (backward direction).  Both directions in ONE
             # batched launch: twice the tiles, so half the K splits (slabs, workgroup start-ups) for the same fill
             e.gemm(ws['Yext'].data_ptr(), self.ldy, ws['dG'].data_ptr(), rk(self.N4), st.ptr(self.name + '.Wh', st.g), 4 * Hh,

@@ -1,6 +1,9 @@
 """Operand packing of the engine: the bf16 images every kernel reads (K-contiguous and K-major GEMM operands, MFMA fragment
 images of the recurrent kernels) are rebuilt from the fp32 masters or the EMA shadows by e2t_pack_batch launches driven by
 device-resident descriptor tables.  Mixed into Seq2SeqEngine (engine.py)."""
+import ctypes as C
+
+import numpy as np
 import torch
 
 from . import hip_lib as H
@@ -33,6 +36,140 @@ class PackingMixin:
                 tab = self._pack_descs(ops, self.store.p) if ops else False
             self._pack_sub[key] = tab
         return tab
+
+    # ------------------------------------------------------------------ update + images in one pass (e2t_adam_pack_batch)
+    def _tile_groups(self, ops):
+        """The pack operations `ops`, grouped by the sub-matrix of the masters they read (master orientation: rows of
+        contiguous elements): [(key = (offset, R, C, row stride), [(image kind, destination address, ld)])], and the operations
+        that cannot go through the tile kernel (alignment)."""
+        p0 = self.store.p.data_ptr()
+        groups, rest = {}, []
+        for op in ops:
+            if op[0] == 'cast':
+                _, sp, rs, cs, R, Cn, dst, k0, r0 = op
+                ld = dst.shape[-1]
+                dptr = dst.data_ptr() + 2 * (r0 * ld + k0)
+                off = (sp - p0) // 4
+                if cs == 1:
+                    key, img = (off, R, Cn, rs), (H.TILE_CAST, dptr, ld)
+                elif rs == 1:
+                    key, img = (off, Cn, R, cs), (H.TILE_CAST_T, dptr, ld)
+                else:
+                    rest.append(op)
+                    continue
+                ok = ld % 4 == 0 and dptr % 8 == 0
+            else:
+                _, sp, ns, ks, Nn, Kk, dst = op
+                off = (sp - p0) // 4
+                if op[0] == 'frag4':
+                    key, img = (off, Kk, 4 * Nn, ks), (H.TILE_FRAG4_KN, dst.data_ptr(), ceil_div(Kk, 32))
+                    ok = ns == 4
+                elif ks == 1:
+                    key, img = (off, Nn, Kk, ns), (H.TILE_FRAG_NK, dst.data_ptr(), ceil_div(Kk, 32))
+                    ok = True
+                elif ns == 1:
+                    key, img = (off, Kk, Nn, ks), (H.TILE_FRAG_KN, dst.data_ptr(), ceil_div(Kk, 32))
+                    ok = True
+                else:
+                    rest.append(op)
+                    continue
+                ok = ok and dst.data_ptr() % 16 == 0
+            off, R, Cc, s0 = key
+            if not (ok and off % 4 == 0 and s0 % 4 == 0 and Cc % 4 == 0 and s0 >= Cc):
+                rest.append(op)
+                continue
+            groups.setdefault(key, []).append((img, op))
+        out = []
+        for key, lst in groups.items():
+            for i in range(0, len(lst), H.TILE_IMG_MAX):       # (more images than a descriptor holds: the first chunk updates, the others only pack)
+                out.append((key, [im for im, _ in lst[i:i + H.TILE_IMG_MAX]], i == 0))
+        return out, rest
+
+    def _tile_table(self, groups):
+        descs = (H.TileDesc * len(groups))()
+        nblk = 0
+        for d, (key, imgs, _) in zip(descs, groups):
+            off, R, Cc, s0 = key
+            d.first_block, d.R, d.C, d.nimg, d.src_off, d.s0 = nblk, R, Cc, len(imgs), off, s0
+            for j, (kind, dptr, ld) in enumerate(imgs):
+                d.img[j].dst, d.img[j].kind, d.img[j].ld = dptr, kind, ld
+            nblk += ceil_div(R, 64) * ceil_div(Cc, 64)
+        raw = bytes(descs)
+        return (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(groups), nblk)
+
+    def _fused_update_plan(self, key):
+        """For the element ranges `key` of the flat buffers: (tile table of the sub-matrices that are updated AND re-packed in one
+        pass, tile table of further images of those sub-matrices (pack only, behind the update), ranges left to the plain optimiser
+        kernel -- biases and whatever no image is made of --, table of the pack operations left to e2t_pack_batch).  Built once,
+        outside any stream capture."""
+        plan = self._fused_plans.get(key)
+        if plan is None:
+            if self._pack_table is None:
+                self.pack('p')
+            ops = [op for op in self._pack_ops[1] if self._op_in(op, key)]
+            groups, rest = self._tile_groups(ops)
+            # a sub-matrix may be updated by the tile kernel only if it lies inside the ranges and no other sub-matrix touches it
+            n = self.store.n
+            cover = np.zeros(n, np.uint8)
+            inside = np.zeros(n, bool)
+            for a, b in key:
+                inside[a:b] = True
+
+            def cells(k):
+                off, R, Cc, s0 = k
+                if s0 == Cc:                       # whole rows: one contiguous range
+                    return slice(off, off + R * Cc)
+                return (off + np.arange(R, dtype=np.int64)[:, None] * s0 + np.arange(Cc, dtype=np.int64)[None, :]).ravel()
+            for k in {g[0] for g in groups}:
+                cover[cells(k)] += 1
+            upd, pack_only = [], []
+            for g in groups:
+                c = cells(g[0])
+                if g[2] and inside[c].all() and (cover[c] == 1).all():
+                    upd.append(g)
+                else:
+                    pack_only.append(g)
+            done = np.zeros(n, bool)
+            for g in upd:
+                done[cells(g[0])] = True
+            left = inside & ~done
+            # contiguous runs of what is left
+            idx = np.flatnonzero(np.diff(np.concatenate([[0], left.view(np.int8), [0]])))
+            plain = [(int(a), int(b)) for a, b in zip(idx[0::2], idx[1::2])]
+            # what is left (bias rows and vectors, matrices without a tile image: whole 64-float groups, segments being padded to
+            # that) rides along in the SAME launch as image-less descriptors of 64-column rows; only ragged ends stay plain ranges
+            if upd:
+                keep = []
+                for a, b in plain:
+                    a4 = -(-a // 4) * 4
+                    nrow = (b - a4) // 64
+                    if nrow > 0 and a4 == a:
+                        upd.append(((a, nrow, 64, 64), [], True))
+                        a = a + nrow * 64
+                    if b > a:
+                        keep.append((a, b))
+                plain = keep
+            plan = (self._tile_table(upd) if upd else None, self._tile_table(pack_only) if pack_only else None, plain,
+                    self._pack_descs(rest, self.store.p) if rest else None)
+            self._fused_plans[key] = plan
+        return plan
+
+    def adam_pack_ranges(self, ranges, step_offset=0):
+        """Adam + EMA on the element ranges AND the re-pack of every image sourced from them: the tile kernel on the weight
+        matrices (one pass: 40 instead of 48 bytes per parameter), the plain optimiser kernel on what is left (biases), the
+        plain pack kernel on images the tile kernel does not make.  Same bits as adam_ranges + pack_ranges."""
+        upd, pack_only, plain, rest = self._fused_update_plan(tuple(ranges))
+        st, store = self.stream, self.store
+        if plain:
+            self.adam_ranges(plain, step_offset=step_offset)
+        if upd:
+            h = self._adam_hyper(step_offset)
+            lib.e2t_adam_pack_batch(upd[0].data_ptr(), upd[1], upd[2], store.p.data_ptr(), store.g.data_ptr(), store.m.data_ptr(),
+                                    store.v.data_ptr(), store.ema.data_ptr(), self.step_t.data_ptr(), C.byref(h), st)
+        if pack_only:
+            lib.e2t_adam_pack_batch(pack_only[0].data_ptr(), pack_only[1], pack_only[2], store.p.data_ptr(), None, None, None, None, None, None, st)
+        if rest:
+            lib.e2t_pack_batch(rest[0].data_ptr(), rest[1], rest[2], store.p.data_ptr(), st)
 
     def _op_in(self, op, ranges):
         off = (op[1] - self.store.p.data_ptr()) // 4

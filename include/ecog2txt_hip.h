@@ -38,7 +38,8 @@ extern "C" {
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
- * which = 0 e2t_gemm_epilogue, 1 e2t_lstm_desc, 2 e2t_pack_desc, 3 e2t_adam_hyper, 4 e2t_dropout, 5 e2t_gemm_call; -1 for any other value */
+ * which = 0 e2t_gemm_epilogue, 1 e2t_lstm_desc, 2 e2t_pack_desc, 3 e2t_adam_hyper, 4 e2t_dropout, 5 e2t_gemm_call, 6 e2t_tile_desc [ABI 8];
+ * -1 for any other value */
 int e2t_sizeof(int which);
 const char* e2t_last_error(void);          /* thread-local, host pointer */
 /* number of compute units / XCDs of `device`, 0 if no device is usable */
@@ -101,6 +102,10 @@ int e2t_decoder_tokens(const int32_t* y, int B, int L, int eos, int32_t* U, int3
 #define E2T_GEMM_ACCUMULATE 4      /* fp32 output only */
 #define E2T_GEMM_DROPOUT 8
 #define E2T_GEMM_SPLITK 16         /* split K over workgroups: partials in splitk_ws, fixed-order reduce which applies the epilogue */
+#define E2T_GEMM_LAST_ROW_ONES 32  /* ABI 8, e2t_gemm_tn_bf16 only: column M-1 of the K-major operand A is all ones (the ones column that turns
+                                      [x | 1]^T . dG into weights + bias), so row M-1 of the product is the column sums of B.  A hint: where
+                                      that row would cost a launch of its own (the ragged edge of a 256 x 256-tiled product) it is computed
+                                      by a column-sum pass over B instead (fp32 sums in a fixed order; alpha and E2T_GEMM_ACCUMULATE apply) */
 typedef struct e2t_gemm_epilogue {
     const float* bias;             /* [N] or NULL */
     const void* relu_bwd_src;      /* bf16 [M][ld]: out = src != 0 ? out : 0 (ReLU/dropout backward) */
@@ -304,6 +309,33 @@ typedef struct e2t_adam_hyper {
 int e2t_inc_step(int32_t* step, const int32_t* skip_if_nonzero, void* stream);
 int e2t_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, const int32_t* step,
                       const e2t_adam_hyper* h /* host pointer */, void* stream);
+
+/* ABI 8 -- the optimiser update and the operand re-pack of a parameter matrix in ONE pass (the HBM-bound tail of the train step:
+ * e2t_adam_ema_step writes the masters and e2t_pack_batch reads them again once per image).  A descriptor names a sub-matrix of the
+ * flat fp32 buffers in MASTER orientation (R rows of C contiguous elements, row stride s0, origin src_off) and up to three bf16
+ * images of it; a 256-thread workgroup owns one 64 x 64 tile: it loads p (and, with an update, g, m, v, ema), applies exactly
+ * e2t_adam_ema_step's arithmetic, writes p, m, v, ema back, and emits the tile's share of every image from LDS -- the same bits
+ * e2t_pack_batch would have produced from the updated masters.  src_off, s0, C multiples of 4; image kinds:
+ *   1  dst[r*ld + c] = bf16(x[r][c])                      (ld multiple of 4, dst 8-B aligned)
+ *   2  dst[c*ld + r] = bf16(x[r][c])                      (ld multiple of 4, dst 8-B aligned)
+ *   3  MFMA fragment image of Bn[n = r][k = c]            (ld = ceil(C/32) k-blocks; e2t_pack_desc kind 1)
+ *   4  MFMA fragment image of Bn[n = c][k = r]            (ld = ceil(R/32); e2t_pack_desc kind 5)
+ *   5  the four per-gate fragment images of a gate-interleaved matrix, Bn_g[n][k = r] = x[r][n*4 + g], contiguous at dst
+ *      [4][ceil(C/64)][ld]                                 (ld = ceil(R/32); C multiple of 4; e2t_pack_desc kind 6)
+ * Descriptors of one launch must not overlap (every element is updated by exactly one workgroup). */
+#define E2T_TILE_IMG_MAX 3
+typedef struct e2t_tile_img { void* dst; int kind; int ld; } e2t_tile_img;
+typedef struct e2t_tile_desc {
+    int first_block;     /* first workgroup of this descriptor (exclusive prefix, ascending); it owns ceil(R/64)*ceil(C/64) */
+    int R, C, nimg;
+    long long src_off;   /* element offset of the sub-matrix's origin in the flat buffers */
+    long long s0;        /* row stride in elements */
+    e2t_tile_img img[E2T_TILE_IMG_MAX];
+} e2t_tile_desc;
+/* h == NULL: images only, from `p` (any flat fp32 buffer: the masters or the EMA shadows); g, m, v, ema are then ignored.
+ * h != NULL: update + images; *h->skip_if_nonzero != 0 leaves everything untouched (the images stay those of the old masters). */
+int e2t_adam_pack_batch(const e2t_tile_desc* descs_dev, int ndesc, int total_blocks, float* p, const float* g, float* m, float* v,
+                        float* ema, const int32_t* step, const e2t_adam_hyper* h /* host pointer or NULL */, void* stream);
 
 /* ---- e1: the exchange step of the utterance-sharded data-parallel path (new: the reference trains on one device,
  *      trainers.py:131).  RCCL over xGMI, one communicator per process / GPU.  Collectives run on a stream the

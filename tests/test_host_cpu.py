@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     # the ctypes mirrors of the boundary structs have the C layouts' sizes
     for which, cls in enumerate([hip_lib.GemmEpilogue, hip_lib.LstmDesc, hip_lib.PackDesc, hip_lib.AdamHyper, hip_lib.Dropout]):
         assert lib.e2t_sizeof(which) == ctypes.sizeof(cls), cls.__name__
+    assert lib.e2t_sizeof(6) == ctypes.sizeof(hip_lib.TileDesc)
     assert lib.e2t_sizeof(99) == -1
 
 
