@@ -3,7 +3,7 @@
 # kernel stats + one-step timelines of cfg2 / cfg4 / cfg5 (fp32 and bf16-staged inputs), the PMC passes of cfg2's kernels, the
 # vendor-BLAS calibration and the data-parallel schedule on one GPU.
 #   scripts/gpu_evidence.sh <tag> [notests]   -> gpurun_out/<tag>/ (copy what is to be judged into profiles/<tag>_*)
-tag=${1:-r04}; out=$PWD/gpurun_out/$tag; mkdir -p $out
+tag=${1:-r05}; out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1 || { tail -20 $out/build.log; exit 1; }
 if [ "$2" != notests ]; then
@@ -26,4 +26,9 @@ python scripts/pmc_kernels_summary.py gpurun_out/pmc_cfg2 $tag > $out/pmc_summar
 timeout 900 python scripts/calib_blas.py all 2>&1 | grep -v amdgpu.ids > $out/calib_blas.txt
 timeout 600 python scripts/dp_step_one_gpu.py 2>&1 | grep "ms per step" > $out/dp_step_one_gpu.txt; cat $out/dp_step_one_gpu.txt
 timeout 600 python scripts/dp_step_one_gpu.py cfg4 30 2>&1 | grep "ms per step" >> $out/dp_step_one_gpu.txt
+# round 5: the fused tail alone, single-utterance decode latency, fit-level throughput, phase stamps of the recurrences
+for c in cfg2 cfg4; do timeout 300 python scripts/bench_tail.py $c 2>&1 | grep -v amdgpu.ids >> $out/tail_alone.txt; done; cat $out/tail_alone.txt
+for c in cfg2 cfg4; do timeout 300 python scripts/latency_b1.py $c 2>&1 | grep -v amdgpu.ids >> $out/latency_b1.txt; done; cat $out/latency_b1.txt
+timeout 600 python scripts/bench_fit.py 100 2>&1 | grep -v amdgpu.ids > $out/fit_throughput.txt; tail -3 $out/fit_throughput.txt
+TIMELINE=1 timeout 600 python scripts/bench_lstm_step.py cfg2 2>&1 | grep -v amdgpu.ids > $out/lstm_step_phases.txt; head -30 $out/lstm_step_phases.txt
 ls $out
