@@ -529,6 +529,7 @@ def main():
             dist.init_process_group(backend, **({'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}))
         return parallel.make_sync(eng.store.g)
 
+    done = printed = None
     if world > 1 and ndev < world and os.environ.get('E2T_BENCH_BACKEND') != 'gloo':
         sys.exit('bench.py: %d ranks, but %d GPU(s) are visible' % (world, ndev))
     out, sync = measure(args.config, args, args.steps, args.warmup, rank, world, dev_index, sync_factory if world > 1 else None,
@@ -543,12 +544,12 @@ def main():
         # line it has and every rank leaves.  If it completes, the line carries both schedules and `value` is the faster one.
         import threading
         first = out
-        done = threading.Event()
+        done, printed = threading.Event(), [False]
         limit = float(os.environ.get('E2T_BENCH_WATCHDOG_S', '300'))
 
         def watchdog():
             if not done.wait(limit if rank == 0 else limit + 20.0):          # (rank 0 prints before the others leave)
-                if rank == 0:
+                if rank == 0 and not printed[0]:
                     first['config']['dp_one_graph'] = 'no result within %.0f s (watchdog); the line is the graph-per-stage schedule' % limit
                     print(json.dumps(first), flush=True)
                 os._exit(0)
@@ -556,11 +557,19 @@ def main():
         sync.barrier()
         sync.close()
         args.engine_option = list(args.engine_option) + ['dp_one_graph=True']
+        out2, err2 = None, None
         try:
             out2, sync = measure(args.config, args, args.steps, args.warmup, rank, world, dev_index, sync_factory, roofline=False,
                                  batch=args.batch, inputs=args.inputs)
-        finally:
-            done.set()
+        except Exception as e:                               # (the line of the default schedule must survive whatever happens here;
+            err2, sync = repr(e)[:300], None                 #  ranks left waiting in a collective are released by their watchdogs)
+        # (the watchdog stays armed until the closing barrier at the end of main(): a rank that failed here leaves, and the others
+        #  must not wait for it for ever)
+        if err2 is not None:
+            if rank == 0:
+                first['config']['dp_one_graph'] = 'failed: %s; the line is the graph-per-stage schedule' % err2
+                print(json.dumps(first), flush=True)
+            os._exit(0)
         if rank == 0:
             both = dict(graph_per_stage_ms=first['ms_per_step'], one_graph_ms=out2['ms_per_step'])
             if out2['ms_per_step'] < first['ms_per_step']:
@@ -598,10 +607,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             spec_kw, B, T, L = CONFIGS[args.config]
             out['cpu_baseline'] = cpu_baseline(spec_kw, args.batch or B, T, L, cfg=args.config, batch_override=args.batch)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        if printed is not None:
+            printed[0] = True
     if sync is not None and hasattr(sync, 'close'):
         sync.barrier()
         sync.close()
+    if done is not None:
+        done.set()
 
 
 if __name__ == '__main__':
