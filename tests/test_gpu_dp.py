@@ -53,10 +53,16 @@ def _run(world, port, root, ckdir, n_cases, **kw):
     procs = [ctx.Process(target=_worker, args=(r, world, port, root, ckdir, n_cases, q), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                  # (a rank that hangs -- in a collective, say -- must not outlive the test)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=30)
     return sorted(res, key=lambda r: r['rank'])
 
 
@@ -187,10 +193,16 @@ def test_cfg2_data_parallel_step_with_a_real_peer(one_graph):
     procs = [ctx.Process(target=_dp_step_worker, args=(r, 2, port, one_graph, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r['rank'])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r['rank'])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=30)
     a, b = res
     assert a['ranks'] == b['ranks'] == 2 and a['err'] == b['err'] == 0 and a['step'] == b['step'] == 13
     assert a['p'] == b['p'] and a['pabs'] == b['pabs']                      # replicas: bit-identical parameters
