@@ -836,6 +836,9 @@ __global__ __launch_bounds__(256) void k_adam_pack(const e2t_tile_desc* descs, i
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1; }
     // (scalar fields only: a local copy of the descriptor, indexed by the image loop below, would live in scratch)
     struct { int R, C, nimg; long long src_off, s0; } d = {descs[lo].R, descs[lo].C, descs[lo].nimg, descs[lo].src_off, descs[lo].s0};
+    const float* gslab = descs[lo].gslab;                  // the gradient as the slabs a split K-major product left (or null: g)
+    const long long gstride = descs[lo].gstride;
+    const int gsplits = descs[lo].gsplits;
     const int lb = bid - descs[lo].first_block;
     const int tcn = (d.C + 63) >> 6;
     const int tr = lb / tcn, tc = lb - tr * tcn;
@@ -858,7 +861,15 @@ __global__ __launch_bounds__(256) void k_adam_pack(const e2t_tile_desc* descs, i
         const size_t idx = in ? (size_t)d.src_off + (size_t)r * (size_t)d.s0 + c : 0;      // (outside: the buffers' first 16 B, zeroed below)
         f4 pv = *(const f4*)(p + idx);
         if (a.update) {
-            const f4 gv = __builtin_nontemporal_load((const f4*)(g + idx));
+            f4 gv;
+            if (gslab) {
+                // sum of the product's split-K slabs in split order: the bits k_splitk_reduce would have written to g
+                const float* q = gslab + (in ? (size_t)(tr * 64 + b + 16 * i) * (size_t)d.s0 + (tc * 64 + a4) : 0);
+                gv = __builtin_nontemporal_load((const f4*)q);
+                for (int sp = 1; sp < gsplits; ++sp) gv += __builtin_nontemporal_load((const f4*)(q + (size_t)sp * gstride));
+            } else {
+                gv = __builtin_nontemporal_load((const f4*)(g + idx));
+            }
             const f4 mv = __builtin_nontemporal_load((const f4*)(m + idx));
             const f4 vv = __builtin_nontemporal_load((const f4*)(v + idx));
             const f4 ev = __builtin_nontemporal_load((const f4*)(ema + idx));

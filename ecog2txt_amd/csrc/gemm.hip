@@ -599,7 +599,7 @@ __host__ __device__ inline size_t splitk_reduce_stride_g(int M, int N, int group
 // PLAIN: nothing between the sum and a 16-B fp32 store (the weight gradients); else the full epilogue of the GEMM kernel
 template <int G, bool PLAIN> __device__ __forceinline__ void splitk_reduce_body(const GemmArgs& p_in, int z);
 __host__ __device__ inline bool splitk_reduce_plain(const GemmArgs& p) {
-    return !p.bias && !p.lens && !p.mask_src && !p.last_col_out && (p.flags & ~E2T_GEMM_SPLITK) == 0 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
+    return !p.bias && !p.lens && !p.mask_src && !p.last_col_out && (p.flags & ~(E2T_GEMM_SPLITK | E2T_GEMM_KEEP_SLABS)) == 0 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
 }
 __host__ __device__ inline int splitk_reduce_groups(const GemmArgs& p) { return !splitk_reduce_plain(p) ? 1 : p.splits <= 2 ? 4 : p.splits <= 4 ? 2 : 1; }
 __device__ __forceinline__ void splitk_reduce_any(const GemmArgs& p, int z) {
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs p_in) { splitk_r
 __global__ __launch_bounds__(256) void k_splitk_reduce_group(GemmGroupArgs g) {
     if ((int)blockIdx.y >= g.n) return;
     const GemmArgs& p = g.p[blockIdx.y];
-    if (p.splits <= 1 || (int)blockIdx.z >= p.batch) return;
+    if (p.splits <= 1 || (p.flags & E2T_GEMM_KEEP_SLABS) || (int)blockIdx.z >= p.batch) return;
     splitk_reduce_any(p, blockIdx.z);
 }
 template <int G, bool PLAIN>
@@ -1257,7 +1257,7 @@ static int gemm_make_args(bool tn, const void* A, int lda, const void* B, int ld
         p.mask_src = (const bf16_t*)ep->relu_bwd_src; p.ld_mask = ep->ld_relu_bwd_src;
         p.lens = ep->row_lens; p.rowsB = ep->rows_per_step > 0 ? ep->rows_per_step : 1; p.rowsG = ep->row_group > 0 ? ep->row_group : 1;
         p.alpha = ep->alpha;
-        p.flags = ep->flags;
+        p.flags = ep->flags & ~(E2T_GEMM_LAST_ROW_ONES | E2T_GEMM_KEEP_SLABS);      // (hints to the launcher: the kernels and the choice of the reduction never see them)
         p.drop.rate = ep->drop_rate; p.drop.seed = ep->drop_seed; p.drop.step = ep->drop_step;
         p.drop.stream = ep->drop_stream; p.ld_logical = ep->drop_ld > 0 ? ep->drop_ld : N;
         p.last_col_out = ep->last_col_out;
@@ -1323,6 +1323,8 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
             (((uintptr_t)B) & 15) == 0) {
             // the one row beyond the last full tile is the ones column's: column sums of B, one pass, no slabs
             e2t_gemm_epilogue e0 = *ep;
+            e0.flags &= ~E2T_GEMM_KEEP_SLABS; e0.slabs_out = nullptr;            // (the row of sums is written straight into C: so is the rest)
+            if (ep->slabs_out) *ep->slabs_out = e2t_slab_info{nullptr, 1, 1, 0};
             if (int rc = gemm_launch(true, A, lda, B, ldb, C, ldc, M - 1, N, K, &e0, stream)) return rc;
             hipLaunchKernelGGL(k_colsum_bf16, dim3((unsigned)((N + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)B, ldb, K, N,
                                (float*)C + (size_t)(M - 1) * ldc, ep->alpha, (ep->flags & E2T_GEMM_ACCUMULATE) ? 1 : 0);
@@ -1331,12 +1333,16 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
         }
         if (rm > 0 && rm <= 32 && M > 256) {
             e2t_gemm_epilogue e0 = *ep, e1 = *ep;
+            e0.flags &= ~E2T_GEMM_KEEP_SLABS; e1.flags &= ~E2T_GEMM_KEEP_SLABS; e0.slabs_out = e1.slabs_out = nullptr;      // (two launches, two split counts)
+            if (ep->slabs_out) *ep->slabs_out = e2t_slab_info{nullptr, 1, 1, 0};
             if (ep->last_col_out) e1.last_col_out = ep->last_col_out + (M - rm);
             if (int rc = gemm_launch(true, A, lda, B, ldb, C, ldc, M - rm, N, K, &e0, stream)) return rc;
             return gemm_launch(true, (const bf16_t*)A + (M - rm), lda, B, ldb, (char*)C + (size_t)(M - rm) * ldc * elt, ldc, rm, N, K, &e1, stream);
         }
         if (rn > 0 && rn <= 32 && N > 256) {
             e2t_gemm_epilogue e0 = *ep, e1 = *ep;
+            e0.flags &= ~E2T_GEMM_KEEP_SLABS; e1.flags &= ~E2T_GEMM_KEEP_SLABS; e0.slabs_out = e1.slabs_out = nullptr;
+            if (ep->slabs_out) *ep->slabs_out = e2t_slab_info{nullptr, 1, 1, 0};
             e0.last_col_out = nullptr;
             if (ep->bias) e1.bias = ep->bias + (N - rn);
             if (int rc = gemm_launch(true, A, lda, B, ldb, C, ldc, M, N - rn, K, &e0, stream)) return rc;
@@ -1379,9 +1385,14 @@ static int gemm_launch(bool tn, const void* A, int lda, const void* B, int ldb, 
     else if (big) E2T_GEMM_GO(256, 256, 2, 4, false, false, 64, 2, 0);
     else E2T_GEMM_GO(128, 128, 2, 2, true, false, 64, 2, 0);
 #undef E2T_GEMM_GO
+    if (ep && ep->slabs_out) *ep->slabs_out = e2t_slab_info{nullptr, 1, batch, 0};
     if (p.splits > 1) {
-        const size_t n = (size_t)M * ((N + 3) / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256), batch), dim3(256), 0, (hipStream_t)stream, p);
+        if (tn && ep && (ep->flags & E2T_GEMM_KEEP_SLABS) && ep->slabs_out && p.alpha == 1.0f && p.ldc == p.N && splitk_reduce_plain(p)) {
+            // the slabs stay where they are: the optimiser kernel sums them as it reads the gradient
+            *ep->slabs_out = e2t_slab_info{p.slab, p.splits, batch, (long long)p.M * p.N};
+        } else {
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256), batch), dim3(256), 0, (hipStream_t)stream, p);
+        }
     }
     E2T_LAUNCH_CHECK();
     return E2T_OK;
@@ -1404,6 +1415,7 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
     E2T_CHECK_ARG(n >= 1 && n <= E2T_GEMM_GROUP_MAX && calls);
     GemmGroupArgs g{};
     int tiles[E2T_GEMM_GROUP_MAX], kt[E2T_GEMM_GROUP_MAX];
+    const e2t_gemm_epilogue* eps[E2T_GEMM_GROUP_MAX];
     int m = 0;
     const e2t_gemm_epilogue* ep0 = nullptr;
     for (int i = 0; i < n; ++i) {
@@ -1418,6 +1430,7 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
         if (!ep0) ep0 = c.ep;
         tiles[m] = ((c.M + 127) / 128) * ((c.N + 127) / 128) * p.batch;
         kt[m] = (c.K + BK - 1) / BK;
+        eps[m] = c.ep;
         g.p[m++] = p;
     }
     if (m == 0) return E2T_OK;
@@ -1452,12 +1465,20 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
         const size_t need = (size_t)sp * p.M * p.N * p.batch * sizeof(float);
         if (sp > 1 && off + need > ep0->splitk_ws_bytes) sp = 1;
         p.splits = sp;
+        const e2t_gemm_epilogue* epi = eps[i];
+        if (epi->slabs_out) *epi->slabs_out = e2t_slab_info{nullptr, 1, p.batch, 0};
         if (sp > 1) {
             p.slab = (float*)((char*)ep0->splitk_ws + off);
             off += (need + 255) / 256 * 256;
-            any_split = true;
-            max_red = std::max(max_red, (unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256));
-            max_batch = std::max(max_batch, p.batch);
+            if ((epi->flags & E2T_GEMM_KEEP_SLABS) && epi->slabs_out && p.alpha == 1.0f && p.ldc == p.N && splitk_reduce_plain(p)) {
+                // left for the optimiser kernel (E2T_GEMM_KEEP_SLABS): the grouped reduction skips this product
+                *epi->slabs_out = e2t_slab_info{p.slab, sp, p.batch, (long long)p.M * p.N};
+                p.flags |= E2T_GEMM_KEEP_SLABS;
+            } else {
+                any_split = true;
+                max_red = std::max(max_red, (unsigned)(splitk_reduce_stride_g(p.M, p.N, splitk_reduce_groups(p)) / 256));
+                max_batch = std::max(max_batch, p.batch);
+            }
         }
         g.first[i] = first;
         g.count[i] = tiles[i] * sp;

@@ -41,10 +41,12 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   launch_stream  captured steps replayed from a stream of the engine's own (False: the caller's stream)
     #   fused_tail     the captured step's early optimiser update and the re-pack of its images as ONE pass over the weight matrices
     #                  (e2t_adam_pack_batch; False: e2t_adam_ema_step, then e2t_pack_batch -- the same bits)
+    #   fused_reduce   (with fused_tail, single GPU) the weight gradients of the early ranges leave their split-K slabs un-reduced and the
+    #                  fused kernel sums them as it reads the gradient (E2T_GEMM_KEEP_SLABS; False: reduction launches as ever)
     #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes; False (the default until that schedule has
     #                  run with more than one RCCL rank): one graph per backward stage, the collectives issued eagerly between them --
     #                  also the fallback ALL ranks take together when any rank's capture is refused
-    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True)
+    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -116,6 +118,8 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         self._pack_table = None
         self._pack_ops, self._pack_sub = None, {}
         self._fused_plans = {}        # element ranges -> tables of e2t_adam_pack_batch (packing._fused_update_plan)
+        self._keep_slabs, self._slab_log, self._arenas, self._arena_seq, self._group_arena = None, [], [], 0, None
+        self._fused_sigs, self._fused_retired = {}, []
         self._img_early = None        # 'all' after a full pack of the masters, else the ranges the last replay re-packed itself
         self._gemm_log = None         # a list while bench.py records the step's products (instance, shape, flops)
         self._in_group = False
@@ -206,6 +210,14 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             flags |= H.GEMM_LAST_ROW_ONES
         # the workspace is always offered: the library also splits K on its own when a product has too few tiles
         wsb = self.splitk_ws_side if self._on_side else self.splitk_ws
+        keep_info = None
+        if self._keep_slabs is not None and tn and splitk and self._keeps(Cp, M, N, ldc, batch, alpha, accumulate, last_col_out, bias):
+            # the captured single-GPU step leaves a weight gradient's split-K slabs for the fused optimiser kernel to sum
+            # (E2T_GEMM_KEEP_SLABS): the slabs need a workspace of their own until that kernel has run -- one arena per launch
+            keep_info = H.SlabInfo()
+            ep.slabs_out = C.pointer(keep_info)
+            flags |= H.GEMM_KEEP_SLABS
+            wsb = self._group_arena if self._group is not None else self._next_arena()
         ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
@@ -221,7 +233,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             # inside `with self.gemm_group():` -- the K-major weight-gradient products of a stage leave in ONE launch.  (A
             # product large enough for the 256 x 256 instance -- H = 1024: 2049 x 8192 x 8704 -- keeps its own launch: the
             # grouped kernel works on 128 x 128 tiles, half the flops per staged byte; cfg4 9.49 -> 9.19 ms.)
-            self._group.append((A, lda, B, ldb, Cp, ldc, M, N, K, ep, alg or (M, N, K), batch[0] if batch is not None else 1))
+            if self._group_arena is not None:          # (one workspace per group: the first call's serves all its products)
+                ep.splitk_ws, ep.splitk_ws_bytes = self._group_arena.data_ptr(), self._group_arena.numel() * 4
+            self._group.append((A, lda, B, ldb, Cp, ldc, M, N, K, ep, alg or (M, N, K), batch[0] if batch is not None else 1, keep_info))
             return
         if self._gemm_log is not None:
             tile, splits = C.c_int(0), C.c_int(0)
@@ -233,6 +247,33 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                                        in_bytes=2 * (am * ak + an * ak) * nb, side=self._on_side,
                                        call=(A, lda, B, ldb, Cp, ldc, M, N, K), ep=ep, tn=tn))
         (lib.e2t_gemm_tn_bf16 if tn else lib.e2t_gemm_nt_bf16)(A, lda, B, ldb, Cp, ldc, M, N, K, C.byref(ep), self.stream)
+        if keep_info is not None:
+            self._log_slabs(Cp, M, N, batch, keep_info)
+
+    # ---- split-K slabs left for the fused optimiser kernel (E2T_GEMM_KEEP_SLABS) ----
+    def _keeps(self, Cp, M, N, ldc, batch, alpha, accumulate, last_col_out, bias):
+        """May this K-major split product leave its slabs un-reduced?  Its gradient must lie inside the ranges the fused kernel
+        updates, be a dense fp32 [M][N] with nothing between the sum and the store, and end on the 64-float grid of the tile
+        descriptors (so that every element of it is reached by a descriptor that knows about the slabs)."""
+        if accumulate or alpha != 1.0 or last_col_out is not None or bias is not None or ldc != N or (M * N) % 64 or N % 4:
+            return False
+        off = (Cp - self.store.g.data_ptr()) // 4
+        nb, cbs = (batch[0], batch[3]) if batch is not None else (1, M * N)
+        if off % 64 or (nb > 1 and cbs != M * N):
+            return False
+        return any(a <= off and off + nb * M * N <= b for a, b in self._keep_slabs)
+
+    def _next_arena(self):
+        i = self._arena_seq
+        self._arena_seq += 1
+        while len(self._arenas) <= i:                     # (allocated by the eager pass in front of a capture, never inside one)
+            self._arenas.append(_f32(self.splitk_ws_side.numel(), device=self.device))
+        return self._arenas[i]
+
+    def _log_slabs(self, Cp, M, N, batch, info):
+        if info.splits > 1:
+            off = (Cp - self.store.g.data_ptr()) // 4
+            self._slab_log.append(dict(off=off, M=M, N=N, batch=batch[0] if batch is not None else 1, slab=info.slab, splits=info.splits, stride=info.stride))
 
     def _plan_tile(self, tn, M, N, K, ep):
         tile, splits = C.c_int(0), C.c_int(0)
@@ -257,11 +298,13 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 assert not eng._in_group
                 eng._in_group = True
                 eng._group = [] if eng.group_gemms else None
+                eng._group_arena = eng._next_arena() if (eng._keep_slabs is not None and eng._group is not None) else None
                 return self_g
 
             def __exit__(self_g, et, ev, tb):
                 items, eng._group = eng._group, None
                 eng._in_group = False
+                eng._group_arena = None
                 if et is not None or not items:
                     return False
                 eng._launch_group(items)
@@ -286,6 +329,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                                            side=self._on_side, group=calls, keep=keep, tn=True,
                                            desc=' + '.join('%dx%dx%d%s' % (it[10][0], it[10][1], it[10][2], ('x%d' % it[11]) if it[11] > 1 else '') for it in part)))
             lib.e2t_gemm_tn_group_bf16(len(part), calls, self.stream)
+            for it in part:
+                if len(it) > 12 and it[12] is not None:
+                    self._log_slabs(it[4], it[6], it[7], (it[11], 0, 0, it[6] * it[7]) if it[11] > 1 else None, it[12])
 
     def _dropout(self, rate, stream):
         d = H.Dropout()
@@ -860,6 +906,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         ws['have_dy'] = [False] * len(self.enc)
         ws['_aux_join'] = None
         ws['fwd_train'] = train
+        self._arena_seq = 0                 # (slab arenas are dealt in launch order: the same order in every backward pass)
         deferred = []
         pending_early = None
         stages = self.backward_stages(ws)
@@ -1250,16 +1297,29 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                         sync.wait_flag()         # the sync_err maximum and, collectives being ordered, every all-reduce issued before it
                                                  # (these ranges'; not the bottom layer's, which follows)
                     if self.options['fused_tail']:
-                        self.adam_pack_ranges(er, step_offset=1)     # update + images in one pass over the weight matrices
+                        self.adam_pack_ranges(er, step_offset=1, slabs=slab_mode[0])     # update + images in one pass over the weight matrices
                     else:
                         self.adam_ranges(er, step_offset=1)
                         self.pack_ranges(er)
                 early = (nl, early_fn)
         g1 = torch.cuda.CUDAGraph()
+        slab_mode = [False]
         if packed_early:
             self._pack_subtable(tuple(packed_early))          # descriptor tables are built outside the capture
             if self.options['fused_tail']:
                 self._fused_update_plan(tuple(packed_early))
+                if not dp and self.options['fused_reduce']:
+                    # single GPU: the weight gradients of the early ranges are never reduced -- the fused kernel sums their split-K
+                    # slabs as it reads them.  One eager backward pass in that mode tells where the launcher leaves the slabs
+                    # (its decisions depend on shapes only: the capture below repeats them) and allocates the arenas.
+                    self._keep_slabs, self._slab_log = tuple(packed_early), []
+                    try:
+                        self.backward(ws, train=True)
+                        torch.cuda.synchronize(self.device)
+                        slab_mode[0] = self._fused_update_plan(tuple(packed_early), slab_log=self._slab_log) is not None
+                    finally:
+                        if not slab_mode[0]:
+                            self._keep_slabs = None
             self._pack_subtable(('skip',) + tuple(packed_early))
         tail = [(max(a, early_end), b) for a, b in tr if b > early_end]
 
@@ -1274,13 +1334,16 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             if dp:
                 sync.join()
             self.adam_ranges(tail, step_offset=1)
-        with capture(g1):
-            if dp:
-                sync.attach()
-            self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None, global_counts=gc)
-            self.backward(ws, train=True, early=early, before_join=tail_update, exchange=exchange if dp else None,
-                          after_last_rec=(lambda: sync.allreduce_flag(self.sync_err[0:1])) if dp else None)
-            lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
+        try:
+            with capture(g1):
+                if dp:
+                    sync.attach()
+                self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None, global_counts=gc)
+                self.backward(ws, train=True, early=early, before_join=tail_update, exchange=exchange if dp else None,
+                              after_last_rec=(lambda: sync.allreduce_flag(self.sync_err[0:1])) if dp else None)
+                lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
+        finally:
+            self._keep_slabs = None
         if dp:
             sync.pending_ranges = []                  # (tickets recorded during a capture mean nothing outside it)
             sync._flag_pending = False

@@ -12,12 +12,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel-variant switches and the phase-stamp buffers exist; the product library has none of them
 LIB_PATH = os.path.join(_HERE, 'libecog2txt_hip_dbg.so' if os.environ.get('E2T_DEBUG_LIB') == '1' else 'libecog2txt_hip.so')
 
-GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK, GEMM_LAST_ROW_ONES = 1, 2, 4, 8, 16, 32
+GEMM_RELU, GEMM_OUT_BF16, GEMM_ACCUMULATE, GEMM_DROPOUT, GEMM_SPLITK, GEMM_LAST_ROW_ONES, GEMM_KEEP_SLABS = 1, 2, 4, 8, 16, 32, 64
 PACK_UNITS = 4            # E2T_PACK_UNITS (include/ecog2txt_hip.h): work units of a pack descriptor per workgroup
 
 
 class Dropout(C.Structure):
     _fields_ = [('rate', C.c_float), ('seed', C.c_ulonglong), ('step', C.c_void_p), ('stream', C.c_uint)]
+
+
+class SlabInfo(C.Structure):
+    _fields_ = [('slab', C.c_void_p), ('splits', C.c_int), ('batch', C.c_int), ('stride', C.c_longlong)]
 
 
 class GemmEpilogue(C.Structure):
@@ -27,7 +31,7 @@ class GemmEpilogue(C.Structure):
                 ('drop_stream', C.c_uint), ('drop_ld', C.c_int), ('last_col_out', C.c_void_p),
                 ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_size_t), ('batch', C.c_int),
                 ('a_batch_stride', C.c_longlong), ('b_batch_stride', C.c_longlong), ('c_batch_stride', C.c_longlong),
-                ('row_group', C.c_int)]
+                ('row_group', C.c_int), ('slabs_out', C.POINTER(SlabInfo))]
 
 
 class GemmCall(C.Structure):
@@ -56,7 +60,8 @@ TILE_CAST, TILE_CAST_T, TILE_FRAG_NK, TILE_FRAG_KN, TILE_FRAG4_KN = 1, 2, 3, 4, 
 
 class TileDesc(C.Structure):
     _fields_ = [('first_block', C.c_int), ('R', C.c_int), ('C', C.c_int), ('nimg', C.c_int), ('src_off', C.c_longlong),
-                ('s0', C.c_longlong), ('img', TileImg * TILE_IMG_MAX)]
+                ('s0', C.c_longlong), ('gslab', C.c_void_p), ('gstride', C.c_longlong), ('gsplits', C.c_int), ('pad_', C.c_int),
+                ('img', TileImg * TILE_IMG_MAX)]
 
 
 class AdamHyper(C.Structure):

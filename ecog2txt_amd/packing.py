@@ -85,25 +85,41 @@ class PackingMixin:
                 out.append((key, [im for im, _ in lst[i:i + H.TILE_IMG_MAX]], i == 0))
         return out, rest
 
-    def _tile_table(self, groups):
+    def _tile_table(self, groups, slabs=None):
+        """slabs: {descriptor key: (address of the sub-matrix's origin in slab 0, slab stride in elements, split count)}"""
         descs = (H.TileDesc * len(groups))()
         nblk = 0
         for d, (key, imgs, _) in zip(descs, groups):
             off, R, Cc, s0 = key
             d.first_block, d.R, d.C, d.nimg, d.src_off, d.s0 = nblk, R, Cc, len(imgs), off, s0
+            if slabs and key in slabs:
+                d.gslab, d.gstride, d.gsplits = slabs[key]
             for j, (kind, dptr, ld) in enumerate(imgs):
                 d.img[j].dst, d.img[j].kind, d.img[j].ld = dptr, kind, ld
             nblk += ceil_div(R, 64) * ceil_div(Cc, 64)
         raw = bytes(descs)
         return (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(groups), nblk)
 
-    def _fused_update_plan(self, key):
+    def _fused_update_plan(self, key, slab_log=None):
         """For the element ranges `key` of the flat buffers: (tile table of the sub-matrices that are updated AND re-packed in one
         pass, tile table of further images of those sub-matrices (pack only, behind the update), ranges left to the plain optimiser
         kernel -- biases and whatever no image is made of --, table of the pack operations left to e2t_pack_batch).  Built once,
         outside any stream capture."""
-        plan = self._fused_plans.get(key)
-        if plan is None:
+        pkey = (key, 'slabs') if slab_log is not None else key
+        if slab_log is None and pkey in self._fused_plans:
+            return self._fused_plans[pkey]
+        if slab_log is not None:
+            # (captured graphs hold the ADDRESS of a plan's descriptor tables: a plan is never replaced by an equal one -- every
+            #  capture of the same ranges finds the slabs where the first one did -- and a superseded one is kept alive)
+            sig = tuple(sorted((e['off'], e['M'], e['N'], e['batch'], e['slab'], e['splits'], e['stride']) for e in slab_log))
+            old = self._fused_plans.get(pkey)
+            if old is not None and self._fused_sigs.get(pkey) == sig:
+                return old
+            if old is not None:
+                self._fused_retired.append(old)
+            self._fused_sigs[pkey] = sig
+        plan = None
+        if True:
             if self._pack_table is None:
                 self.pack('p')
             ops = [op for op in self._pack_ops[1] if self._op_in(op, key)]
@@ -133,9 +149,19 @@ class PackingMixin:
             for g in upd:
                 done[cells(g[0])] = True
             left = inside & ~done
-            # contiguous runs of what is left
+            # contiguous runs of what is left (cut where a product that kept its slabs begins or ends: a descriptor reads its
+            # gradient from ONE place)
+            prods = []
+            for e in (slab_log or []):
+                for z in range(e['batch']):
+                    lo = e['off'] + z * e['M'] * e['N']
+                    prods.append((lo, lo + e['M'] * e['N'], e['slab'] + 4 * z * e['splits'] * e['stride'], e['stride'], e['splits'], e['N']))
             idx = np.flatnonzero(np.diff(np.concatenate([[0], left.view(np.int8), [0]])))
-            plain = [(int(a), int(b)) for a, b in zip(idx[0::2], idx[1::2])]
+            cuts = sorted({x for lo, hi, *_ in prods for x in (lo, hi)})
+            plain = []
+            for a, b in zip(idx[0::2].tolist(), idx[1::2].tolist()):
+                pts = [a] + [c for c in cuts if a < c < b] + [b]
+                plain += list(zip(pts[:-1], pts[1:]))
             # what is left (bias rows and vectors, matrices without a tile image: whole 64-float groups, segments being padded to
             # that) rides along in the SAME launch as image-less descriptors of 64-column rows; only ragged ends stay plain ranges
             if upd:
@@ -149,16 +175,42 @@ class PackingMixin:
                     if b > a:
                         keep.append((a, b))
                 plain = keep
-            plan = (self._tile_table(upd) if upd else None, self._tile_table(pack_only) if pack_only else None, plain,
+            slabs = None
+            if slab_log is not None:
+                # every descriptor that updates elements of a product whose slabs were kept must read them; one that cannot (it
+                # straddles a product's border, its rows are not the product's rows, or elements of such a product are left to the
+                # plain kernel) makes the whole scheme unusable for this step: the caller then captures with reductions as ever
+                slabs = {}
+
+                def find(off):
+                    for pr in prods:
+                        if pr[0] <= off < pr[1]:
+                            return pr
+                    return None
+                for k_, _, _ in upd:
+                    off, R, Cc, s0 = k_
+                    pr = find(off)
+                    if pr is None:
+                        if any(off < hi and lo < off + (R - 1) * s0 + Cc for lo, hi, *_ in prods):
+                            return None
+                        continue
+                    lo, hi, addr, stride, splits, N = pr
+                    if off + (R - 1) * s0 + Cc > hi or not (s0 == N or (s0 == Cc and Cc == 64)):
+                        return None
+                    slabs[k_] = (addr + 4 * (off - lo), stride, splits)
+                for a, b in plain:
+                    if any(a < hi and lo < b for lo, hi, *_ in prods):
+                        return None
+            plan = (self._tile_table(upd, slabs) if upd else None, self._tile_table(pack_only) if pack_only else None, plain,
                     self._pack_descs(rest, self.store.p) if rest else None)
-            self._fused_plans[key] = plan
+            self._fused_plans[pkey] = plan
         return plan
 
-    def adam_pack_ranges(self, ranges, step_offset=0):
+    def adam_pack_ranges(self, ranges, step_offset=0, slabs=False):
         """Adam + EMA on the element ranges AND the re-pack of every image sourced from them: the tile kernel on the weight
         matrices (one pass: 40 instead of 48 bytes per parameter), the plain optimiser kernel on what is left (biases), the
         plain pack kernel on images the tile kernel does not make.  Same bits as adam_ranges + pack_ranges."""
-        upd, pack_only, plain, rest = self._fused_update_plan(tuple(ranges))
+        upd, pack_only, plain, rest = self._fused_plans[(tuple(ranges), 'slabs')] if slabs else self._fused_update_plan(tuple(ranges))
         st, store = self.stream, self.store
         if plain:
             self.adam_ranges(plain, step_offset=step_offset)

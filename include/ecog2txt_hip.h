@@ -102,10 +102,18 @@ int e2t_decoder_tokens(const int32_t* y, int B, int L, int eos, int32_t* U, int3
 #define E2T_GEMM_ACCUMULATE 4      /* fp32 output only */
 #define E2T_GEMM_DROPOUT 8
 #define E2T_GEMM_SPLITK 16         /* split K over workgroups: partials in splitk_ws, fixed-order reduce which applies the epilogue */
+#define E2T_GEMM_KEEP_SLABS 64     /* ABI 8, K-major entry points, with slabs_out: a split product whose reduction has nothing between the sum and the
+                                      store (a weight gradient: alpha 1, fp32, no bias / mask / diverted column) is NOT reduced -- its slabs stay
+                                      in splitk_ws and *slabs_out says where: the optimiser kernel sums them as it reads the gradient
+                                      (e2t_adam_pack_batch), so C is never written and never read.  The workspace must then be the caller's to
+                                      keep until that kernel has run. */
 #define E2T_GEMM_LAST_ROW_ONES 32  /* ABI 8, e2t_gemm_tn_bf16 only: column M-1 of the K-major operand A is all ones (the ones column that turns
                                       [x | 1]^T . dG into weights + bias), so row M-1 of the product is the column sums of B.  A hint: where
                                       that row would cost a launch of its own (the ragged edge of a 256 x 256-tiled product) it is computed
                                       by a column-sum pass over B instead (fp32 sums in a fixed order; alpha and E2T_GEMM_ACCUMULATE apply) */
+/* ABI 8: where the partial sums of a split product were LEFT (E2T_GEMM_KEEP_SLABS): element (z, m, n) of the product is
+ * sum over s < splits of slab[(z * splits + s) * stride + m * N + n]; splits == 1: nothing was left, C holds the product. */
+typedef struct e2t_slab_info { const float* slab; int splits; int batch; long long stride; } e2t_slab_info;
 typedef struct e2t_gemm_epilogue {
     const float* bias;             /* [N] or NULL */
     const void* relu_bwd_src;      /* bf16 [M][ld]: out = src != 0 ? out : 0 (ReLU/dropout backward) */
@@ -127,6 +135,7 @@ typedef struct e2t_gemm_epilogue {
     long long a_batch_stride, b_batch_stride, c_batch_stride;
     int row_group;                 /* 0 / 1: output rows are (step, utterance) time-major; G > 1: grouped order of e2t_conv_pack_grouped --
                                       only the row_lens mask looks at it */
+    e2t_slab_info* slabs_out;      /* ABI 8, host pointer or NULL: filled by the K-major entry points when E2T_GEMM_KEEP_SLABS is set */
 } e2t_gemm_epilogue;
 int e2t_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const e2t_gemm_epilogue* ep /* host pointer or NULL */, void* stream);
@@ -330,6 +339,10 @@ typedef struct e2t_tile_desc {
     int R, C, nimg;
     long long src_off;   /* element offset of the sub-matrix's origin in the flat buffers */
     long long s0;        /* row stride in elements */
+    const float* gslab;  /* NULL: the gradient is g[src_off + r*s0 + c]; else it is the sum over s < gsplits, in that order, of
+                            gslab[s*gstride + r*s0 + c] -- the slabs a K-major product left (E2T_GEMM_KEEP_SLABS) */
+    long long gstride;
+    int gsplits, pad_;
     e2t_tile_img img[E2T_TILE_IMG_MAX];
 } e2t_tile_desc;
 /* h == NULL: images only, from `p` (any flat fp32 buffer: the masters or the EMA shadows); g, m, v, ema are then ignored.

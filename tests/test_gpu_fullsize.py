@@ -191,3 +191,47 @@ def test_long_run_at_full_size_has_no_in_kernel_timeouts():
     last = eng.losses(ws)
     assert not slow, slow
     assert np.isfinite(last['total']) and last['decoder'] < 0.5 * first, (first, last)
+
+
+@pytest.mark.parametrize('name', ['cfg2', 'cfg4'])
+def test_slabs_summed_by_the_optimiser_kernel_leave_the_bits_of_the_reduction(name):
+    """Round 5 (`fused_reduce`): in the captured single-GPU step the weight gradients of everything above the bottom layer are never
+    reduced -- the products leave their split-K slabs (E2T_GEMM_KEEP_SLABS) and `k_adam_pack` sums them, in split order, as it reads
+    the gradient.  At the configurations' own sizes (the small cases do not split K): a step with and without it leaves masters,
+    Adam moments and EMA shadows bit for bit the same, and two more steps agree to round-off (mocha-1_word_sequence.yaml:5, trainers.py:467-468)."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    kw, B, T, L = bench.CONFIGS[name]
+    batch = bench.synth_batch(kw, B, T, L, seed=4)
+    out = []
+    for fused in (True, False):
+        eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=7, options={'fused_reduce': fused})
+        eng.init_params(seed=0)
+        ws = eng.workspace(401, B, T, L)
+        eng.set_batch(ws, batch)
+        eng.train_step(ws)
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) == 0 and int(eng.step_t.item()) == 1
+        if fused:
+            plan = eng._fused_plans[next(k for k in eng._fused_plans if isinstance(k, tuple) and len(k) == 2 and k[1] == 'slabs')]
+            from ecog2txt_amd.hip_lib import TileDesc
+            raw = plan[0][0].cpu().numpy().tobytes()
+            descs = (TileDesc * plan[0][1]).from_buffer_copy(raw)
+            nslab = sum(1 for d in descs if d.gsplits > 1)
+            assert nslab >= 4, 'the case must exercise the slab path (%d descriptors read slabs)' % nslab
+        else:
+            assert not any(isinstance(k, tuple) and len(k) == 2 and k[1] == 'slabs' for k in eng._fused_plans)
+        st = eng.store
+        e0, e1 = st.seg_range('dec.emb')
+        keep = torch.ones(st.n, dtype=torch.bool, device='cuda'); keep[e0:e1] = False          # (embedding: fp32 atomics in any order)
+        first = [t[keep].clone() for t in (st.p, st.m, st.v, st.ema)]
+        for _ in range(2):                                     # (from the second step on the embedding's 1e-11 differences are everywhere)
+            eng.train_step(ws)
+        torch.cuda.synchronize()
+        out.append((first, [t.clone() for t in (st.p, st.ema)], eng.losses(ws)))
+        eng._ws.clear(); del eng, ws
+        torch.cuda.empty_cache()
+    for k, x, y in zip('pmve', out[0][0], out[1][0]):
+        assert torch.equal(x, y), k
+    for x, y in zip(out[0][1], out[1][1]):
+        torch.testing.assert_close(x, y, atol=2e-5, rtol=0)
+    assert out[0][2]['total'] == pytest.approx(out[1][2]['total'], rel=1e-4)
