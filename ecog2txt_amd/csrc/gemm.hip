@@ -1452,7 +1452,12 @@ extern "C" int e2t_gemm_tn_group_bf16(int n, const e2t_gemm_call* calls, void* s
             if (sp > 1) bytes += ((size_t)sp * g.p[i].M * g.p[i].N * g.p[i].batch * sizeof(float) + 255) / 256 * 256;
         }
         if (bytes > ep0->splitk_ws_bytes) continue;
-        if (items >= 300 || d == std::min(16, kmax)) { best_d = d; break; }
+        // (round 5: a group of fewer than 200 tiles -- the bottom layer's, which ends the step beside the HBM-bound optimiser update, and the
+        //  head's -- is cut for about 450 workgroups instead of 300: three K ranges per tile instead of two; cfg2 1.579 -> 1.569 ms over three
+        //  same-box pairs, the other configurations unchanged; 600 was slower again.  E2T_GROUP_FEW_TILES=0 switches it off.)
+        { static const int few = e2t_dbg_int("E2T_GROUP_FEW_TILES", 200), want = e2t_dbg_int("E2T_GROUP_FEW_ITEMS", 448);
+          long tt = 0; for (int i = 0; i < m; ++i) tt += tiles[i];
+          if (items >= ((few > 0 && tt < few) ? want : 300) || d == std::min(16, kmax)) { best_d = d; break; } }
     }
     if (forced_depth > 0) best_d = std::min(kmax, forced_depth);
     size_t off = 0;
