@@ -36,7 +36,7 @@ def r64(x):
 
 SHAPES = {
     'cfg2': [('dW_x (K-major)', 'tn', 801, 3200, 8704, 1), ('dW_h x2 (K-major)', 'tn', 400, 1600, 8704, 2),
-             ('dW dec (K-major)', 'tn', 800, 3200, 2560, 1), ('Gx (NT)', 'nt', 8704, 3200, 832, 1), ('dIn (NT)', 'nt', 8704, 832, 3200, 1),
+             ('dW dec (K-major)', 'tn', 800, 3200, 2560, 1), ('Gx (NT)', 'nt', 8704, 3200, 832, 1), ('Gx l0 (NT)', 'nt', 8704, 3200, 128, 1), ('dIn (NT)', 'nt', 8704, 832, 3200, 1),
              ('proj (NT)', 'nt', 2560, 1806, 832, 1), ('aux fwd (NT)', 'nt', 8704, 225, 832, 1), ('conv (NT)', 'nt', 8704, 100, 3136, 1),
              ('square 4096 (NT)', 'nt', 4096, 4096, 4096, 1), ('square 4096 (K-major)', 'tn', 4096, 4096, 4096, 1)],
     'cfg4': [('dW_x (K-major)', 'tn', 2049, 8192, 8704, 1), ('dW_x w/o bias row (K-major)', 'tn', 2048, 8192, 8704, 1),
