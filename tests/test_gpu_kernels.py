@@ -896,3 +896,40 @@ def test_adam_pack_skips_when_the_error_word_is_set(hl):
     hl.lib.e2t_adam_pack_batch(*args)
     torch.cuda.synchronize()
     assert not torch.equal(bufs[0], keep[0]) and torch.equal(img, bufs[0].view(64, 64).bfloat16())
+
+
+@pytest.mark.parametrize('M,N,K,nb', [(401, 1600, 8704, 2), (801, 3200, 8704, 1), (1024, 4096, 8704, 2)])
+def test_gemm_tn_keep_slabs_sum_to_the_reduced_product(hl, M, N, K, nb):
+    """E2T_GEMM_KEEP_SLABS (ABI 8): a split K-major product whose reduction would be plain leaves its slabs and says where
+    (e2t_slab_info); their sum in split order is, bit for bit, what the same call writes to C without the flag.  A product that
+    does not qualify (here: alpha != 1) is reduced as ever and reports splits = 1."""
+    rng = np.random.default_rng(M + N)
+    lda, ldb = nb * r8(M) + 8, nb * r8(N)
+    a, b = dev_bf16(rng.standard_normal((K, lda))), dev_bf16(rng.standard_normal((K, ldb)))
+    wsb = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device='cuda')
+
+    def call(flags, alpha=1.0):
+        ep = hl.GemmEpilogue(); ep.alpha = alpha
+        ep.flags = hl.GEMM_SPLITK | flags
+        ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        if nb > 1:
+            ep.batch, ep.a_batch_stride, ep.b_batch_stride, ep.c_batch_stride = nb, r8(M), r8(N), M * N
+        info = hl.SlabInfo()
+        ep.slabs_out = C.pointer(info)
+        c = torch.full((nb, M, N), 7.0, dtype=torch.float32, device='cuda')
+        hl.lib.e2t_gemm_tn_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), N, M, N, K, C.byref(ep), st())
+        torch.cuda.synchronize()
+        return c, info
+    want, info0 = call(0)
+    assert info0.splits == 1 and not info0.slab
+    c, info = call(hl.GEMM_KEEP_SLABS)
+    assert info.splits >= 2 and info.batch == nb and info.stride == M * N, (info.splits, info.batch, info.stride)
+    assert bool((c == 7.0).all())                                             # C was not touched
+    off = (info.slab - wsb.data_ptr()) // 4
+    slabs = wsb[off:off + nb * info.splits * M * N].view(nb, info.splits, M, N)
+    acc = slabs[:, 0].clone()
+    for s in range(1, info.splits):
+        acc += slabs[:, s]
+    assert torch.equal(acc, want)
+    c2, info2 = call(hl.GEMM_KEEP_SLABS, alpha=0.5)
+    assert info2.splits == 1 and torch.equal(c2, 0.5 * want)
