@@ -217,7 +217,6 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             keep_info = H.SlabInfo()
             ep.slabs_out = C.pointer(keep_info)
             flags |= H.GEMM_KEEP_SLABS
-            wsb = self._group_arena if self._group is not None else self._next_arena()
         ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
         if drop is not None and drop[0] > 0:
             flags |= H.GEMM_DROPOUT
@@ -229,7 +228,15 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             ep.row_lens, ep.rows_per_step = row_lens
             ep.row_group = row_group
         ep.flags = flags
-        if self._group is not None and tn and splitk and self._plan_tile(tn, M, N, K, ep) != 256:
+        to_group = self._group is not None and tn and splitk and self._plan_tile(tn, M, N, K, ep) != 256
+        if keep_info is not None and not to_group:
+            # a kept product that keeps a launch of its OWN (the 256 x 256 instance, or no group open) gets an arena of its own:
+            # the group's arena is dealt from offset 0 by the grouped launch at the end of the stage, and two launches must never
+            # share slab space before the fused optimiser kernel has read it (every arena has the workspace's size, so
+            # the launch plan is the same)
+            wsb = self._next_arena()
+            ep.splitk_ws, ep.splitk_ws_bytes = wsb.data_ptr(), wsb.numel() * 4
+        if to_group:
             # inside `with self.gemm_group():` -- the K-major weight-gradient products of a stage leave in ONE launch.  (A
             # product large enough for the 256 x 256 instance -- H = 1024: 2049 x 8192 x 8704 -- keeps its own launch: the
             # grouped kernel works on 128 x 128 tiles, half the flops per staged byte; cfg4 9.49 -> 9.19 ms.)
@@ -262,6 +269,10 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         if off % 64 or (nb > 1 and cbs != M * N):
             return False
         return any(a <= off and off + nb * M * N <= b for a, b in self._keep_slabs)
+
+    @staticmethod
+    def _slab_sig(log):
+        return tuple(sorted((e['off'], e['M'], e['N'], e['batch'], e['slab'], e['splits'], e['stride']) for e in log))
 
     def _next_arena(self):
         i = self._arena_seq
@@ -1320,7 +1331,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                     finally:
                         if not slab_mode[0]:
                             self._keep_slabs = None
-            self._pack_subtable(('skip',) + tuple(packed_early))
+        probe_sig = self._slab_sig(self._slab_log) if slab_mode[0] else None
         tail = [(max(a, early_end), b) for a, b in tr if b > early_end]
 
         def exchange(ranges):
@@ -1335,6 +1346,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 sync.join()
             self.adam_ranges(tail, step_offset=1)
         try:
+            if packed_early:
+                self._pack_subtable(('skip',) + tuple(packed_early))
+            self._slab_log = []
             with capture(g1):
                 if dp:
                     sync.attach()
@@ -1342,8 +1356,19 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 self.backward(ws, train=True, early=early, before_join=tail_update, exchange=exchange if dp else None,
                               after_last_rec=(lambda: sync.allreduce_flag(self.sync_err[0:1])) if dp else None)
                 lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
+            diverged = probe_sig is not None and self._slab_sig(self._slab_log) != probe_sig
         finally:
+            # (whatever happens between the probe and the end of the capture: no later eager backward() runs without its reductions)
             self._keep_slabs = None
+        if diverged:
+            # the capture did not leave the slabs where the probe pass did (the descriptors k_adam_pack reads were built from the
+            # probe's addresses): that graph must never be replayed -- capture again with the reductions in place
+            self._keep_slabs = None
+            prev, self.options['fused_reduce'] = self.options['fused_reduce'], False
+            try:
+                return self._capture_step(ws, sync, gc)
+            finally:
+                self.options['fused_reduce'] = prev
         if dp:
             sync.pending_ranges = []                  # (tickets recorded during a capture mean nothing outside it)
             sync._flag_pending = False

@@ -156,6 +156,12 @@ class PackingMixin:
                 for z in range(e['batch']):
                     lo = e['off'] + z * e['M'] * e['N']
                     prods.append((lo, lo + e['M'] * e['N'], e['slab'] + 4 * z * e['splits'] * e['stride'], e['stride'], e['splits'], e['N']))
+            # two kept products must never share slab space (each launch has an arena of its own: engine.gemm); should a launcher
+            # ever hand out overlapping extents the scheme is off for this capture (reductions as ever) rather than silently wrong
+            ext = sorted((pr[2], pr[2] + 4 * pr[4] * pr[3]) for pr in prods)
+            if any(ext[i][1] > ext[i + 1][0] for i in range(len(ext) - 1)):
+                self._fused_plans.pop(pkey, None)
+                return None
             idx = np.flatnonzero(np.diff(np.concatenate([[0], left.view(np.int8), [0]])))
             cuts = sorted({x for lo, hi, *_ in prods for x in (lo, hi)})
             plain = []

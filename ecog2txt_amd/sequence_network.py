@@ -11,6 +11,7 @@ All device work goes through ecog2txt_amd.engine (hand-written HIP kernels); hos
 data staging, the epoch loop, metrics and checkpoint files."""
 import os
 import re
+import time
 
 import numpy as np
 
@@ -599,9 +600,20 @@ class SequenceNetwork:
             arrays['__step'] = eng.step_t.cpu().numpy()
             ckdir = os.path.dirname(self.checkpoint_path) or '.'
             os.makedirs(ckdir, exist_ok=True)
+            from . import tf_checkpoint
             for f in os.listdir(ckdir):                        # temporaries a crashed writer left behind -- not those of a LIVE
-                m = re.match(r'\.tmp-(\d+)-', f)               # process writing into the same directory (another fit or assessment)
-                if m and (int(m.group(1)) == os.getpid() or not _pid_alive(int(m.group(1)))):
+                m = re.match(r'\.tmp-(\d+)-(?:h([0-9a-f]{8})-)?', f)     # process writing into the same directory (another fit or assessment)
+                if not m:
+                    continue
+                if m.group(2) is not None and m.group(2) != tf_checkpoint.host_tag():
+                    # another HOST's writer (shared file system): its process id says nothing here -- reaped by age only
+                    try:
+                        stale = time.time() - os.path.getmtime(os.path.join(ckdir, f)) > 3600.0
+                    except OSError:
+                        continue
+                else:
+                    stale = int(m.group(1)) == os.getpid() or not _pid_alive(int(m.group(1)))
+                if stale:
                     try:
                         os.remove(os.path.join(ckdir, f))
                     except OSError:
@@ -609,13 +621,12 @@ class SequenceNetwork:
             # written under temporary names and moved into place (os.replace is atomic): a reader never sees a partial file;
             # the names start with '.tmp-', which the trainer's restore scan ('model.ckpt-<epoch>.index') cannot match
             final = self._ckpt(epoch)
-            tmp = os.path.join(ckdir, '.tmp-%d-' % os.getpid() + os.path.basename(final))
+            tmp = os.path.join(ckdir, tf_checkpoint.temp_prefix() + os.path.basename(final))
             np.savez(tmp + '.npz', **arrays)
             os.replace(tmp + '.npz', final + '.npz')
             # the same variables (weights + EMA shadows, reference naming grammar) as a TensorFlow V2 checkpoint:
             # `model.ckpt-<epoch>.index` is what the trainer's restore_epoch scan looks for (trainers.py:235-252), and the
             # pair is readable by TF's own checkpoint reader (recover_model_sizes, trainers.py:444-554)
-            from . import tf_checkpoint
             tf_checkpoint.write_checkpoint(final, {k: v for k, v in arrays.items() if not k.startswith('__')})
         finally:
             # (the barrier is reached whatever happened above: the other ranks are waiting in theirs; the error is re-raised)

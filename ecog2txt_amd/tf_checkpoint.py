@@ -332,6 +332,19 @@ def list_variables(prefix, with_dtype=False):
     return out
 
 
+def host_tag():
+    """8 hex digits naming this host (CRC-32 of its node name): a process id means something on ITS host only."""
+    import platform
+    import zlib
+    return '%08x' % (zlib.crc32(platform.node().encode('utf-8')) & 0xFFFFFFFF)
+
+
+def temp_prefix():
+    """Name prefix of a checkpoint writer's temporaries: '.tmp-<pid>-h<host tag>-' (SequenceNetwork._save reaps what crashed
+    writers left: by process id on the same host, by age for names that carry another host's tag -- a shared file system)."""
+    return '.tmp-%d-h%s-' % (os.getpid(), host_tag())
+
+
 def write_checkpoint(prefix, arrays):
     """Write {name: ndarray} as a single-shard TF V2 checkpoint (`<prefix>.index`, `<prefix>.data-00000-of-00001`)."""
     items = []
@@ -342,7 +355,7 @@ def write_checkpoint(prefix, arrays):
     # (temporary names start with '.tmp-': the trainer's restore scan keys on names that START with 'model.ckpt-' and end in
     #  '.index' -- a temporary index left behind by a crash must not look like a finished epoch)
     final_prefix = prefix
-    prefix = os.path.join(os.path.dirname(prefix), '.tmp-%d-' % os.getpid() + os.path.basename(prefix))
+    prefix = os.path.join(os.path.dirname(prefix), temp_prefix() + os.path.basename(prefix))
     with open(_shard_name(prefix, 0, 1), 'wb') as f:
         for name in sorted(arrays, key=lambda s: s.encode('utf-8')):
             a = np.asarray(arrays[name], order='C')              # (ascontiguousarray would turn a scalar into shape (1,))

@@ -140,46 +140,185 @@ def test_full_graph_against_torch_cpu(name, B):
         ['%s cos %.5f ratio %.4f' % (k, c, r) for c, r, k in worst[:4]]))
 
 
-@pytest.mark.parametrize('train', [False, True], ids=['dropout_off', 'dropout_on'])
-def test_cfg2_graph_against_bf16_emulating_oracle(train):
-    """The same cfg2 graph (3 x 400 bidirectional, decoder 800, V = 1806, T = 400 -> 34 steps, K = 3072 conv) at B = 16 against the
-    NumPy oracle with the device's rounding points: the tight tolerances of test_gpu_parity.py.  train=True: FF dropout 0.1 and
-    RNN dropout 0.5 on, Philox masks on both sides."""
+def _rl2(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-12))
+
+
+def _check_against_oracle(tag, losses, G, want, WG, XG, train, report):
+    """Losses and every gradient tensor of one forward / backward pass of the HIP path against the bf16-emulating oracle (WG) at
+    the tolerances of tests/test_gpu_parity.py.  XG (dropout-on legs) = the oracle's gradients in its EXACT fp64 mode: the
+    yardstick of the relative criterion."""
     from test_gpu_parity import check_grad, relu_class, LOSS_RTOL
-    from ecog2txt_amd.engine import NetSpec
-    kw, _, T, L = bench.CONFIGS['cfg2']
-    B = 16
-    ospec = O.NetSpec(**NetSpec(**kw).as_dict())
-    P = _biases_off_zero(O.init_params(ospec, seed=5), 6)
-    batch = bench.synth_batch(kw, B, T, L, seed=9)
-    _ragged(batch, T, 200, seed=2)
-    eng, ws, losses, logits, G = _hip(kw, B, T, L, batch, P, train=train)
-    want, cache = O.forward(P, ospec, batch, train=train, seed=5, emulate_bf16=True)
     for k in ('decoder', 'aux'):
-        assert abs(losses[k] - want[k]) <= LOSS_RTOL * max(1.0, abs(want[k])), (k, losses, want)
-    np.testing.assert_array_equal(ws['lens'].cpu().numpy(), cache['lens'])
-    np.testing.assert_allclose(logits, cache['dec']['logits'], atol=3e-2, rtol=1e-2)
-    WG = O.backward(P, cache)
-    if train:
-        # the oracle's own distance between its bf16 mode and the exact fp64 spec: the yardstick of the dropout-on leg
-        _, cache_x = O.forward(P, ospec, batch, train=True, seed=5, emulate_bf16=False)
-        XG = O.backward(P, cache_x)
-    rl2 = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-12))
+        if k in want:
+            assert abs(losses[k] - want[k]) <= LOSS_RTOL * max(1.0, abs(want[k])), (tag, k, losses, want)
     for k in sorted(WG):
-        # 54 400 conv activations here (16 utterances x 34 steps x 100 units) against ~2 000 in the small cases: a few units sit
+        # 54 400 conv activations at cfg2 (16 utterances x 34 steps x 100 units) against ~2 000 in the small cases: a few units sit
         # on the ReLU knife edge, each moving one column (1 %) of the conv weight gradient
         # ... and 1.7 M input projections per layer are rounded to bf16 (544 per bias element): two or three entries of a 1600-entry
         # bias gradient beyond 5e-3 (measured 6.3e-3 at most)
+        worst = float(np.abs(G[k] - WG[k]).max() / (np.abs(WG[k]).max() + 1e-12))
+        report.append((worst, _rl2(G[k], WG[k]), tag, k))
         if not train:
             check_grad(k, G[k], WG[k], relu_outliers=4e-2, flip_outliers=3e-3)
             continue
         # dropout on (scripts/diag_fullsize_dropout.py): every kept activation carries 1 / keep = 2x, so a 1-ulp bf16 flip or a
         # flipped ReLU unit of the 225-wide auxiliary layer weighs twice as much in everything below the tapped layer, and the
-        # share of entries beyond a fixed 5e-3 grows with it.  No outlier allowance is made for that (round 5): THE assertion is
-        # relative to the oracle's own band -- the HIP path must be CLOSER to the bf16-emulating oracle than 0.6 of that oracle's
-        # distance from the exact fp64 spec (measured: 0.2 .. 0.46) -- plus the hard ceilings of test_gpu_parity.py on the single
-        # worst entry (2e-2 of the tensor's maximum; 5e-2 behind a ReLU mask of the tensor's own layer)
-        band = rl2(XG[k], WG[k])
-        assert rl2(G[k], WG[k]) <= max(0.6 * band, 2e-3), (k, rl2(G[k], WG[k]), band)
-        worst = float(np.abs(G[k] - WG[k]).max() / (np.abs(WG[k]).max() + 1e-12))
-        assert worst < (5e-2 if relu_class(k) else 2e-2), (k, worst)
+        # share of entries beyond a fixed 5e-3 grows with it.  THE assertion is relative to the oracle's own band -- the HIP path
+        # must be CLOSER to the bf16-emulating oracle than 0.6 of that oracle's distance from the exact fp64 spec (measured:
+        # 0.2 .. 0.46) -- plus the hard ceilings of test_gpu_parity.py on the single worst entry (2e-2 of the tensor's maximum;
+        # 5e-2 behind a ReLU mask of the tensor's own layer) ...
+        band = _rl2(XG[k], WG[k])
+        assert _rl2(G[k], WG[k]) <= max(0.6 * band, 2e-3), (tag, k, _rl2(G[k], WG[k]), band)
+        assert worst < (5e-2 if relu_class(k) else 2e-2), (tag, k, worst)
+        # ... AND the element-wise outlier shares (ADVICE r5: a shift of many entries by a few 1e-3 that stays inside the band
+        # must not pass): at most 10 % (ReLU class) / 3 % of a tensor's entries beyond 5e-3 of its maximum, relative L2 < 1.5e-2
+        check_grad(k, G[k], WG[k], relu_outliers=1e-1, flip_outliers=3e-2, l2_scale=1.5)
+
+
+def _print_worst(title, report, n=5):
+    report.sort(reverse=True)
+    print('\n%s -- worst tensors (max error / max |g|, relative L2):' % title)
+    for worst, rel, tag, k in report[:n]:
+        print('  %-8s %-66s %.2e  %.2e' % (tag, k, worst, rel))
+
+
+# the REAL graph of every BASELINE configuration against the oracle with the device's rounding points (VERDICT r5 item 1):
+#   cfg2  3 x 400 bidirectional, decoder 800, V = 1806, T = 400 -> 34 sweeps, K = 3072 conv                           B = 16
+#   cfg4  4 x lstm_big (H = 1024), 256 x 256 K-major products, k_colsum_bf16 bias rows, launch-per-step decoder 2048   B = 16
+#   cfg5  1024 electrodes x 2000 samples: S = 167 persistent sweeps, K = 12 288, the ONE-PASS front-end the engine picks at
+#         B = 256 (forced here: fused_conv='1'), and the bf16-staged input form                                        B = 8
+ORACLE_LEGS = {
+    'cfg2': ('cfg2', 16, 200, None, None),
+    'cfg4': ('cfg4', 16, 200, None, None),
+    'cfg5_one_pass_frontend': ('cfg5', 8, 1200, {'fused_conv': '1'}, None),
+    'cfg5_bf16_staged': ('cfg5', 8, 1200, None, _stage_bf16),
+}
+
+
+@pytest.mark.parametrize('train', [False, True], ids=['dropout_off', 'dropout_on'])
+@pytest.mark.parametrize('leg', list(ORACLE_LEGS))
+def test_real_graph_against_bf16_emulating_oracle(leg, train):
+    """The graphs of BASELINE.json's configurations at a batch the NumPy oracle finishes in a minute, against that oracle with
+    the device's rounding points: the tight tolerances of test_gpu_parity.py (losses 2e-4, gradients 5e-3 of the tensor's
+    maximum, lengths equal, logits 3e-2).  train=True: FF dropout 0.1 and RNN dropout 0.5 on, Philox masks on both sides.
+    Kernel shapes: trainers.py:527-541; sizes: mocha-1_word_sequence.yaml:57-61."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    name, B, lo, options, prepare = ORACLE_LEGS[leg]
+    kw, _, T, L = bench.CONFIGS[name]
+    ospec = O.NetSpec(**NetSpec(**kw).as_dict())
+    P = _biases_off_zero(O.init_params(ospec, seed=5), 6)
+    batch = bench.synth_batch(kw, B, T, L, seed=9)
+    _ragged(batch, T, lo, seed=2)
+    eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=5, options=options)
+    eng.load_params(P)
+    ws = eng.workspace(401, B, T, L)
+    eng.set_batch(ws, batch)
+    if prepare is not None:
+        prepare(eng, ws)
+    eng.forward(ws, train=train)
+    if leg == 'cfg5_one_pass_frontend':
+        assert bool(ws['A_stale']) is (not train) and not ws.get('packed')    # e2t_conv_fwd_fused ran (inference leaves no im2row copy)
+    if prepare is not None:
+        assert ws['packed'] and torch.isnan(ws['X']).all()
+    eng.backward(ws, train=train)
+    torch.cuda.synchronize()
+    assert int(eng.sync_err[0].item()) == 0
+    losses = eng.losses(ws)
+    logits = ws['proj']['out'].float().cpu().numpy().reshape(L, B, -1)
+    G = eng.store.export_tf('g')
+    want, cache = O.forward(P, ospec, batch, train=train, seed=5, emulate_bf16=True)
+    np.testing.assert_array_equal(ws['lens'].cpu().numpy(), cache['lens'])
+    np.testing.assert_allclose(logits, cache['dec']['logits'], atol=3e-2, rtol=1e-2)
+    WG = O.backward(P, cache)
+    XG = None
+    if train:
+        # the oracle's own distance between its bf16 mode and the exact fp64 spec: the yardstick of the dropout-on leg
+        _, cache_x = O.forward(P, ospec, batch, train=True, seed=5, emulate_bf16=False)
+        XG = O.backward(P, cache_x)
+    report = []
+    _check_against_oracle(leg, losses, G, want, WG, XG, train, report)
+    _print_worst('%s B=%d dropout %s: losses hip %s oracle %s' % (
+        leg, B, 'on' if train else 'off', {k: round(v, 6) for k, v in losses.items() if k in want},
+        {k: round(float(v), 6) for k, v in want.items() if k in ('decoder', 'aux')}), report)
+
+
+def test_cfg3_round_robin_round_against_bf16_emulating_oracle():
+    """cfg3's single-GPU half at FULL widths (BASELINE.json configs[2]; grids 16x16 / 16x16 / 8x16 / 16x16:
+    mochastar_word_sequence.yaml:57-59, 150-152, 243-245, 336-338; per-subject front-ends trainers.py:801-818): one round-robin
+    round over the four participants at B = 16 with dropout on and Adam + EMA between the steps.  Every step: losses and all
+    gradients (the participant's own front-end included) against the bf16-emulating oracle evaluated at the ORACLE's trajectory;
+    afterwards parameters and EMA shadows of the round.  Then one more round replayed from the captured graphs (one per
+    participant) -- the trajectory still follows."""
+    from ecog2txt_amd.engine import Seq2SeqEngine, NetSpec
+    from test_gpu_parity import relu_class
+    kw, _, T, L = bench.CONFIGS['cfg3']
+    B, lr = 16, 5e-4
+    spec = NetSpec(**kw)
+    ospec = O.NetSpec(**spec.as_dict())
+    P = _biases_off_zero(O.init_params(ospec, seed=5), 6)
+    eng = Seq2SeqEngine(spec, device='cuda:0', seed=11, lr=lr)
+    eng.load_params(P)
+    batches, wss = {}, {}
+    for i, sid in enumerate(kw['channels']):
+        kw1 = dict(kw, channels={sid: kw['channels'][sid]})
+        batches[sid] = bench.synth_batch(kw1, B, T, L, seed=20 + i)
+        _ragged(batches[sid], T, 200, seed=30 + i)
+        wss[sid] = eng.workspace(sid, B, T, L)
+        eng.set_batch(wss[sid], batches[sid])
+    Po = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in P.items()}     # the device's fp32 masters
+    state, step, report = {}, 0, []
+    for sid in kw['channels']:
+        ws = wss[sid]
+        # (exactly train_step(use_graph=False), with the gradient read out in between)
+        eng.forward(ws, train=True)
+        eng.backward(ws, train=True)
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) == 0
+        losses, G = eng.losses(ws), eng.store.export_tf('g')
+        # the oracle at the DEVICE's current masters: each step's gradient comparison stands on its own (the trajectory legs
+        # below carry the accumulated difference)
+        Pd = {k: np.asarray(v, np.float64) for k, v in eng.store.export_tf('p').items()}
+        want, cache = O.forward(Pd, ospec, batches[sid], train=True, seed=11 + step, emulate_bf16=True)
+        WG = O.backward(Pd, cache)
+        _, cache_x = O.forward(Pd, ospec, batches[sid], train=True, seed=11 + step, emulate_bf16=False)
+        XG = O.backward(Pd, cache_x)
+        own = O.conv_name(ospec, sid) + '/weights'      # (the oracle returns the stepping participant's front-end only)
+        assert own in WG and np.abs(WG[own]).max() > 0 and sum('subnet_' in k for k in WG) == 2
+        _check_against_oracle('sid %s' % sid, losses, G, want, WG, XG, True, report)
+        eng.adam_step(sid)
+        # the oracle's own trajectory
+        _, c2 = O.forward(Po, ospec, batches[sid], train=True, seed=11 + step, emulate_bf16=True)
+        Po, state = O.adam_ema_step(Po, O.backward(Po, c2), state, lr=lr)
+        step += 1
+    _print_worst('cfg3 B=%d, one round over 4 participants, dropout on' % B, report)
+
+    def follows(nsteps):
+        torch.cuda.synchronize()
+        assert int(eng.sync_err[0].item()) == 0 and int(eng.step_t.item()) == nsteps
+        Pd, Ed = eng.store.export_tf('p'), eng.store.export_tf('ema')
+        for k in Po:
+            err = np.abs(Pd[k] - Po[k])
+            relu = relu_class(k)
+            # (the bands of tests/test_gpu_decode_fullsize.py::test_cfg2_three_adam_ema_steps_follow_the_oracle: Adam normalises every
+            #  coordinate's step to ~lr; a coordinate whose gradient is within round-off of zero may step the other way)
+            nflip = int((err > 3 * lr * 0.35).sum())
+            assert nflip <= max(5, (2e-2 if relu else 5e-3) * err.size), (k, float(err.max()), nflip, err.size)
+            assert err.max() <= 2.0 * nsteps * lr * 1.01, (k, float(err.max()))
+            disp = Po[k] - np.asarray(P[k], np.float32)
+            if np.linalg.norm(disp) > 0:
+                assert np.linalg.norm(Pd[k] - Po[k]) / np.linalg.norm(disp) < (0.17 if relu else 0.12), k
+            assert np.abs(Ed[k] - state['ema'][k]).max() < 1e-4, k
+    follows(4)
+    # a participant's front-end moved on its own step only: three of the four steps left it alone -- it is one Adam step from P
+    for sid in kw['channels']:
+        k = O.conv_name(ospec, sid) + '/weights'
+        d = np.abs(eng.store.export_tf('p')[k] - np.asarray(P[k], np.float32))
+        assert 0 < d.max() <= lr * 1.01, (sid, float(d.max()))
+    # second round: captured graphs, one per participant
+    for sid in kw['channels']:
+        eng.train_step(wss[sid], use_graph=True)
+        _, c2 = O.forward(Po, ospec, batches[sid], train=True, seed=11 + step, emulate_bf16=True)
+        Po, state = O.adam_ema_step(Po, O.backward(Po, c2), state, lr=lr)
+        step += 1
+    follows(8)

@@ -2,6 +2,7 @@
 written files, round trips; no TensorFlow needed (and none is available to cross-read)."""
 import os
 import struct
+import time
 
 import numpy as np
 import pytest
@@ -178,13 +179,20 @@ def test_save_removes_a_dead_writers_temporaries_and_leaves_a_live_writers_alone
     live = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)'])
     try:
         names = {'dead': '.tmp-%d-model.ckpt-7.npz' % gone.pid, 'live': '.tmp-%d-model.ckpt-8.npz' % live.pid,
-                 'own': '.tmp-%d-model.ckpt-1.npz' % os.getpid(), 'other': 'notes.txt'}
+                 'own': '.tmp-%d-model.ckpt-1.npz' % os.getpid(), 'other': 'notes.txt',
+                 # host-tagged names (what the writers use): this host's by process id, another host's by age only -- a live
+                 # writer on another node of a shared file system looks dead from here
+                 'dead_here': '.tmp-%d-h%s-model.ckpt-7.index' % (gone.pid, T.host_tag()),
+                 'elsewhere_fresh': '.tmp-%d-h%s-model.ckpt-9.npz' % (gone.pid, 'f' * 8 if T.host_tag() != 'f' * 8 else '0' * 8),
+                 'elsewhere_old': '.tmp-%d-h%s-model.ckpt-6.npz' % (gone.pid, 'f' * 8 if T.host_tag() != 'f' * 8 else '0' * 8)}
         for f in names.values():
             (tmp_path / f).write_bytes(b'x')
+        old = time.time() - 7200
+        os.utime(tmp_path / names['elsewhere_old'], (old, old))
         net._save(eng, 3)
         left = set(os.listdir(tmp_path))
-        assert names['live'] in left and names['other'] in left
-        assert names['dead'] not in left and names['own'] not in left
+        assert names['live'] in left and names['other'] in left and names['elsewhere_fresh'] in left
+        assert names['dead'] not in left and names['own'] not in left and names['dead_here'] not in left and names['elsewhere_old'] not in left
         assert 'model.ckpt-3.index' in left and 'model.ckpt-3.npz' in left
     finally:
         live.kill()
