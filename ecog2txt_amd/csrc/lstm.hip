@@ -251,7 +251,13 @@ struct LstmFwdArgs {
     DropCfg drop;
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
     int gx_nt;              // persistent kernels: prefetch Gx with the non-temporal policy (set by the launcher for long sequences)
+    int dbgv;               // diagnostics build only (E2T_REC_VARIANT): timing experiments that SKIP parts of the side work
 };
+#ifdef E2T_DEBUG
+#define E2T_DBGV(p) ((p).dbgv)
+#else
+#define E2T_DBGV(p) 0
+#endif
 
 __global__ __launch_bounds__(512) void k_lstm_step_fwd(LstmFwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -432,7 +438,14 @@ struct LstmPersistArgs {
 };
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int KB>        // k-blocks of 32 over H8: compile-time, so every fragment sits in a fixed register
+// DEFER (round 6 experiment, diagnostics build only -- MEASURED AND REJECTED): the dropped copy of step s (Philox mask + store) is made
+// at step s+1, its Philox evaluation (336 cycles per wave, scripts/probes/philox_probe.hip) UNDER the state loads of step s+1 instead
+// of in front of them.  Same arithmetic, same bits.  Phase stamps (profiles/r06_rec_sidework_probe.txt): the mask does hide under the
+// loads (state landed 0.72 vs 0.68 us, no retries) and the side phase shrinks 0.6 -> 0.4 us, but the pending store in front of the
+// MFMAs lengthens that phase 0.56 -> 0.80: 2.44 vs 2.36 us from step top to step bottom, 2.81 vs 2.70 us per step by the clock, the
+// cfg2 train step 1.671 vs 1.562 ms.  (What the side work in front of the loads does buy: with NOTHING between the exchange store and
+// the loads the first attempt always finds stale stamps and pays a second round trip -- 2.94 us per step.)
+template <int KB, bool DEFER>        // k-blocks of 32 over H8: compile-time, so every fragment sits in a fixed register
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa) {
     const LstmFwdArgs& p = pa.a;
     const int lane = threadIdx.x & 63;
@@ -504,6 +517,19 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
     const long long t_entry = p.dbg ? wall_clock64() : 0;
 #define PSTAMP(i) do { if (p.dbg && s == S / 2) pts[i] = wall_clock64(); } while (0)      // 100 MHz, chip-wide
 
+    // DEFER: the previous step's h (fp32, before the mask), where its dropped copy goes, and whether there is one to make
+    float hvp[4] = {0.f, 0.f, 0.f, 0.f};
+    size_t ydp_off = 0;
+    unsigned long long ctrp = 0ull;          // Philox counter of the lane's 4-unit group (logical element index / 4)
+    int prev = 0;                            // 0 nothing pending, 1 an active cell (mask), 2 a padded position (zeros)
+    const unsigned dthresh = (unsigned)(p.drop.rate * 16777216.0f);
+    const float dkeep = 1.0f / (1.0f - p.drop.rate);
+    const bool masked = DEFER && p.Ydrop && p.drop.rate > 0.f;          // wave-uniform
+    auto ydrop_put = [&](const float (&sc)[4]) {                          // the pending dropped copy (after the state has landed)
+        if (prev == 1) nt_store_bf4(p.Ydrop + ydp_off, f2bf(hvp[0] * sc[0]), f2bf(hvp[1] * sc[1]), f2bf(hvp[2] * sc[2]), f2bf(hvp[3] * sc[3]));
+        else if (prev == 2) *(unsigned long long*)(p.Ydrop + ydp_off) = 0ull;
+    };
+
     for (int s = 0; s < S; ++s) {
         PSTAMP(0);
         // ---- h_{t-1} fragments of this lane's utterance (MFMA B operand: k = kb*32 + fq*8 .. +8) ----
@@ -511,6 +537,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         const int t = dir ? (len - 1 - s) : s;
         u32x4 st[KB];
         f32x4 acc[2][4];
+        float dscp[4] = {1.f, 1.f, 1.f, 1.f};
         {
             if (s == 0) {
                 // initial state from the row-major array: block 0 (forward), the all-zero slack block S+1 (backward);
@@ -533,13 +560,25 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                 const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
                 int spins = 0;
                 for (;;) {
-                    // NOTHING may sit between the issue and the wait, and the loads stay inline (not in a lambda): a copy of a
-                    // load destination taken while the load is in flight is garbage -- hipcc makes such copies when it parks
-                    // registers in AGPRs or gives a by-reference capture a home (seen: stale stamps, timeout).  Moving the
-                    // Philox mask in front of the MFMAs was measured too: +0.2 us on the MFMA phase, more retries, slower.
+                    // NOTHING that touches the load destinations may sit between the issue and the wait, and the loads stay inline
+                    // (not in a lambda): a copy of a load destination taken while the load is in flight is garbage -- hipcc makes
+                    // such copies when it parks registers in AGPRs or gives a by-reference capture a home (seen: stale stamps,
+                    // timeout; scripts/check_inflight_regs.py walks the ISA for them).  Moving the Philox mask in front of the MFMAs
+                    // was measured too: +0.2 us on the MFMA phase, more retries, slower.
     #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)     // the immediate offset field is 13-bit signed: one base per 4 k-blocks
                         asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
+                    if (masked && spins == 0) {
+                        // DEFER: the previous step's Philox mask, pure VALU on registers of its own, while the state is on its way
+                        // (the counter is pinned behind the issue, the result in front of the wait: hipcc may not move it out)
+                        unsigned clo = (unsigned)ctrp, chi = (unsigned)(ctrp >> 32);
+                        asm volatile("" : "+v"(clo), "+v"(chi));
+                        unsigned r[4];
+                        philox4x32_10(clo, chi, p.drop.stream, 0u, (unsigned)key, (unsigned)(key >> 32), r);
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) dscp[i] = (r[i] >> 8) >= dthresh ? dkeep : 0.0f;
+                        asm volatile("" :: "v"(dscp[0]), "v"(dscp[1]), "v"(dscp[2]), "v"(dscp[3]));
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));     // uses stay behind the wait
@@ -574,6 +613,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             }
             PSTAMP(2);
             if (s + 2 < S) gx_load(s + 2);
+            if (DEFER && p.Ydrop && own) ydrop_put(dscp);
 
     #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -622,7 +662,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         PSTAMP(4);
         PSTAMP(5);
         // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
-        if (own) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
+        const int dv = E2T_DBGV(p);      // (0 in the product build: folds away)
+        if (own && !(dv & 8)) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
             const size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
             *(unsigned long long*)(p.Yext + (blk * B + b) * p.ldy + dir * p.H8 + u0) = hb;
         }
@@ -630,6 +671,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             if (active) {
                 const size_t m = (size_t)t * B + b;
                 const size_t tile = native_tile(s, dir, rt, ut, p.ndir, RT, p.UT);
+                if (!(dv & 2)) {
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
                     const uint2 a = gates_pack(gi[2 * rp], gj[2 * rp], gf[2 * rp], go[2 * rp]), c = gates_pack(gi[2 * rp + 1], gj[2 * rp + 1], gf[2 * rp + 1], go[2 * rp + 1]);
@@ -637,12 +679,21 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                 }
                 nt_store_f2(p.Cs + ((tile * 2 + 0) * 64 + lane) * 2, cst[0], cst[1]);
                 nt_store_f2(p.Cs + ((tile * 2 + 1) * 64 + lane) * 2, cst[2], cst[3]);
-                if (p.Ydrop) {
+                }
+                if (DEFER && p.Ydrop) {
+                    // made at the next step, its Philox evaluation under that step's state loads (the launcher requires H % 8 == 0
+                    // and u0 is a multiple of 4: the lane's 4 elements always share one counter)
+                    prev = 1; ydp_off = m * p.ldy + dir * p.H8 + u0; ctrp = (m * NH + dir * H + u0) >> 2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hvp[r] = hv[r];
+                } else if (p.Ydrop && !(dv & 4)) {
                     float dsc4[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
+                    if (p.drop.rate > 0.f && !(dv & 1)) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
                     nt_store_bf4(p.Ydrop + m * p.ldy + dir * p.H8 + u0, f2bf(hv[0] * dsc4[0]), f2bf(hv[1] * dsc4[1]), f2bf(hv[2] * dsc4[2]), f2bf(hv[3] * dsc4[3]));
                 }
-            } else if (p.Ydrop) {
+            } else if (DEFER && p.Ydrop) {
+                prev = 2; ydp_off = ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0;
+            } else if (p.Ydrop && !(dv & 4)) {
                 *(unsigned long long*)(p.Ydrop + ((size_t)s * B + b) * p.ldy + dir * p.H8 + u0) = 0ull;
             }
         }
@@ -650,6 +701,16 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         if (p.dbg && s == S / 2 && lane == 0)
             for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pts[i];
         if (p.dbg && s == 0 && lane == 0) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = wall_clock64() - t_entry;   // prologue + step 0
+    }
+    if (DEFER && p.Ydrop && own) {           // the last step's dropped copy
+        float sc[4] = {1.f, 1.f, 1.f, 1.f};
+        if (masked && prev == 1) {
+            unsigned r[4];
+            philox4x32_10((unsigned)ctrp, (unsigned)(ctrp >> 32), p.drop.stream, 0u, (unsigned)key, (unsigned)(key >> 32), r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[i] = (r[i] >> 8) >= dthresh ? dkeep : 0.0f;
+        }
+        ydrop_put(sc);
     }
     if (ut == 0 && threadIdx.x == 0) {
         // stamps the buffers are left with: buffer q was written at steps q, q+2, ... <= S-2 with stamps base, !base, ...
@@ -934,6 +995,7 @@ struct LstmBwdArgs {
     int S, B, H, H8, ndir, lddg, lddy, UT, KB4, step, rb_begin, rb_count;
     DropCfg drop;
     long long* dbg;         // diagnostic timeline (E2T_LSTM_DBG), null in production
+    int dbgv;               // diagnostics build only (E2T_REC_VARIANT): see LstmFwdArgs
 };
 
 // NU = unit tiles (of 16 units) per workgroup.  1: the general form.  2: large hidden sizes (H % 32 == 0, H >= 1024: the H_d = 2048
@@ -1110,7 +1172,13 @@ struct LstmBwdPersistArgs {
 };
 #define E2T_BWD_PRE16 (6 * 64)              // 16-B units of one prefetch buffer: Gs 4 KiB, Cs 1 KiB, dY 1 KiB
 
-template <int KQ, bool WIDE>
+// DEFER (round 6 experiment, diagnostics build only -- MEASURED AND REJECTED): the factors of step s (LDS reads of the prefetched
+// saves, Philox mask of dY, 4 tanh, ~60 flops per cell: 0.45 us of the wave's one instruction stream) computed UNDER the state loads
+// of step s instead of behind the exchange store of step s+1, i.e. in front of those loads.  Same arithmetic, same bits.  The loads
+// then leave 0.1 instead of 0.8 us behind the exchange store, ALWAYS find stale stamps and pay a second round trip: state landed
+// 2.0 instead of 0.8 us, 3.92 vs 3.40 us per step (profiles/r06_rec_sidework_probe.txt).  The side work is the spacer that makes the
+// first attempt succeed; it is not idle time that could be given back.
+template <int KQ, bool WIDE, bool DEFER>
 __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs pa) {
     const LstmBwdArgs& p = pa.a;
     const int lane = threadIdx.x & 63;
@@ -1227,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
             if (p.dY) {
                 const uint4 raw = src[5 * 64 + lane];
                 dy[0] = __uint_as_float(raw.x); dy[1] = __uint_as_float(raw.y); dy[2] = __uint_as_float(raw.z); dy[3] = __uint_as_float(raw.w);
-                if (p.drop.rate > 0.f) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
+                if (p.drop.rate > 0.f && !(E2T_DBGV(p) & 1)) drop_scale4(p.drop.rate, key, p.drop.stream, m * NH + dir * H + u0, dsc4);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1287,6 +1355,15 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
 #pragma unroll
                     for (int i = 0; i < KQ; ++i)        // the immediate offset field is 13-bit signed: one base per 4 k-blocks
                         asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[i]) : "v"(src + (i >> 2) * 2048), "i"((i & 3) * 1024) : "memory");
+                    if (DEFER && r2 == 0 && spins == 0 && s >= 0) {
+                        // this step's factors while the state is on its way: LDS reads + VALU on registers of their own (their operands
+                        // were prefetched two steps ago and have landed: the previous step's wait covered them); the results are
+                        // pinned in front of the wait so that hipcc cannot sink the arithmetic behind it
+                        precompute(s);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            asm volatile("" :: "v"(f_add[r]), "v"(k1[r]), "v"(k2[r]), "v"(k3[r]), "v"(k4[r]), "v"(k5[r]), "v"(k6[r]), "v"(ct[r]));
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int i = 0; i < KQ; ++i) asm volatile("" : "+v"(st[i]));
@@ -1389,12 +1466,12 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd_persist(LstmBwdPersistArgs
         }
         PSTAMP(5);
         // ---- off the critical path: row-major dG for the weight-gradient GEMMs, factors of the next step ----
-        if (own) {
+        if (own && !(E2T_DBGV(p) & 2)) {
             const int t = dir ? (len - 1 - s) : s;
             uint4* gp = (uint4*)(p.dG + ((size_t)(active ? t : s) * B + b) * p.lddg + (size_t)dir * K4 + u0 * 4);
             gp[0] = og0; gp[1] = og1;
         }
-        if (s > 0) precompute(s - 1);        // (a first look at the next step's flags from here was measured: slower,
+        if (!DEFER && s > 0 && !(E2T_DBGV(p) & 4)) precompute(s - 1);        // (a first look at the next step's flags from here was measured: slower,
                                              //  hipcc waits for the loads at once when registers are this tight)
         PSTAMP(6);
         if (p.dbg && s == S / 2 && lane == 0)
@@ -1466,6 +1543,7 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* G
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     pa.hx = (bf16_t*)hx; pa.err = err;
     p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
+    p.dbgv = e2t_dbg_int("E2T_REC_VARIANT", 0);
     p.gx_nt = (size_t)d->S * d->B * d->ndir * d->H * 4 * sizeof(bf16_t) > ((size_t)128 << 20);     // beyond half the 256-MB infinity cache
     if (p.KB > 13 && p.KB <= 26 && d->H % 8 == 0) {
         // wide layer: 32 x 32 workgroups, K halves in the accumulation order of k_lstm_step_fwd (its LDS chunk geometry)
@@ -1500,12 +1578,25 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* G
         e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
         return E2T_ERR_ARG;
     }
-#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL(k_lstm_seq_fwd_persist<K>, dim3(nwg), dim3(256), 4 * 3 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
-    switch (p.KB) {
-        E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5)
-        E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10)
-        E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13)
+#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL((k_lstm_seq_fwd_persist<K, E2T_FWD_DEFER>), dim3(nwg), dim3(256), 4 * 3 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
+#define E2T_PERSIST_CASES switch (p.KB) { \
+        E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5) \
+        E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10) \
+        E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13) }
+    // (DEFER is a measured REJECTION, kept in the diagnostics build so that it can be re-taken: scripts/probe_rec_sidework.py)
+#ifdef E2T_DEBUG
+    if (e2t_dbg_int("E2T_FWD_DEFER", 0) != 0) {
+#define E2T_FWD_DEFER true
+        E2T_PERSIST_CASES
+#undef E2T_FWD_DEFER
+    } else
+#endif
+    {
+#define E2T_FWD_DEFER false
+        E2T_PERSIST_CASES
+#undef E2T_FWD_DEFER
     }
+#undef E2T_PERSIST_CASES
 #undef E2T_PERSIST_CASE
     E2T_LAUNCH_CHECK();
     return E2T_OK;
@@ -1565,6 +1656,7 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     p.UT = (d->H + 15) / 16; p.KB4 = (4 * d->H + 31) / 32;
     p.drop.rate = d->drop_rate; p.drop.seed = d->drop_seed; p.drop.step = d->drop_step; p.drop.stream = d->drop_stream;
     p.dbg = (long long*)e2t_dbg_ptr("E2T_LSTM_DBG");
+    p.dbgv = e2t_dbg_int("E2T_REC_VARIANT", 0);
     // (the BPTT's prefetch of the saved gates / cells / dY with the non-temporal policy, and its row-major dG stores, were measured
     //  at cfg5: no difference)
     pa.dgx = (bf16_t*)dgx; pa.flags = flags; pa.err = err;
@@ -1581,16 +1673,31 @@ extern "C" int e2t_lstm_seq_bwd_persistent(const e2t_lstm_desc* d, const void* W
     }
     pa.fstride = wide ? 128 : 32;
     const size_t lds = (size_t)(4 * 3 * E2T_BWD_PRE16 + 16 * 64) * 16;        // prefetch rings, K-quarter partials
-#define E2T_PERSIST_CASE(K, W) case K: hipLaunchKernelGGL((k_lstm_seq_bwd_persist<K, W>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
-    if (!wide) {
-        switch (KQ) {
-            E2T_PERSIST_CASE(1, false) E2T_PERSIST_CASE(2, false) E2T_PERSIST_CASE(3, false) E2T_PERSIST_CASE(4, false) E2T_PERSIST_CASE(5, false)
-            E2T_PERSIST_CASE(6, false) E2T_PERSIST_CASE(7, false) E2T_PERSIST_CASE(8, false) E2T_PERSIST_CASE(9, false) E2T_PERSIST_CASE(10, false)
-            E2T_PERSIST_CASE(11, false) E2T_PERSIST_CASE(12, false) E2T_PERSIST_CASE(13, false)
-        }
-    } else {
-        switch (KQ) { E2T_PERSIST_CASE(16, true) E2T_PERSIST_CASE(20, true) E2T_PERSIST_CASE(25, true) }
+#define E2T_PERSIST_CASE(K, W) case K: hipLaunchKernelGGL((k_lstm_seq_bwd_persist<K, W, E2T_BWD_DEFER>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, pa); break;
+#define E2T_PERSIST_CASES \
+    if (!wide) { \
+        switch (KQ) { \
+            E2T_PERSIST_CASE(1, false) E2T_PERSIST_CASE(2, false) E2T_PERSIST_CASE(3, false) E2T_PERSIST_CASE(4, false) E2T_PERSIST_CASE(5, false) \
+            E2T_PERSIST_CASE(6, false) E2T_PERSIST_CASE(7, false) E2T_PERSIST_CASE(8, false) E2T_PERSIST_CASE(9, false) E2T_PERSIST_CASE(10, false) \
+            E2T_PERSIST_CASE(11, false) E2T_PERSIST_CASE(12, false) E2T_PERSIST_CASE(13, false) \
+        } \
+    } else { \
+        switch (KQ) { E2T_PERSIST_CASE(16, true) E2T_PERSIST_CASE(20, true) E2T_PERSIST_CASE(25, true) } \
     }
+    // (DEFER is a measured REJECTION, kept in the diagnostics build so that it can be re-taken: scripts/probe_rec_sidework.py)
+#ifdef E2T_DEBUG
+    if (e2t_dbg_int("E2T_BWD_DEFER", 0) != 0) {
+#define E2T_BWD_DEFER true
+        E2T_PERSIST_CASES
+#undef E2T_BWD_DEFER
+    } else
+#endif
+    {
+#define E2T_BWD_DEFER false
+        E2T_PERSIST_CASES
+#undef E2T_BWD_DEFER
+    }
+#undef E2T_PERSIST_CASES
 #undef E2T_PERSIST_CASE
     E2T_LAUNCH_CHECK();
     return E2T_OK;
