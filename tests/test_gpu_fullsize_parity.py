@@ -341,13 +341,18 @@ def test_cfg3_round_robin_round_against_bf16_emulating_oracle():
             # (the bands of tests/test_gpu_decode_fullsize.py::test_cfg2_three_adam_ema_steps_follow_the_oracle: Adam normalises every
             #  coordinate's step to ~lr; a coordinate whose gradient is within round-off of zero may step the other way)
             assert err.max() <= 2.0 * nsteps * lr * 1.01, (k, float(err.max()))
-            assert np.abs(Ed[k] - state['ema'][k]).max() < 1e-4, k
+            # EMA shadows (decay 0.99): a coordinate that steps the other way at EVERY one of n steps is 2 lr i off after step i, its
+            # shadow 0.01 lr n (n + 1) after n (1e-4 at n = 4, 3.6e-4 at n = 8): asserted at 0.6 of that (measured 1.4e-4 at n = 8)
+            assert np.abs(Ed[k] - state['ema'][k]).max() < max(1e-4, 0.6 * 0.01 * lr * nsteps * (nsteps + 1)), k
             if 'subnet_' in k:
-                # a participant's front-end takes ONE step per round, and Adam's first step is lr * sign(g) whatever |g| is: a
-                # coordinate whose gradient lies within the gradient tolerance of zero may go either way (measured: 1.8 % of a
-                # 307 200-entry kernel), so the statement is made where the sign is decided -- |g| >= 5e-2 of the tensor's
-                # maximum, ten times the tolerance of the gradient legs above: there every coordinate took the oracle's step
-                clear = np.abs(first_g[k]) >= 5e-2 * np.abs(first_g[k]).max()
+                # a participant's front-end takes ONE step per round, and that first step is c lr g / (|g| + eps') with c <= 1 (TF1 form:
+                # at global step 3 a fresh tensor's step is 0.64 lr, eps' = 3e-7) -- nearly lr sign(g) whatever |g| is: a coordinate
+                # whose gradient lies within the gradient error of zero may go either way (measured: 1.8 % of a 307 200-entry kernel
+                # differ by more than a third of a step; the gradient legs above allow single entries 3e-2 of the maximum off, and
+                # this leg compares TRAJECTORIES, whose shared body has drifted by then).  The statement is made where the sign is
+                # decided -- |g| >= 0.15 of the tensor's maximum: there every coordinate took the oracle's step -- plus a ceiling on
+                # the share of all coordinates that went the other way
+                clear = np.abs(first_g[k]) >= 0.15 * np.abs(first_g[k]).max()
                 assert clear.sum() >= min(1000, err.size // 10) and err[clear].max() < 0.35 * lr * (nsteps // 4), (k, int(clear.sum()), float(err[clear].max()))
                 assert (err > 0.35 * lr * (nsteps // 4)).mean() < 5e-2, (k, float((err > 0.35 * lr).mean()))
                 continue
