@@ -46,7 +46,11 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes; False (the default until that schedule has
     #                  run with more than one RCCL rank): one graph per backward stage, the collectives issued eagerly between them --
     #                  also the fallback ALL ranks take together when any rank's capture is refused
-    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True)
+    #   big_bptt_masks  a large layer (lstm_big) applies its output-dropout mask to dY inside its BPTT, so the producers of dY (the input
+    #                   gradient of the layer above: the 256 x 256 lean-epilogue instance then takes it) do not (layers._Lstm.out_drop).
+    #                   Round 6, measured and left OFF: cfg4 8.27 / 8.21 ms with it against 8.17 / 8.19 without (two same-box pairs)
+    OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True,
+                   big_bptt_masks=False)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -1411,9 +1415,19 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
 
     def _replay_staged(self, ws, g, sync, lazy):
         cur = torch.cuda.current_stream(self.device)
+        tr = self.trainable_ranges(ws['sid'])
+        follow = bool(lazy and getattr(sync, 'pending_ranges', None) is not None)     # the optimiser follows the exchange range by range
+
+        def update(w, a, b):
+            w.wait()                         # the current stream waits for this collective only
+            er = [(max(a, x), min(b, y)) for x, y in tr if x < b and y > a]
+            if er:
+                self.adam_ranges(er, step_offset=1)
 
         def replay_stages(side_stream, exchange):
+            early_done = None
             for i, (gm, gs, ranges) in enumerate(g[0]):
+                last_rec = exchange and i == len(g[0]) - 2
                 if gs is not None:
                     ev = torch.cuda.Event()
                     ev.record(cur)                   # everything the side work reads was enqueued on the main stream before
@@ -1423,12 +1437,38 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                         if exchange:
                             self._exchange(sync, ranges)     # the collective orders itself behind the side stream
                 gm.replay()
-                if exchange and i == len(g[0]) - 2:
+                if last_rec:
                     # the last kernel that can raise sync_err (the bottom layer's BPTT) has been enqueued: the word's maximum over the
                     # ranks makes a step that one rank must skip a step that every rank skips (the replicas cannot drift apart)
                     sync.allreduce_flag(self.sync_err[0:1])
+                    if follow and sync.pending_ranges:
+                        # Round 6: the updates of every range exchanged so far (all but the bottom layer's) go out HERE, behind the
+                        # bottom layer's BPTT and the flag -- in front of the main chain's last graph (the bottom layer's weight
+                        # gradients), next to which they run, as the single-GPU graph's early update does.
+                        # (They used to be enqueued behind the WHOLE main chain: profiles/r06_dp_timeline_graph_per_stage.txt,
+                        # 110 us of optimiser launches exposed behind the last product, 1.757 vs 1.566 ms per cfg2 step on one rank.)
+                        # They are HBM-bound and write fp32 masters and optimiser state, which no backward kernel reads.  No update
+                        # may read sync_err before its last writer and the maximum over the ranks are done: a step is applied on every
+                        # range and every rank, or on none.
+                        # Stream: the SIDE stream, behind its last weight-gradient graph.  (A stream of the optimiser's own, so that
+                        # each update waits for its own collective only, was measured: HIP dealt it the MAIN stream's hardware queue,
+                        # and an update waiting for its all-reduce held up the main chain's last graph behind it -- 2.02 instead of
+                        # 1.68 ms per step.  With eager launches the stream -> queue map is not ours to choose.)
+                        evm = torch.cuda.Event()
+                        evm.record(cur)
+                        side_stream.wait_event(evm)
+                        with torch.cuda.stream(side_stream):
+                            sync.wait_flag()
+                            for w, a, b in list(sync.pending_ranges):
+                                update(w, a, b)
+                        early_done = len(sync.pending_ranges)
                 if gs is None and exchange:
                     self._exchange(sync, ranges)
+            if not (exchange and early_done is not None):
+                join_side_stream(side_stream)
+            return early_done
+
+        def join_side_stream(side_stream):
             ev = torch.cuda.Event()
             ev.record(side_stream)
             cur.wait_event(ev)
@@ -1452,36 +1492,19 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 if best is None or t < best[0]:
                     best = (t, st)
             ws['graph']['side_stream'] = best[1]
-        replay_stages(ws['graph']['side_stream'], True)
-        pend = getattr(sync, 'pending_ranges', None)
-        if pend and lazy:
-            # the optimiser follows the exchange range by range (the ranges complete in backward order): only the last
-            # range's update is exposed behind its all-reduce, the earlier ones run under the later collectives
-            # The updates of all ranges but the last go out on the SIDE stream, behind its last weight-gradient graph: they are
-            # HBM-bound and run next to the bottom layer's weight gradients, which close the main chain (the single-GPU graph's
-            # early update, same place); they write fp32 masters and optimiser state, which no backward kernel reads.
-            tr = self.trainable_ranges(ws['sid'])
-            pl = list(pend)
-            side_stream = ws['graph']['side_stream']
-
-            def update(w, a, b):
-                w.wait()                         # the current stream waits for this collective only
-                er = [(max(a, x), min(b, y)) for x, y in tr if x < b and y > a]
-                if er:
-                    self.adam_ranges(er, step_offset=1)
-            # (no update may read sync_err before the whole main chain -- the bottom layer's BPTT is its last writer -- and the
-            #  maximum of the ranks' words are done: a step is applied on every range and every rank, or on none)
-            evm = torch.cuda.Event()
-            evm.record(cur)
-            side_stream.wait_event(evm)
-            with torch.cuda.stream(side_stream):
+        early_done = replay_stages(ws['graph']['side_stream'], True)
+        if follow and sync.pending_ranges:
+            # what was exchanged behind the early updates (the bottom layer's ranges, completed by the main chain's last graph): only
+            # these updates are exposed behind their all-reduce
+            if early_done is None:
                 sync.wait_flag()
-                for w, a, b in pl[:-1]:
-                    update(w, a, b)
-                evs = torch.cuda.Event()
-                evs.record(side_stream)
-            update(*pl[-1])
-            cur.wait_event(evs)
+            for w, a, b in list(sync.pending_ranges)[early_done or 0:]:
+                update(w, a, b)
+            if early_done is not None:
+                # (the main stream joins the side stream -- its weight-gradient graphs and the early updates -- only now, behind its own
+                #  last update: joined in front of it, that update waited for the early ones, 30 us of exposed tail;  the step counter
+                #  moves when every update, which reads it, is done)
+                join_side_stream(ws['graph']['side_stream'])
             sync.wait()                          # (all done: clears the lists)
             lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
             self._packed = None

@@ -269,7 +269,13 @@ class _Lstm:
         not spend a Philox evaluation per step and cell on the critical loop.  None: BPTT masks dY itself (no dropout, or
         the padded column layout differs from the logical one)."""
         rate = self.eng.spec.rnn_dropout if train else 0.0
-        if rate > 0 and self.H8 == self.H:
+        # Round 6 experiment (engine option big_bptt_masks, OFF): a LARGE layer (H = 1024, csrc/lstm_big.hip) masks dY in its BPTT, so
+        # that the input gradient of the layer above (8704 x 2048 x 8192 at BASELINE config 4) has no dropout in its epilogue and
+        # runs on the 256 x 256 instance, whose epilogue is the lean one (csrc/gemm.hip: the full body does not unroll over 32
+        # accumulator tiles).  Parity green (tests/test_gpu_fullsize_parity.py cfg4 legs), but the step is no faster: 8.27 / 8.21 ms
+        # against 8.17 / 8.19 -- beside the 256 x 256 weight-gradient product of the other branch a second 256 x 256 launch gains
+        # nothing (as in round 4: the last round of a 256 x 256 product on 128 x 128 tiles, alone 303 -> 279 us, in the step slower)
+        if rate > 0 and self.H8 == self.H and not (self.big and self.eng.options.get('big_bptt_masks', False)):
             return (rate, self.stream, self.ndir * self.H)
         return None
 

@@ -12,7 +12,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 kw, B, T, L = bench.CONFIGS[cfg]
 batch = bench.synth_batch(kw, B, T, L, seed=5)
-for mode in ('one_graph', 'graph_per_stage', 'single'):
+for mode in (os.environ.get('DP_MODES', 'one_graph,graph_per_stage,single').split(',')):
     # (one engine per schedule: both data-parallel schedules -- the step as ONE graph with the collectives as nodes, and the default,
     #  one graph per backward stage with the collectives issued between them -- and the single-GPU graph for reference)
     eng = Seq2SeqEngine(NetSpec(**kw), device='cuda:0', seed=3, options={'dp_one_graph': mode == 'one_graph'})

@@ -356,7 +356,7 @@ def test_cfg3_round_robin_round_against_bf16_emulating_oracle():
                 assert clear.sum() >= min(1000, err.size // 10) and err[clear].max() < 0.35 * lr * (nsteps // 4), (k, int(clear.sum()), float(err[clear].max()))
                 assert (err > 0.35 * lr * (nsteps // 4)).mean() < 5e-2, (k, float((err > 0.35 * lr).mean()))
                 continue
-            nflip = int((err > 3 * lr * 0.35).sum())
+            nflip = int((err > nsteps * lr * 0.35).sum())          # (a third of the way the tensor can have moved by then)
             assert nflip <= max(5, (2e-2 if relu else 5e-3) * err.size), (k, float(err.max()), nflip, err.size)
             disp = Po[k] - np.asarray(P[k], np.float32)
             if np.linalg.norm(disp) > 0:
