@@ -3,7 +3,7 @@
 # kernel stats + one-step timelines of cfg2 / cfg4 / cfg5 (fp32 and bf16-staged inputs), the PMC passes of cfg2's kernels, the
 # vendor-BLAS calibration and the data-parallel schedule on one GPU.
 #   scripts/gpu_evidence.sh <tag> [notests]   -> gpurun_out/<tag>/ (copy what is to be judged into profiles/<tag>_*)
-tag=${1:-r05}; out=$PWD/gpurun_out/$tag; mkdir -p $out
+tag=${1:-r06}; out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1 || { tail -20 $out/build.log; exit 1; }
 if [ "$2" != notests ]; then
@@ -31,4 +31,9 @@ for c in cfg2 cfg4; do timeout 300 python scripts/bench_tail.py $c 2>&1 | grep -
 for c in cfg2 cfg4; do timeout 300 python scripts/latency_b1.py $c 2>&1 | grep -v amdgpu.ids >> $out/latency_b1.txt; done; cat $out/latency_b1.txt
 timeout 600 python scripts/bench_fit.py 100 2>&1 | grep -v amdgpu.ids > $out/fit_throughput.txt; tail -3 $out/fit_throughput.txt
 TIMELINE=1 timeout 600 python scripts/bench_lstm_step.py cfg2 2>&1 | grep -v amdgpu.ids > $out/lstm_step_phases.txt; head -30 $out/lstm_step_phases.txt
+ls $out
+# round 6: cfg5 front-end HBM bytes on the final tree, the recurrences' side-work probe + DEFER experiment, the data-parallel timeline
+bash scripts/pmc_frontend.sh > $out/pmc_frontend.log 2>&1; cp gpurun_out/pmc_frontend/summary.txt $out/pmc_cfg5_frontend.txt; cat $out/pmc_cfg5_frontend.txt
+timeout 600 python scripts/probe_rec_sidework.py cfg2 quick 2>&1 | grep -v amdgpu.ids > $out/rec_sidework_quick.txt; cat $out/rec_sidework_quick.txt
+bash scripts/prof_dp.sh graph_per_stage cfg2 > $out/dp_timeline_graph_per_stage.txt 2>&1
 ls $out
