@@ -180,16 +180,27 @@ def test_long_run_at_full_size_has_no_in_kernel_timeouts():
     for _ in range(3):
         eng.train_step(ws)
     first = eng.losses(ws)['decoder']
-    slow = []
+    slow, slow_host = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for step in range(150):
         torch.cuda.synchronize(); t0 = time.perf_counter()
+        e0.record()
         eng.train_step(ws)
+        e1.record()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        # the DEVICE's time between the two events is what an in-kernel wait that spins (and in the end succeeds or gives up) would
+        # lengthen; the host's wall clock also sees the box (a 32-ms step with a clean error word was seen once in round 6 on a
+        # shared box; 18 000 steps in a row of scripts/probe_slow_steps.py: maximum 3.1 ms) -- reported, not asserted
+        if e0.elapsed_time(e1) > 20.0:
+            slow.append((step, e0.elapsed_time(e1)))
         if dt > 20e-3:
-            slow.append((step, dt))
+            slow_host.append((step, round(1e3 * dt, 1), round(e0.elapsed_time(e1), 2)))
         assert int(eng.sync_err[0].item()) == 0, ('in-kernel wait timed out', step, eng.sync_err.cpu().numpy().tolist())
     last = eng.losses(ws)
+    if slow_host:
+        print('\nsteps slow on the host clock (step, host ms, device ms): %s' % slow_host)
     assert not slow, slow
+    assert len(slow_host) <= 2, slow_host
     assert np.isfinite(last['total']) and last['decoder'] < 0.5 * first, (first, last)
 
 
