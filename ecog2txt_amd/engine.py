@@ -46,11 +46,14 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   dp_one_graph   data parallel: the step as ONE graph with the collectives as nodes; False (the default until that schedule has
     #                  run with more than one RCCL rank): one graph per backward stage, the collectives issued eagerly between them --
     #                  also the fallback ALL ranks take together when any rank's capture is refused
+    #   fused_bottom   (with fused_tail, single GPU) the BOTTOM encoder layer's update at the end of the captured step goes through the fused
+    #                  kernel too (slab sums + Adam + EMA + its operand images in one pass) instead of reduction + e2t_adam_ema_step now and
+    #                  e2t_pack_batch at the start of the next step
     #   big_bptt_masks  a large layer (lstm_big) applies its output-dropout mask to dY inside its BPTT, so the producers of dY (the input
     #                   gradient of the layer above: the 256 x 256 lean-epilogue instance then takes it) do not (layers._Lstm.out_drop).
     #                   Round 6, measured and left OFF: cfg4 8.27 / 8.21 ms with it against 8.17 / 8.19 without (two same-box pairs)
     OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True,
-                   big_bptt_masks=False)
+                   big_bptt_masks=False, fused_bottom=True)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -1319,24 +1322,41 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 early = (nl, early_fn)
         g1 = torch.cuda.CUDAGraph()
         slab_mode = [False]
+        tail = [(max(a, early_end), b) for a, b in tr if b > early_end]
+        # Round 6 (option fused_bottom): the bottom layer's ranges go through the fused kernel as well -- at the END of the step, where
+        # the separate reduction + update launches used to close it.  Its images are then current when the step ends, and the next
+        # step re-packs only the per-subject front-end images (the first pack launch, next to the weight-free start of the
+        # front-end).  `packed_all` = every range whose images this graph rebuilds itself: the early ranges + the bottom layer's,
+        # WITHOUT the front-end segments (no image of theirs is in the second pack table), so that it is the same set for every
+        # participant's graph (BASELINE config 3: one graph per participant, replayed in turn).
+        conv_start = min([self.store.seg_range(nm)[0] for nm in self.store.order if nm.startswith('conv')] or [self.store.n])
+        fuse_bottom = bool(packed_early) and not dp and self.options['fused_tail'] and self.options['fused_bottom']
+        packed_all = [(a, min(b, conv_start)) for a, b in tr if a < conv_start] if fuse_bottom else list(packed_early)
+        tail_slabs = [False]
         if packed_early:
             self._pack_subtable(tuple(packed_early))          # descriptor tables are built outside the capture
             if self.options['fused_tail']:
                 self._fused_update_plan(tuple(packed_early))
+                if fuse_bottom:
+                    self._fused_update_plan(tuple(tail))
                 if not dp and self.options['fused_reduce']:
                     # single GPU: the weight gradients of the early ranges are never reduced -- the fused kernel sums their split-K
                     # slabs as it reads them.  One eager backward pass in that mode tells where the launcher leaves the slabs
                     # (its decisions depend on shapes only: the capture below repeats them) and allocates the arenas.
-                    self._keep_slabs, self._slab_log = tuple(packed_early), []
-                    try:
-                        self.backward(ws, train=True)
-                        torch.cuda.synchronize(self.device)
-                        slab_mode[0] = self._fused_update_plan(tuple(packed_early), slab_log=self._slab_log) is not None
-                    finally:
-                        if not slab_mode[0]:
-                            self._keep_slabs = None
+                    for keep in ([tuple(packed_early) + tuple(tail), tuple(packed_early)] if fuse_bottom else [tuple(packed_early)]):
+                        self._keep_slabs, self._slab_log = keep, []
+                        try:
+                            self.backward(ws, train=True)
+                            torch.cuda.synchronize(self.device)
+                            slab_mode[0] = self._fused_update_plan(tuple(packed_early), slab_log=self._slab_log) is not None
+                            tail_slabs[0] = slab_mode[0] and len(keep) > len(packed_early) and \
+                                self._fused_update_plan(tuple(tail), slab_log=self._slab_log) is not None
+                        finally:
+                            if not slab_mode[0]:
+                                self._keep_slabs = None
+                        if tail_slabs[0] or len(keep) == len(packed_early) or not slab_mode[0]:
+                            break         # (else: the bottom layer's slabs cannot be named by its descriptors -- probe again, early ranges only)
         probe_sig = self._slab_sig(self._slab_log) if slab_mode[0] else None
-        tail = [(max(a, early_end), b) for a, b in tr if b > early_end]
 
         def exchange(ranges):
             for a, b in ranges:
@@ -1348,15 +1368,18 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             # like the early update it runs on the un-incremented step counter (step_offset = 1)
             if dp:
                 sync.join()
-            self.adam_ranges(tail, step_offset=1)
+            if fuse_bottom:
+                self.adam_pack_ranges(tail, step_offset=1, slabs=tail_slabs[0])
+            else:
+                self.adam_ranges(tail, step_offset=1)
         try:
-            if packed_early:
-                self._pack_subtable(('skip',) + tuple(packed_early))
+            if packed_all:
+                self._pack_subtable(('skip',) + tuple(packed_all))
             self._slab_log = []
             with capture(g1):
                 if dp:
                     sync.attach()
-                self.forward(ws, train=True, pack_first=True, pack_skip=packed_early or None, global_counts=gc)
+                self.forward(ws, train=True, pack_first=True, pack_skip=packed_all or None, global_counts=gc)
                 self.backward(ws, train=True, early=early, before_join=tail_update, exchange=exchange if dp else None,
                               after_last_rec=(lambda: sync.allreduce_flag(self.sync_err[0:1])) if dp else None)
                 lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), self.stream)
@@ -1378,7 +1401,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             sync._flag_pending = False
         self._packed = None
         self._img_early = None
-        return (g1, tuple(packed_early))
+        return (g1, tuple(packed_all))
 
     def _capture_staged(self, ws, lazy, gc):
         """The data-parallel step as one graph per backward stage for the BPTT chain (main stream) and one per stage for its
