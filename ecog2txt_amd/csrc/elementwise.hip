@@ -671,6 +671,169 @@ __global__ __launch_bounds__(256) void k_greedy_step(const float* logits, int ld
 }
 
 // ---------------------------------------------------------------------------
+// ABI 9: greedy decoding of FEW utterances (the online predictor decodes ONE per call, ecog2txt/trainers.py:925-949).  At B = 1 a
+// decoder step was four launches -- row gather, recurrence step, a 15-tile projection GEMM whose 128-row tiles hold one real row
+// (12.8 us), arg-max (4.6 us) -- on an otherwise idle chip: 30 us per token, all of it launch latency and padding.  Here the head
+// of a step is ONE launch: a matrix-vector product on the vector units (4 lanes per vocabulary row, 16 rows per wave pass, the
+// state in LDS as fp32), the arg-max through a two-level reduction (wave shuffles, LDS, then one 8-byte {value, index} per
+// workgroup and utterance written through to L2 and a ticket: the LAST workgroup to arrive reduces them), the bookkeeping of
+// k_greedy_step, and the copy of the chosen token's input-projection row for the next step.
+// ---------------------------------------------------------------------------
+#define E2T_HEAD_MAXB 8
+__global__ __launch_bounds__(256) void k_decode_init(int* done, int* hyp, int* tok0, int* dlens, int B, int Lmax, int eos, int pad) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * Lmax; i += gridDim.x * 256) hyp[i] = pad;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) { done[b] = 0; tok0[b] = eos; dlens[b] = Lmax; }
+}
+__device__ __forceinline__ unsigned long long head_key(float v, int idx) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)idx; }
+__device__ __forceinline__ bool head_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+__global__ __launch_bounds__(256) void k_greedy_head_small(const bf16_t* h, int ldh, const bf16_t* WT, int ldw, const float* bias, int B, int V, int K,
+                                                           int l, int Lmax, int eos, int pad, int* done, int* out, int* next_tok,
+                                                           const unsigned* table, size_t row_words, unsigned* gx_next, unsigned* scratch) {
+    extern __shared__ uint4 head_lds[];                 // [B][K8 / 8] the state as it lies (bf16), then [4 waves][B] {value, index}
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K8 = (K + 7) & ~7, nchunk = K8 >> 3;
+    {
+        bf16_t* hs = (bf16_t*)head_lds;
+        for (int i = threadIdx.x; i < B * K8; i += 256) {
+            const int b = i / K8, k = i - b * K8;
+            hs[i] = k < K ? h[(size_t)b * ldh + k] : (bf16_t)0;
+        }
+    }
+    __syncthreads();
+    float bestv[E2T_HEAD_MAXB]; int besti[E2T_HEAD_MAXB];
+#pragma unroll
+    for (int b = 0; b < E2T_HEAD_MAXB; ++b) { bestv[b] = -INFINITY; besti[b] = 0x7fffffff; }
+    // 8 lanes per vocabulary row (lane q takes the 16-B chunks q, q + 8, ...), 8 rows per wave pass; a lane's loads of a pass are
+    // issued together, eight at a time (one dependent load per loop trip made the launch 20 us: 25 round trips to L2 in a row)
+    const int q = lane & 7, r = lane >> 3;
+    for (int v0 = (blockIdx.x * 4 + wave) * 8; v0 < V; v0 += gridDim.x * 32) {
+        const int v = v0 + r;
+        const uint4* wrow = (const uint4*)(WT + (size_t)min(v, V - 1) * ldw);
+        float acc[E2T_HEAD_MAXB];
+#pragma unroll
+        for (int b = 0; b < E2T_HEAD_MAXB; ++b) acc[b] = 0.f;
+        for (int c0 = q; c0 < nchunk; c0 += 64) {
+            uint4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int c = c0 + 8 * j; w[j] = c < nchunk ? wrow[c] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 8 * j;
+                if (c < nchunk) {
+                    const float wf[8] = {__uint_as_float(w[j].x << 16), __uint_as_float(w[j].x & 0xFFFF0000u), __uint_as_float(w[j].y << 16), __uint_as_float(w[j].y & 0xFFFF0000u),
+                                         __uint_as_float(w[j].z << 16), __uint_as_float(w[j].z & 0xFFFF0000u), __uint_as_float(w[j].w << 16), __uint_as_float(w[j].w & 0xFFFF0000u)};
+#pragma unroll
+                    for (int b = 0; b < E2T_HEAD_MAXB; ++b) {
+                        if (b < B) {
+                            const uint4 x = head_lds[b * nchunk + c];
+                            float a = acc[b];
+                            a = fmaf(wf[0], __uint_as_float(x.x << 16), a); a = fmaf(wf[1], __uint_as_float(x.x & 0xFFFF0000u), a);
+                            a = fmaf(wf[2], __uint_as_float(x.y << 16), a); a = fmaf(wf[3], __uint_as_float(x.y & 0xFFFF0000u), a);
+                            a = fmaf(wf[4], __uint_as_float(x.z << 16), a); a = fmaf(wf[5], __uint_as_float(x.z & 0xFFFF0000u), a);
+                            a = fmaf(wf[6], __uint_as_float(x.w << 16), a); a = fmaf(wf[7], __uint_as_float(x.w & 0xFFFF0000u), a);
+                            acc[b] = a;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < E2T_HEAD_MAXB; ++b) {
+            if (b < B) {
+                float a = acc[b];
+                a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);      // the row's eight partial sums (fixed order)
+                if (v < V) {
+                    a += bias ? bias[v] : 0.f;
+                    if (head_better(a, v, bestv[b], besti[b])) { bestv[b] = a; besti[b] = v; }
+                }
+            }
+        }
+    }
+    // wave -> workgroup
+    float* red = (float*)(head_lds + B * nchunk);        // [4][B][2]
+#pragma unroll
+    for (int b = 0; b < E2T_HEAD_MAXB; ++b) {
+        if (b < B) {
+            float mv = bestv[b]; int mi = besti[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(mv, o, 64); const int oi = __shfl_xor(mi, o, 64);
+                if (head_better(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+            }
+            if (lane == 0) { red[(wave * B + b) * 2] = mv; red[(wave * B + b) * 2 + 1] = __int_as_float(mi); }
+        }
+    }
+    __syncthreads();
+    unsigned long long* part = (unsigned long long*)(scratch + 2);        // [gridDim.x][B] {value, index}; scratch[0] = ticket
+    if (threadIdx.x < B) {
+        const int b = threadIdx.x;
+        float mv = red[b * 2]; int mi = __float_as_int(red[b * 2 + 1]);
+        for (int w = 1; w < 4; ++w) {
+            const float ov = red[(w * B + b) * 2]; const int oi = __float_as_int(red[(w * B + b) * 2 + 1]);
+            if (head_better(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+        }
+        __hip_atomic_store(part + (size_t)blockIdx.x * B + b, head_key(mv, mi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through stores have reached L2 before the ticket is taken
+    __syncthreads();
+    __shared__ unsigned ticket;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    // ---- the last workgroup: final arg-max, bookkeeping, next step's input-projection rows ----
+    __shared__ int tok[E2T_HEAD_MAXB];
+    __shared__ unsigned long long allp[64 * E2T_HEAD_MAXB];
+    // (every partial by a thread of its own: read one after the other by the B reducing threads they were 57 round trips to L2 in a
+    //  row, 30 us)
+    for (unsigned i = threadIdx.x; i < gridDim.x * (unsigned)B; i += 256)
+        allp[i] = __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x < B) {
+        const int b = threadIdx.x;
+        float mv = -INFINITY; int mi = 0x7fffffff;
+        for (unsigned g = 0; g < gridDim.x; ++g) {
+            const unsigned long long kx = allp[g * B + b];
+            const float ov = __uint_as_float((unsigned)(kx >> 32)); const int oi = (int)(unsigned)kx;
+            if (head_better(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+        }
+        const int arg = (mi == 0x7fffffff) ? 0 : mi;
+        const int dn = done[b];
+        out[(size_t)b * Lmax + l] = dn ? pad : arg;
+        done[b] = dn | (arg == eos);
+        if (next_tok) next_tok[b] = arg;
+        tok[b] = arg;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the ticket word for the next launch
+    __syncthreads();
+    if (table && gx_next) {
+        // the chosen tokens' input-projection rows, all loads of a thread in flight together (a load -> store loop was one round
+        // trip to L2 per trip: 6 us per utterance)
+        if ((row_words & 3) == 0 && ((((uintptr_t)table) | ((uintptr_t)gx_next)) & 15) == 0) {
+            const size_t rq = row_words >> 2, total = (size_t)B * rq;
+            for (size_t i0 = threadIdx.x; i0 < total; i0 += 256 * 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t i = i0 + 256 * j;
+                    if (i < total) { const int b = (int)(i / rq); v[j] = ((const uint4*)(table + (size_t)tok[b] * row_words))[i - b * rq]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t i = i0 + 256 * j;
+                    if (i < total) { const int b = (int)(i / rq); ((uint4*)(gx_next + (size_t)b * row_words))[i - b * rq] = v[j]; }
+                }
+            }
+        } else {
+            for (int b = 0; b < B; ++b) {
+                const unsigned* src = table + (size_t)tok[b] * row_words;
+                unsigned* dst = gx_next + (size_t)b * row_words;
+                for (size_t i = threadIdx.x; i < row_words; i += 256) dst[i] = src[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a9, beam_width > 1 (mocha-1_word_sequence.yaml:31; temperature :82): one step of beam search for utterance b = blockIdx.x.
 // Rows b*W + w of `logits` are the W live hypotheses.  Candidates: for a live beam w every token v, scored
 // score[w] + log softmax(logits[w] / temperature)[v]; for a finished beam only "stay finished" (score unchanged).  The W best
@@ -1156,6 +1319,24 @@ extern "C" int e2t_greedy_step(const float* logits, int ldl, int B, int V, int l
                                int32_t* next_tok, void* stream) {
     E2T_CHECK_ARG(logits && done && out && B > 0 && V > 0 && ldl >= V && l >= 0 && l < Lmax);
     hipLaunchKernelGGL(k_greedy_step, dim3((B + 3) / 4), dim3(256), 0, ST, logits, ldl, B, V, l, Lmax, eos, pad, done, out, next_tok);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_decode_init(int32_t* done, int32_t* hyp, int32_t* tok0, int32_t* dlens, int B, int Lmax, int eos, int pad, void* stream) {
+    E2T_CHECK_ARG(done && hyp && tok0 && dlens && B > 0 && Lmax > 0);
+    hipLaunchKernelGGL(k_decode_init, dim3((B * Lmax + 255) / 256 > 64 ? 64 : (B * Lmax + 255) / 256), dim3(256), 0, ST, done, hyp, tok0, dlens, B, Lmax, eos, pad);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_greedy_head_small(const void* h, int ldh, const void* WT, int ldw, const float* bias, int B, int V, int K, int l, int Lmax,
+                                     int eos, int pad, int32_t* done, int32_t* out, int32_t* next_tok, const void* table, size_t row_words,
+                                     void* gx_next, uint32_t* scratch, void* stream) {
+    E2T_CHECK_ARG(h && WT && done && out && scratch && B > 0 && B <= E2T_HEAD_MAXB && V > 0 && K > 0 && l >= 0 && l < Lmax);
+    E2T_CHECK_ARG(ldh >= K && ldw >= ((K + 7) & ~7) && (ldw & 7) == 0 && (((uintptr_t)WT) & 15) == 0 && (!table || gx_next));
+    const int K8 = (K + 7) & ~7;
+    const size_t lds = (size_t)B * K8 * 2 + 4 * B * 2 * sizeof(float);
+    E2T_CHECK_ARG(lds <= 64 * 1024);
+    int grid = (V + 31) / 32; if (grid > 64) grid = 64;          // 8 rows per wave pass, 4 waves: one pass at V = 1806 on 57 workgroups
+    hipLaunchKernelGGL(k_greedy_head_small, dim3(grid), dim3(256), lds, ST, (const bf16_t*)h, ldh, (const bf16_t*)WT, ldw, bias, B, V, K, l, Lmax,
+                       eos, pad, done, out, next_tok, (const unsigned*)table, row_words, (unsigned*)gx_next, scratch);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_beam_step(const float* logits, int ldl, int B, int W, int V, float temperature, int l, int Lmax, int eos, int pad,

@@ -1,5 +1,5 @@
 """Decoding with the trained network (assessment: restore_and_assess, the online predictor): greedy search and beam search,
-one decoder step per token through the launch-per-step kernels; the input projection of a token is a row of a table made once per call.  Mixed into Seq2SeqEngine (engine.py)."""
+one decoder step per token through the launch-per-step kernels; the input projection of a token is a row of a table made once per set of weights.  Mixed into Seq2SeqEngine (engine.py)."""
 import torch
 
 from .hip_lib import lib
@@ -39,13 +39,30 @@ class DecodingMixin:
         max_len = L if max_len is None else min(max_len, L)
         st = self.stream
         self.encode(ws, src, False)
-        lib.e2t_fill_u32(ws['done'].data_ptr(), B, 0, st)
-        lib.e2t_fill_u32(ws['hyp'].data_ptr(), B * L, PAD_ID, st)
-        lib.e2t_fill_u32(ws['U'].data_ptr(), B, EOS_ID, st)
-        lib.e2t_fill_u32(ws['dlens'].data_ptr(), B, L, st)
+        lib.e2t_decode_init(ws['done'].data_ptr(), ws['hyp'].data_ptr(), ws['U'].data_ptr(), ws['dlens'].data_ptr(), B, L, EOS_ID, PAD_ID, st)
         dw = ws['dec']
         pw = ws['proj']
-        table = self._token_projection_table(src)
+        table = self._token_projection_table(src, which)
+        if B <= self.small_batch_head_max and self.proj.nl == 1 and self.options['small_batch_head']:
+            # ONE or TWO utterances (the online predictor's one, trainers.py:925-949): a step = the recurrence's launch + ONE head
+            # launch (e2t_greedy_head_small: projection on the vector units, arg-max, bookkeeping, the next step's input-projection
+            # row: 13-14 us) instead of gather + recurrence + a 128-row-tile GEMM for B real rows + arg-max (4.6 + 12.8 + 4.6 us).
+            # Measured host to host at cfg2 (profiles/r06_latency_b1.txt): B = 1 0.578 vs 0.620 ms, B = 2 equal, B = 4 0.72 vs 0.66,
+            # B = 8 0.90 vs 0.69 -- the kernel takes B <= 8, the engine uses it up to small_batch_head_max = 2
+            if self._head_scratch is None:
+                self._head_scratch = torch.zeros(2 + 2 * 64 * 8, dtype=torch.int32, device=self.device)
+            lib.e2t_gather_rows_u32(table.data_ptr(), ws['U'].data_ptr(), B, B, self.dec.N4 // 2, dw['Gx'].data_ptr(), st)
+            pr = self.proj
+            for l in range(max_len):
+                self.dec.fwd(dw, None, ws['dlens'], src, False, c0=ws['c0'], steps=(l, l + 1))
+                more = l + 1 < max_len
+                lib.e2t_greedy_head_small(dw['Yext'].data_ptr() + 2 * (l + 1) * B * self.dec.ldy, self.dec.ldy, pr.WT[0].data_ptr(), pr.in_ld,
+                                          pr.bias_ptr(0, src), B, s.vocab, s.dec_rnn, l, L, EOS_ID, PAD_ID, ws['done'].data_ptr(),
+                                          ws['hyp'].data_ptr(), ws['U'].data_ptr() + 4 * (l + 1) * B if l + 1 < L else None,
+                                          table.data_ptr() if more else None, self.dec.N4 // 2,
+                                          dw['Gx'].data_ptr() + 2 * (l + 1) * B * self.dec.N4 if more else None,
+                                          self._head_scratch.data_ptr(), st)
+            return ws['hyp']
         for l in range(max_len):
             # input projection of this step's tokens: rows of the table (embedding and projection of a token are the same for every
             # utterance and step -- decoding applies no dropout: the embedding lookup + a 256-row GEMM per step were two launches)
@@ -94,7 +111,7 @@ class DecodingMixin:
         lib.e2t_fill_u32(wb['U'].data_ptr(), BW, EOS_ID, st)
         lib.e2t_fill_u32(wb['dlens'].data_ptr(), BW, L, st)
         dw, pw = wb['dec'], wb['proj']
-        table = self._token_projection_table(src)
+        table = self._token_projection_table(src, which)
         RT, UT = ceil_div(BW, 16), ceil_div(s.dec_rnn, 16)
         cs_step = RT * UT * 2 * 64 * 2                            # floats of one step's lane-native cell save
         cur = 0
@@ -116,7 +133,7 @@ class DecodingMixin:
         hyp = bm['hyp'][cur].view(B, W, L)[:, 0, :].contiguous()  # survivors are kept best first
         return hyp, bm['score'][cur].view(B, W)
 
-    def _token_projection_table(self, src):
+    def _token_projection_table(self, src, which=None):
         """bf16 [V][4 H_d]: the decoder's input projection of every token, W_x . embedding[v] + b, from the images packed last
         (one 1806-row GEMM per decode call in place of an embedding lookup + a B-row GEMM per step: the same operands and K
         order; bit-identical to the per-step product where the launch plan picks the same tile and K split for M = V as for
@@ -124,6 +141,14 @@ class DecodingMixin:
         s = self.spec
         if self._dec_table is None:
             self._dec_table = _bf(s.vocab, self.dec.N4, device=self.device)
+        # (round 6: the table depends on the weights only -- it is made once per set of operand images, not once per call: 12 us of a
+        #  0.6-ms single-utterance decode.  _img_version moves whenever an image or a parameter may have changed.)
+        key = (which, self._img_version) if which is not None else None
+        if torch.cuda.is_current_stream_capturing():
+            key = None                 # (a captured decode rebuilds the table at every replay: the graph outlives the weights it was captured with)
+        if key is not None and self._dec_table_key == key:
+            return self._dec_table
+        self._dec_table_key = key
         self.gemm(self.emb.data_ptr(), self.E8, self.dec.WxT.data_ptr(), self.E8, self._dec_table.data_ptr(), self.dec.N4,
                   s.vocab, self.dec.N4, self.E8, bias=self.dec.bias_ptr(src), out_bf16=True)
         return self._dec_table

@@ -49,11 +49,12 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   fused_bottom   (with fused_tail, single GPU) the BOTTOM encoder layer's update at the end of the captured step goes through the fused
     #                  kernel too (slab sums + Adam + EMA + its operand images in one pass) instead of reduction + e2t_adam_ema_step now and
     #                  e2t_pack_batch at the start of the next step
+    #   small_batch_head  greedy decoding of <= 8 utterances: one head launch per token (e2t_greedy_head_small) instead of gather + GEMM + arg-max
     #   big_bptt_masks  a large layer (lstm_big) applies its output-dropout mask to dY inside its BPTT, so the producers of dY (the input
     #                   gradient of the layer above: the 256 x 256 lean-epilogue instance then takes it) do not (layers._Lstm.out_drop).
     #                   Round 6, measured and left OFF: cfg4 8.27 / 8.21 ms with it against 8.17 / 8.19 without (two same-box pairs)
     OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True,
-                   big_bptt_masks=False, fused_bottom=True)
+                   big_bptt_masks=False, fused_bottom=True, small_batch_head=True)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -158,6 +159,8 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         self._ustream = None          # data parallel: the early optimiser update's stream inside the captured step
         self._lstream = None
         self._dec_table = None          # decoding: the decoder's input projection of every token (decoding.py)
+        self._dec_table_key, self._img_version, self._head_scratch = None, 0, None
+        self.small_batch_head_max = 2   # greedy decoding: the one-launch head (e2t_greedy_head_small) up to this many utterances
         self.launch_stream_on = bool(opt['launch_stream'])
         # (measured and dropped in rounds 1-2, DESIGN.md appendix: weight gradients on TWO side streams, the BPTT chain alone
         #  on the chip with all weight gradients behind it, per-stage joins)
@@ -1132,6 +1135,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         [0, skip_below) were already updated by adam_ranges(..., step_offset=1)."""
         store = self.store
         st = self.stream
+        self._img_version += 1
         lib.e2t_inc_step(self.step_t.data_ptr(), self.sync_err.data_ptr(), st)
         h = H.AdamHyper()
         h.lr, h.beta1, h.beta2, h.eps = self.hyper['lr'], self.hyper['beta1'], self.hyper['beta2'], self.hyper['eps']
@@ -1217,6 +1221,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             cur.wait_event(ev2)
 
     def _train_step(self, ws, use_graph, sync):
+        self._img_version += 1
         dp = sync is not None and sync.world > 1
         gc = bool(dp and ws.get('global_counts'))          # losses normalised by the global counts: the exchange is a plain sum
         lazy = use_graph and self.overlap      # re-pack inside the (first) graph

@@ -111,6 +111,8 @@ SIGNATURES = {
     'e2t_softmax_ce': [_p, _i, _i, _i, _p, _p, _i, _p, _f, _p, _p, _p, _p, _i, _p],
     'e2t_greedy_update': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     'e2t_greedy_step': [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    'e2t_decode_init': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'e2t_greedy_head_small': [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p, _p, _p],
     'e2t_beam_step': [_p, _i, _i, _i, _i, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'e2t_beam_reorder': [_p, _i, _p, _i, _i, _p, _p, _p, _p],
     'e2t_mse': [_p, _i, _p, _i, _i, _p, _i, _p, _f, _p, _p, _i, _p],

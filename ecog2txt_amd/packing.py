@@ -18,6 +18,7 @@ class PackingMixin:
         the captured train step right behind the optimiser update of those ranges, so that the next step starts with
         only the bottom layer's images left to build."""
         tab = self._pack_subtable(tuple(ranges))
+        self._img_version += 1
         if tab:
             lib.e2t_pack_batch(tab[0].data_ptr(), tab[1], tab[2], self.store.p.data_ptr(), self.stream)
 
@@ -218,6 +219,7 @@ class PackingMixin:
         plain pack kernel on images the tile kernel does not make.  Same bits as adam_ranges + pack_ranges."""
         upd, pack_only, plain, rest = self._fused_plans[(tuple(ranges), 'slabs')] if slabs else self._fused_update_plan(tuple(ranges))
         st, store = self.stream, self.store
+        self._img_version += 1
         if plain:
             self.adam_ranges(plain, step_offset=step_offset)
         if upd:
@@ -239,6 +241,7 @@ class PackingMixin:
         kernels of all subjects, then everything else; after_head() runs between the two (an event record: the conv GEMM
         of a captured step waits for the first launch only, not for the 80 us of the second)."""
         src = getattr(self.store, which)
+        self._img_version += 1
         if skip_ranges:
             # (a captured train step re-packed these images itself, behind their optimiser update: pack_ranges)
             tab = self._pack_subtable(('skip',) + tuple(skip_ranges))

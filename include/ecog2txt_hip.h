@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define E2T_ABI_VERSION 8
+#define E2T_ABI_VERSION 9
 
 int e2t_abi_version(void);
 /* sizeof() of the structs that cross the boundary, for bindings to check their layouts against:
@@ -290,6 +290,21 @@ int e2t_greedy_update(const int32_t* pred, int B, int l, int Lmax, int eos, int 
 /* ABI 7: arg-max of the step's logits (lowest index on ties) + the bookkeeping of e2t_greedy_update, one launch */
 int e2t_greedy_step(const float* logits, int ldl, int B, int V, int l, int Lmax, int eos, int pad, int32_t* done, int32_t* out,
                     int32_t* next_tok, void* stream);
+/* ABI 9 -- decoding FEW utterances at a time (the reference's online predictor: one utterance per call, ecog2txt/trainers.py:925-949).
+ * e2t_decode_init: the start state of a greedy search in one launch -- done[b] = 0, hyp[b][:] = pad, tok0[b] = eos (the start symbol),
+ * dlens[b] = Lmax -- instead of four fills.
+ * e2t_greedy_head_small: one decoder step's HEAD for B <= 8 rows in one launch instead of three (vocabulary projection GEMM on a
+ * 128-row tile, arg-max, row gather): logits[b][v] = bias[v] + sum_k WT[v][k] h[b][k] (bf16 operands, fp32 accumulation; WT is the
+ * K-contiguous image the projection GEMM multiplies, h the decoder state of the step as the recurrence wrote it), arg-max over v
+ * (lowest index on ties) and e2t_greedy_step's bookkeeping (done / out / next_tok), and -- table != NULL -- row next_tok[b] of
+ * `table` ([V][row_words] 32-bit words: the decoder's input projection of every token) copied to gx_next[b][row_words] for the next
+ * step.  scratch: device words, >= 2 * 64 * 8 + 1, ZERO before the first call (the kernel leaves its ticket word at zero).
+ * The sums are taken in a different order than the MFMA product's: logits agree to fp32 round-off, tokens wherever the top-2
+ * margin exceeds it. */
+int e2t_decode_init(int32_t* done, int32_t* hyp, int32_t* tok0, int32_t* dlens, int B, int Lmax, int eos, int pad, void* stream);
+int e2t_greedy_head_small(const void* h, int ldh, const void* WT, int ldw, const float* bias, int B, int V, int K, int l, int Lmax,
+                          int eos, int pad, int32_t* done, int32_t* out, int32_t* next_tok, const void* table, size_t row_words,
+                          void* gx_next, uint32_t* scratch, void* stream);
 /* Beam search (beam_width > 1, mocha-1_word_sequence.yaml:31; temperature :82): one step for B utterances x W hypotheses
  * (rows b*W + w of logits [B*W][ldl]).  A live hypothesis continues with every token, scored
  * score + log softmax(logits / temperature); a finished one (it has emitted <EOS>) only as itself; the W best survive (ties:

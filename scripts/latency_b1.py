@@ -17,12 +17,14 @@ kw, _, T, L = bench.CONFIGS[cfg]
 eng = Seq2SeqEngine(NetSpec(**kw), seed=1)
 eng.init_params(0)
 eng.pack('ema')
-for B in (1, 8):
+sweep = os.environ.get('LAT_SWEEP') == '1'            # B = 1, 2, 4, 8 with the one-launch head (e2t_greedy_head_small) on and off, eager only
+for B in ((1, 2, 4, 8) if sweep else (1, 8)):
     ws = eng.workspace(401, B, T, L)
     x = bench.synth_batch(kw, B, T, L, seed=3)['encoder_inputs'].astype(np.float32)
     x[:, 350:] = 0                                      # 1.75 s of signal, zero padded to the 2-s window
     xh = torch.from_numpy(x).pin_memory()
-    for mode in ('eager', 'graph'):
+    for mode in (('eager', 'eager/general-head') if sweep else ('eager', 'graph')):
+        eng.options['small_batch_head'] = mode != 'eager/general-head'
         def predict():
             ws['X'].copy_(xh, non_blocking=True)
             hyp = eng.greedy_decode(ws, which='ema', use_graph=(mode == 'graph')).cpu().numpy()
@@ -35,5 +37,5 @@ for B in (1, 8):
             t0 = time.perf_counter(); h = predict(); ts.append(time.perf_counter() - t0)
             assert np.array_equal(h, ref)
         ts = 1e3 * np.sort(np.array(ts))
-        print('%s B=%d %-5s  host-to-host per call: median %.3f ms  p10 %.3f  p99 %.3f   (%.0f utterances/s)' % (
+        print('%s B=%d %-18s  host-to-host per call: median %.3f ms  p10 %.3f  p99 %.3f   (%.0f utterances/s)' % (
             cfg, B, mode, np.median(ts), ts[len(ts) // 10], ts[int(0.99 * len(ts))], B / np.median(ts) * 1e3), flush=True)

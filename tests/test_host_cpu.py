@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(hip_lib.SIGNATURES) | set(hip_lib.PLAIN)
-    assert lib.e2t_abi_version() == 8
+    assert lib.e2t_abi_version() == 9
     # the ctypes mirrors of the boundary structs have the C layouts' sizes
     for which, cls in enumerate([hip_lib.GemmEpilogue, hip_lib.LstmDesc, hip_lib.PackDesc, hip_lib.AdamHyper, hip_lib.Dropout]):
         assert lib.e2t_sizeof(which) == ctypes.sizeof(cls), cls.__name__
