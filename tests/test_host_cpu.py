@@ -225,8 +225,8 @@ def test_register_budgets_of_the_co_resident_kernels():
 
     def alloc(n):
         return (n + 7) // 8 * 8
-    bptt = regs('void k_lstm_seq_bwd_persist<13, false>')
-    fwd = regs('void k_lstm_seq_fwd_persist<13>')
+    bptt = regs('void k_lstm_seq_bwd_persist<13, false, false>')        # (KQ, WIDE, DEFER: the product instantiates DEFER = false only)
+    fwd = regs('void k_lstm_seq_fwd_persist<13, false>')
     tn = max(regs('k_gemm_tn_group'), regs('void k_gemm_nt<128, 128, 2, 2, false, true, 64, 2, 0>'))
     nt = regs('void k_gemm_nt<128, 128, 2, 2, true, false, 64, 2, 0>')
     assert alloc(bptt) + alloc(tn) <= 512, (bptt, tn)
