@@ -445,7 +445,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // MFMAs lengthens that phase 0.56 -> 0.80: 2.44 vs 2.36 us from step top to step bottom, 2.81 vs 2.70 us per step by the clock, the
 // cfg2 train step 1.671 vs 1.562 ms.  (What the side work in front of the loads does buy: with NOTHING between the exchange store and
 // the loads the first attempt always finds stale stamps and pays a second round trip -- 2.94 us per step.)
-template <int KB, bool DEFER>        // k-blocks of 32 over H8: compile-time, so every fragment sits in a fixed register
+// PIPE (round 6 experiment, diagnostics build only -- MEASURED AND REJECTED): the state fragments consumed AS THEY LAND -- VMEM returns
+// in issue order, so `s_waitcnt vmcnt(KB-1-kb)` retires exactly fragment kb; its stamps go into running AND / OR words, its four MFMAs
+// are issued at once (behind a sched_barrier: hipcc otherwise sinks all 52 behind the last wait) -- and the freshness check is made
+// ONCE, behind the last fragment: a product on stale state is discarded and the step taken again.  Same MFMAs on the same accumulators
+// in the same order: same bits.  The idea was to run the 0.56-us MFMA phase under the 0.68-us load phase.  Measured
+// (profiles/r06_rec_sidework_probe.txt): loads + MFMAs 1.36 us against 0.68 + 0.56 -- a wave's thirteen fragments land TOGETHER at the
+// end of one L2 round trip, there is nothing to run under; 3.23 vs 2.70 us per step.
+template <int KB, bool DEFER, bool PIPE>        // k-blocks of 32 over H8: compile-time, so every fragment sits in a fixed register
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa) {
     const LstmFwdArgs& p = pa.a;
     const int lane = threadIdx.x & 63;
@@ -551,6 +558,42 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(st[kb]));         // uses stay behind the wait
+            } else if (PIPE) {
+                const bf16_t* src = pa.hx + ((((size_t)((s - 1) & 1) * p.ndir + dir) * (RB * 4) + rt) * KB * 64 + lane) * 8;
+                const bool tag1 = ((((s - 1) >> 1) & 1) ^ ((s - 1) & 1 ? base[1] : base[0])) != 0;      // wave-uniform
+                const bool chk_last = (KB - 1) * 32 + fq * 8 < H;            // the last k-block is partly padding (never written)
+                int spins = 0;
+                for (;;) {
+    #pragma unroll
+                    for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)     // the immediate offset field is 13-bit signed: one base per 4 k-blocks
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(st[kb]) : "v"(src + (kb >> 2) * 2048), "i"((kb & 3) * 1024) : "memory");
+                    unsigned mand = 0xFFFFFFFFu, mor = 0u;
+    #pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        // fragment kb has landed when at most KB-1-kb vector-memory operations are outstanding (everything older --
+                        // the previous step's stores and prefetches -- retired before it); the register is an OUTPUT of the wait, so
+                        // hipcc cannot read it earlier
+                        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(st[kb]) : "n"(KB - 1 - kb) : "memory");
+                        const unsigned a = st[kb][0] & st[kb][1] & st[kb][2] & st[kb][3], o = st[kb][0] | st[kb][1] | st[kb][2] | st[kb][3];
+                        const bool chk = kb < KB - 1 || chk_last;
+                        mand &= chk ? a : 0xFFFFFFFFu; mor |= chk ? o : 0u;
+                        const u32x4 x = st[kb] & 0xBFFFBFFFu;                // stamps off (a no-op where they are clear)
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[(kb >> 1) & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[kb][g], *(const bf16x8*)&x, acc[(kb >> 1) & 1][g], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);                  // (hipcc otherwise sinks all 52 MFMAs behind the last wait)
+                    }
+                    const bool fresh = tag1 ? ((mand & 0x40004000u) == 0x40004000u) : ((mor & 0x40004000u) == 0u);
+                    if (__all(fresh || !active)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;        // bounded: never hang the GPU; once any wave has given up nobody waits any more
+                    if ((spins & 255) == 0 && __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1 << 17)) { __hip_atomic_store(pa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if (p.dbg && s == S / 2) pts[1] = spins;
             } else {
                 // No flags: every bf16 in the exchange buffer carries a 1-bit stamp in bit 14 (free: |h| <= 1 keeps the
                 // exponent below 128).  Buffer (s-1)&1 is rewritten every other step, so its stamp toggles with (s-1)>>1;
@@ -615,6 +658,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             if (s + 2 < S) gx_load(s + 2);
             if (DEFER && p.Ydrop && own) ydrop_put(dscp);
 
+            if (!(PIPE && s > 0)) {
     #pragma unroll
             for (int h = 0; h < 2; ++h)
     #pragma unroll
@@ -629,6 +673,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             if (KB & 1) {                                                // odd tail k-block: the half that owns pair index npr
     #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[npr & 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[KB - 1][g], *(bf16x8*)&st[KB - 1], acc[npr & 1][g], 0, 0, 0);
+            }
             }
         }
         PSTAMP(3);
@@ -1578,22 +1623,33 @@ extern "C" int e2t_lstm_seq_fwd_persistent(const e2t_lstm_desc* d, const void* G
         e2t_set_error("persistent recurrence not applicable (H=%d, %d workgroups, %d CUs)", d->H, nwg, num_cus);
         return E2T_ERR_ARG;
     }
-#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL((k_lstm_seq_fwd_persist<K, E2T_FWD_DEFER>), dim3(nwg), dim3(256), 4 * 3 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
+#define E2T_PERSIST_CASE(K) case K: hipLaunchKernelGGL((k_lstm_seq_fwd_persist<K, E2T_FWD_DEFER, E2T_FWD_PIPE>), dim3(nwg), dim3(256), 4 * 3 * 4 * 64 * 16, (hipStream_t)stream, pa); break;
 #define E2T_PERSIST_CASES switch (p.KB) { \
         E2T_PERSIST_CASE(1) E2T_PERSIST_CASE(2) E2T_PERSIST_CASE(3) E2T_PERSIST_CASE(4) E2T_PERSIST_CASE(5) \
         E2T_PERSIST_CASE(6) E2T_PERSIST_CASE(7) E2T_PERSIST_CASE(8) E2T_PERSIST_CASE(9) E2T_PERSIST_CASE(10) \
         E2T_PERSIST_CASE(11) E2T_PERSIST_CASE(12) E2T_PERSIST_CASE(13) }
     // (DEFER is a measured REJECTION, kept in the diagnostics build so that it can be re-taken: scripts/probe_rec_sidework.py)
+#define E2T_FWD_PIPE_PRODUCT false
 #ifdef E2T_DEBUG
     if (e2t_dbg_int("E2T_FWD_DEFER", 0) != 0) {
 #define E2T_FWD_DEFER true
+#define E2T_FWD_PIPE false
         E2T_PERSIST_CASES
+#undef E2T_FWD_PIPE
+#undef E2T_FWD_DEFER
+    } else if (e2t_dbg_int("E2T_FWD_PIPE", E2T_FWD_PIPE_PRODUCT) != (E2T_FWD_PIPE_PRODUCT ? 1 : 0)) {
+#define E2T_FWD_DEFER false
+#define E2T_FWD_PIPE (!E2T_FWD_PIPE_PRODUCT)
+        E2T_PERSIST_CASES
+#undef E2T_FWD_PIPE
 #undef E2T_FWD_DEFER
     } else
 #endif
     {
 #define E2T_FWD_DEFER false
+#define E2T_FWD_PIPE E2T_FWD_PIPE_PRODUCT
         E2T_PERSIST_CASES
+#undef E2T_FWD_PIPE
 #undef E2T_FWD_DEFER
     }
 #undef E2T_PERSIST_CASES

@@ -55,15 +55,21 @@ quick = len(sys.argv) > 2 and sys.argv[2] == 'quick'
 for name, fn, variants in (('forward', fwd_p, (0,) if quick else (0, 1, 2, 4, 8, 3, 7, 15, 0)), ('BPTT', bwd_p, (0,) if quick else (0, 1, 2, 4, 6, 7, 0))):
     # round 6: E2T_FWD_DEFER / E2T_BWD_DEFER = 0 selects the round-5 order (mask / factors in FRONT of the next step's state loads), 1 the
     # product's (under them); the variant switches act on the round-5 order only
+    modes = [('product order', {}), ('DEFER: side work UNDER the next state loads', dict(E2T_FWD_DEFER='1', E2T_BWD_DEFER='1')),
+             ('PIPE: fragments consumed as they land', dict(E2T_FWD_PIPE='1', E2T_BWD_PIPE='1'))]
+    if os.environ.get('PROBE_MODES'):
+        modes = [m for m in modes if m[0].split(':')[0].split(' ')[0] in os.environ['PROBE_MODES'].split(',')]
     for rep in range(3):
-        for defer in (0, 1):
-            os.environ['E2T_FWD_DEFER'] = os.environ['E2T_BWD_DEFER'] = str(defer)
+        for label, env in modes:
+            for k in ('E2T_FWD_DEFER', 'E2T_BWD_DEFER', 'E2T_FWD_PIPE', 'E2T_BWD_PIPE'):
+                os.environ[k] = env.get(k, '0')
             os.environ['E2T_REC_VARIANT'] = '0'
-            print('%s, side work %s the next state loads: %.3f us per step (S = %d, err %d)' % (
-                name, 'UNDER' if defer else 'in front of', timeit(fn, S), S, int(err[0].item())), flush=True)
+            print('%s, %s: %.3f us per step (S = %d, err %d)' % (name, label, timeit(fn, S), S, int(err[0].item())), flush=True)
+    for k in ('E2T_FWD_PIPE', 'E2T_BWD_PIPE'):
+        os.environ[k] = '0'
     os.environ['E2T_FWD_DEFER'] = os.environ['E2T_BWD_DEFER'] = '0'
     for v in variants:
         os.environ['E2T_REC_VARIANT'] = str(v)
         print('%s (round-5 order) variant %2d: %.3f us per step (S = %d, err %d)' % (name, v, timeit(fn, S), S, int(err[0].item())), flush=True)
-for k in ('E2T_REC_VARIANT', 'E2T_FWD_DEFER', 'E2T_BWD_DEFER'):
+for k in ('E2T_REC_VARIANT', 'E2T_FWD_DEFER', 'E2T_BWD_DEFER', 'E2T_FWD_PIPE', 'E2T_BWD_PIPE'):
     os.environ.pop(k, None)
