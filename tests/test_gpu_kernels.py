@@ -933,3 +933,54 @@ def test_gemm_tn_keep_slabs_sum_to_the_reduced_product(hl, M, N, K, nb):
     assert torch.equal(acc, want)
     c2, info2 = call(hl.GEMM_KEEP_SLABS, alpha=0.5)
     assert info2.splits == 1 and torch.equal(c2, 0.5 * want)
+
+
+@pytest.mark.parametrize('B,V,K', [(1, 1806, 800), (3, 1806, 800), (8, 950, 2048), (2, 70, 52), (5, 2500, 136)])
+def test_greedy_head_small_equals_projection_argmax_and_gather(hl, B, V, K):
+    """e2t_decode_init + e2t_greedy_head_small (ABI 9; the online predictor's one utterance per call, trainers.py:925-949): logits =
+    bias + WT . h in fp32 from bf16 operands, arg-max (lowest index on ties), the bookkeeping of e2t_greedy_step, and the chosen
+    tokens' rows of the input-projection table copied for the next step -- one launch.  Against numpy on the rounded operands;
+    launched three times in a row on one scratch buffer (the ticket word is left at zero by the last workgroup to arrive)."""
+    rng = np.random.default_rng(B * 1000 + V + K)
+    L, eos, pad = 6, 1, 0
+    ldh, ldw = r8(K) + 16, r8(K) + 8
+    Hn, Wn = rng.standard_normal((B, K)), rng.standard_normal((V, K)) * 0.2
+    bias = rng.standard_normal(V).astype(np.float32)
+    hbuf = torch.zeros(B, ldh, dtype=torch.bfloat16, device='cuda'); hbuf[:, :K] = dev_bf16(Hn)
+    hbuf[:, K:] = 1.0                                              # (the ones column / padding beyond K must not enter the sums)
+    wbuf = torch.zeros(V, ldw, dtype=torch.bfloat16, device='cuda'); wbuf[:, :K] = dev_bf16(Wn)
+    bt = torch.tensor(bias, device='cuda')
+    rw = 24                                                        # 32-bit words per table row
+    table = torch.arange(V * rw, dtype=torch.int32, device='cuda').reshape(V, rw).contiguous()
+    done, hyp = torch.full((B,), 7, dtype=torch.int32, device='cuda'), torch.full((B, L), -3, dtype=torch.int32, device='cuda')
+    tok0, dlens = torch.full((B,), -3, dtype=torch.int32, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
+    hl.lib.e2t_decode_init(done.data_ptr(), hyp.data_ptr(), tok0.data_ptr(), dlens.data_ptr(), B, L, eos, pad, st())
+    torch.cuda.synchronize()
+    assert not host(done).any() and (host(hyp) == pad).all() and (host(tok0) == eos).all() and (host(dlens) == L).all()
+    logits = round_bf16(Hn) @ round_bf16(Wn).T + bias
+    want = (round_bf16(Hn) @ round_bf16(Wn).T + bias).argmax(1)
+    top2 = np.sort(round_bf16(Hn) @ round_bf16(Wn).T + bias, 1)[:, -2:]
+    assert ((top2[:, 1] - top2[:, 0]) > 1e-4).all()               # (random logits: the decision is clear of fp32 summation order)
+    scratch = torch.zeros(2 + 2 * 64 * 8, dtype=torch.int32, device='cuda')
+    nxt, gx = torch.full((B,), -3, dtype=torch.int32, device='cuda'), torch.full((B, rw), -1, dtype=torch.int32, device='cuda')
+    done0 = np.zeros(B, np.int32)
+    if B > 2:
+        done[2] = 1; done0[2] = 1
+    for l in range(3):                                             # same inputs three times: the ticket word resets itself
+        hl.lib.e2t_greedy_head_small(hbuf.data_ptr(), ldh, wbuf.data_ptr(), ldw, bt.data_ptr(), B, V, K, l, L, eos, pad, done.data_ptr(),
+                                     hyp.data_ptr(), nxt.data_ptr(), table.data_ptr(), rw, gx.data_ptr(), scratch.data_ptr(), st())
+        torch.cuda.synchronize()
+        assert int(scratch[0].item()) == 0
+        np.testing.assert_array_equal(host(nxt), want)
+        np.testing.assert_array_equal(host(hyp)[:, l], np.where(done0 != 0, pad, want))
+        np.testing.assert_array_equal(host(gx), host(table)[want])
+        done0 = done0 | (want == eos)
+        np.testing.assert_array_equal(host(done), done0)
+    assert (host(hyp)[:, 3:] == pad).all()
+    # ties: two identical vocabulary rows -> the lower index; no bias, no table
+    wbuf[V - 1] = wbuf[3]; wbuf[3] *= 0; wbuf[V - 1] *= 0
+    wbuf[10, :K] = 4.0 * hbuf[0, :K]; wbuf[V - 2, :K] = 4.0 * hbuf[0, :K]
+    hl.lib.e2t_greedy_head_small(hbuf.data_ptr(), ldh, wbuf.data_ptr(), ldw, None, 1, V, K, 4, L, eos, pad, done.data_ptr(),
+                                 hyp.data_ptr(), nxt.data_ptr(), None, 0, None, scratch.data_ptr(), st())
+    torch.cuda.synchronize()
+    assert int(nxt[0].item()) == 10
