@@ -132,8 +132,11 @@ __global__ __launch_bounds__(256) void k_sum_i32(const int* x, int n, int* out) 
 }
 
 // out[slot] = scale * sum_i x[i] / max(*count,1)  (single block, fixed order => deterministic)
-__global__ __launch_bounds__(256) void k_sum_f32(const float* x, int n, const int* count, float scale, float* out) {
+// (blockIdx.x = 1: the second of two sums made in one launch, e2t_sum2_f32 -- same association, same bits)
+__global__ __launch_bounds__(256) void k_sum_f32(const float* x, int n, const int* count, float scale, float* out,
+                                                  const float* x1 = nullptr, float scale1 = 0.f, float* out1 = nullptr) {
     __shared__ float sh[256];
+    if (blockIdx.x == 1) { x = x1; scale = scale1; out = out1; }
     // 4 loads in flight per thread (a single dependent chain over 8704 elements took 20 us); the association is fixed
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = threadIdx.x;
@@ -1200,6 +1203,12 @@ extern "C" int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int 
 extern "C" int e2t_sum_i32(const int32_t* x, int n, int32_t* out, void* stream) {
     E2T_CHECK_ARG(x && out && n > 0);
     hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(256), 0, ST, x, n, out);
+    E2T_LAUNCH_CHECK(); return E2T_OK;
+}
+extern "C" int e2t_sum2_f32(const float* x0, const float* x1, int n, const int32_t* count, float scale0, float scale1, float* out0, float* out1,
+                            void* stream) {
+    E2T_CHECK_ARG(x0 && x1 && out0 && out1 && n > 0);
+    hipLaunchKernelGGL(k_sum_f32, dim3(2), dim3(256), 0, ST, x0, n, count, scale0, out0, x1, scale1, out1);
     E2T_LAUNCH_CHECK(); return E2T_OK;
 }
 extern "C" int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float* out, void* stream) {

@@ -49,12 +49,14 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   fused_bottom   (with fused_tail, single GPU) the BOTTOM encoder layer's update at the end of the captured step goes through the fused
     #                  kernel too (slab sums + Adam + EMA + its operand images in one pass) instead of reduction + e2t_adam_ema_step now and
     #                  e2t_pack_batch at the start of the next step
+    #   lean_critical  the decoder's loss and accuracy sums in one launch (e2t_sum2_f32), the zero fill of the embedding gradient on the
+    #                  weight-gradient branch that uses it: two launches fewer on the critical branch between forward and backward pass
     #   small_batch_head  greedy decoding of <= 8 utterances: one head launch per token (e2t_greedy_head_small) instead of gather + GEMM + arg-max
     #   big_bptt_masks  a large layer (lstm_big) applies its output-dropout mask to dY inside its BPTT, so the producers of dY (the input
     #                   gradient of the layer above: the 256 x 256 lean-epilogue instance then takes it) do not (layers._Lstm.out_drop).
     #                   Round 6, measured and left OFF: cfg4 8.27 / 8.21 ms with it against 8.17 / 8.19 without (two same-box pairs)
     OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True,
-                   big_bptt_masks=False, fused_bottom=True, small_batch_head=True)
+                   big_bptt_masks=False, fused_bottom=True, small_batch_head=True, lean_critical=True)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -808,8 +810,12 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         lib.e2t_softmax_ce(logits.data_ptr(), s.vocab, Md, s.vocab, ws['Tg'].data_ptr(), ws['dlens'].data_ptr(), B,
                            ntokp, s.dec_scale, ws['rowloss'].data_ptr(), ws['pred'].data_ptr(),
                            ws['correct'].data_ptr(), ws['dlogits'].data_ptr(), rk(s.vocab), st)
-        lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ntokp, 1.0, ws['loss'].data_ptr(), st)
-        lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ntokp, 1.0, ws['loss'].data_ptr() + 8, st)
+        # (decoder loss and token accuracy in ONE launch: two single-workgroup launches sat on the critical branch here)
+        if self.options['lean_critical']:
+            lib.e2t_sum2_f32(ws['rowloss'].data_ptr(), ws['correct'].data_ptr(), Md, ntokp, 1.0, 1.0, ws['loss'].data_ptr(), ws['loss'].data_ptr() + 8, st)
+        else:
+            lib.e2t_sum_f32(ws['rowloss'].data_ptr(), Md, ntokp, 1.0, ws['loss'].data_ptr(), st)
+            lib.e2t_sum_f32(ws['correct'].data_ptr(), Md, ntokp, 1.0, ws['loss'].data_ptr() + 8, st)
         for j in joins:
             self.join_side(j)
 
@@ -988,8 +994,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         """Critical path of the head: gradient through the vocabulary projection, decoder BPTT (-> gradient into the
         encoder's final state and into the embedded tokens)."""
         s, store = self.spec, self.store
-        a_, b_ = store.seg_range('dec.emb')               # the embedding scatter-add accumulates by atomics
-        lib.e2t_fill_u32(store.g.data_ptr() + 4 * a_, b_ - a_, 0, self.stream)
+        if not self.options['lean_critical']:
+            a_, b_ = store.seg_range('dec.emb')
+            lib.e2t_fill_u32(store.g.data_ptr() + 4 * a_, b_ - a_, 0, self.stream)
         dd = self.dec.out_drop(train)
         self.proj.bwd_dx(ws['proj'], ws['dlogits'], ws['dHd'].data_ptr(), self.dec.ldy, False, train, d_in_drop=dd)
         self.dec.bwd_rec(ws['dec'], ws['e'].data_ptr(), ws['dlens'], ws['dHd'].data_ptr(), self.dec.ldy, train,
@@ -1004,6 +1011,11 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             self.dec.bwd_weights(ws['dec'], ws['e'].data_ptr())
         # the gradient into the embedded tokens only feeds the embedding table: off the encoder's critical path
         self.dec.bwd_d_in(ws['dec'], ws['de'].data_ptr(), self.E8)
+        # (the embedding scatter-add accumulates by atomics onto a zeroed segment: zeroed HERE, on the branch that uses it -- it used
+        #  to be the first launch of the backward pass on the critical branch)
+        if self.options['lean_critical']:
+            a_, b_ = store.seg_range('dec.emb')
+            lib.e2t_fill_u32(store.g.data_ptr() + 4 * a_, b_ - a_, 0, self.stream)
         dr = self._dropout(s.ff_dropout if train else 0.0, STREAM_DEC_EMB)
         lib.e2t_embed_bwd(ws['de'].data_ptr(), self.E8, ws['U'].data_ptr(), ws['Md'], s.dec_embed,
                           store.ptr('dec.emb', store.g), s.dec_embed, C.byref(dr), self.stream)

@@ -81,6 +81,7 @@ SIGNATURES = {
     'e2t_seq_lengths_i32': [_p, _i, _i, _i, _i, _p, _p, _p],
     'e2t_sum_i32': [_p, _i, _p, _p],
     'e2t_sum_f32': [_p, _i, _p, _f, _p, _p],
+    'e2t_sum2_f32': [_p, _p, _i, _p, _f, _f, _p, _p, _p],
     'e2t_conv_pack': [_p, _p, _i, _i, _i, _i, _p, _i, _p],
     'e2t_conv_pack_grouped': [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     'e2t_conv_fwd_fused': [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, C.POINTER(GemmEpilogue), _p],

@@ -75,6 +75,10 @@ int e2t_seq_lengths_tail_f32(const float* x, int B, int T, int C, int div, int32
 int e2t_seq_lengths_i32(const int32_t* x, int B, int L, int pad, int div, int32_t* lens, int32_t* lens_div, void* stream);
 int e2t_sum_i32(const int32_t* x, int n, int32_t* out, void* stream);
 int e2t_sum_f32(const float* x, int n, const int32_t* count, float scale, float* out, void* stream);
+/* ABI 9: two such sums over n elements each (same count) in ONE launch -- the decoder's loss and token accuracy, which sat as two
+ * launches on the critical branch between the cross-entropy and the backward pass; same association, same bits */
+int e2t_sum2_f32(const float* x0, const float* x1, int n, const int32_t* count, float scale0, float scale1, float* out0, float* out1,
+                 void* stream);
 
 /* ---- a5+a6: tf.reverse_sequence (trainers.py:808-810) fused with the im2row staging of
  *      SequenceNetwork._convolve_sequences (trainers.py:813-818): x [B][T][C] fp32 ->
