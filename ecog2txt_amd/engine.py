@@ -49,6 +49,9 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #   fused_bottom   (with fused_tail, single GPU) the BOTTOM encoder layer's update at the end of the captured step goes through the fused
     #                  kernel too (slab sums + Adam + EMA + its operand images in one pass) instead of reduction + e2t_adam_ema_step now and
     #                  e2t_pack_batch at the start of the next step
+    #   prefetch_batches  (round 6 experiment, OFF) a fit whose partitions are resident in HBM: the captured step gathers the NEXT batch into its
+    #                  own input buffers on a side branch (set_prefetch); False: the fit gathers between steps (42 us per cfg2 step).  Same
+    #                  results (tests/test_gpu_e2e.py), but SLOWER wherever the gather was placed: 1.78 vs 1.68 ms per step at fit level
     #   lean_critical  the decoder's loss and accuracy sums in one launch (e2t_sum2_f32), the zero fill of the embedding gradient on the
     #                  weight-gradient branch that uses it: two launches fewer on the critical branch between forward and backward pass
     #   small_batch_head  greedy decoding of <= 8 utterances: one head launch per token (e2t_greedy_head_small) instead of gather + GEMM + arg-max
@@ -56,7 +59,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     #                   gradient of the layer above: the 256 x 256 lean-epilogue instance then takes it) do not (layers._Lstm.out_drop).
     #                   Round 6, measured and left OFF: cfg4 8.27 / 8.21 ms with it against 8.17 / 8.19 without (two same-box pairs)
     OPTIONS = dict(persistent='1', overlap=True, fused_conv='auto', tn=True, group_gemms=True, launch_stream=True, dp_one_graph=False, fused_tail=True, fused_reduce=True,
-                   big_bptt_masks=False, fused_bottom=True, small_batch_head=True, lean_critical=True)
+                   big_bptt_masks=False, fused_bottom=True, small_batch_head=True, lean_critical=True, prefetch_batches=False)
 
     def __init__(self, spec, device='cuda:0', seed=0, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.99, options=None):
         if not torch.cuda.is_available():
@@ -492,6 +495,7 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
     def set_batch(self, ws, batch):
         self.check_end_padded(batch['encoder_inputs'])
         ws['packed'] = False
+        ws['have'] = None
         ws['X'].copy_(torch.as_tensor(np.asarray(batch['encoder_inputs']), dtype=torch.float32))
         ws['Y'].copy_(torch.as_tensor(np.asarray(batch['decoder_targets']), dtype=torch.int32))
         if self.aux and 'encoder_targets' in batch:
@@ -537,6 +541,27 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         lib.e2t_gather_rows_u32(pk['lens_d'].data_ptr(), idx_dev.data_ptr(), B, B, 1, ws['lens_d'].data_ptr(), st)
         ws['packed'] = True
         ws['A_stale'] = False
+
+    def set_prefetch(self, ws, sources):
+        """Round 6: let the CAPTURED train step of this workspace assemble the NEXT batch itself.  sources = [(resident partition
+        tensor [n, ...], workspace buffer [B, ...])] (the fit's HBM-resident arrays: inputs, decoder targets, encoder targets); the
+        rows to take are ws['next_idx'] (device int32 [B], -1 = padding utterance), which the caller fills before every replay.
+        The gathers sit on the side branch behind the decoder-side preparation (the only reader of the target buffers) and behind the
+        front-end (the only reader of the inputs): a batch's 105 MB (cfg2) move under the encoder instead of between two steps.
+        None switches it off.  Only captured steps prefetch (ws['prefetched'] says whether the last train_step did)."""
+        if sources is None or not self.options['prefetch_batches'] or not self.overlap or self.aux_x:
+            ws.pop('prefetch', None)
+            return False
+        if 'next_idx' not in ws:
+            ws['next_idx'] = torch.full((ws['B'],), -1, dtype=torch.int32, device=self.device)
+        ws['prefetch'] = [(src, dst, int(src[0].numel())) for src, dst in sources]
+        ws['prefetch_key'] = tuple((src.data_ptr(), dst.data_ptr(), int(src.shape[0])) for src, dst in sources)
+        return True
+
+    def _prefetch_next(self, ws):
+        st = self.stream
+        for src, dst, words in ws['prefetch']:
+            lib.e2t_gather_rows_u32(src.data_ptr(), ws['next_idx'].data_ptr(), ws['B'], ws['B'], words, dst.data_ptr(), st)
 
     def set_global_counts(self, ws, ntok, nval=0, nval_extra=()):
         """Data parallel: the batch's token count and auxiliary-sample count(s) over ALL ranks (host integers; every rank
@@ -755,8 +780,28 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
         def before_enc():
             if 'pack' in pend:
                 self.join_side(pend.pop('pack'))
+            if len(self.enc) < 2:
+                prefetch_mark()
+
+        def prefetch_mark():
+            # (two phases, as everywhere in a captured step: the fork point is taken HERE, the side work is enqueued behind the main
+            #  branch's next kernel -- of the two children of a fork the one created first keeps the parent's hardware queue)
+            if ahead and train and ws.get('prefetch') and ws.get('_prefetch_now'):
+                pend['pf_ev'] = self.fork_point()
+
+        def prefetch_here():
+            if 'pf_ev' in pend:
+                # every reader of this batch's inputs (lengths, im2row / the one-pass front-end) is enqueued on this branch, the
+                # readers of its targets (dec_prep) on the side stream: the next batch may land (set_prefetch).  WHERE: behind
+                # the bottom layer's recurrence, beside the next layer's input projection.  MEASURED AND LEFT OFF (scripts/bench_fit.py,
+                # three same-box pairs each): forked right behind the front-end 1.775 vs 1.69 ms per step; here, created before the main
+                # branch's next kernel 1.85 vs 1.70; here in two phases 1.78 vs 1.68 -- 210 MB of copy traffic beside a persistent
+                # recurrence sit in the memory queues of the CUs that hand the state around (MI355X_MICROARCH.md, handoff-1to1 by
+                # streaming waves on the endpoint CUs) and cost 140 us where the gather between two steps costs 42.
+                joins.append(self.run_side(pend.pop('pf_ev'), lambda: self._prefetch_next(ws)))
 
         def after_gx(l):
+            prefetch_here()
             # the auxiliary head taps layer aux_layer: its forward starts once the NEXT layer's input projection is done,
             # i.e. under that layer's recurrence (latency-bound, 56 CUs idle) rather than next to the projection GEMM
             # (which it slowed from 69 to 96 us), and long before the decoder, which then has the chip to itself
@@ -764,6 +809,8 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 pend['aux_ev'] = self.fork_point()
 
         def after_layer(l):
+            if l == 0 and len(self.enc) >= 2:
+                prefetch_mark()
             if ahead and ws['use_aux'] and l == s.aux_layer and l == len(self.enc) - 1:
                 pend['aux_ev'] = self.fork_point()         # the head taps the top layer: under the decoder
             elif 'aux_ev' in pend:
@@ -1250,14 +1297,42 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
             return
         # the captured Adam launches bake in the trainable ranges and the gradient scale
         one = not dp or (getattr(sync, 'capturable', False) and self.overlap and self.options['dp_one_graph'] and not ws['graph'].get('dp_staged'))
+        pf = ws.get('prefetch_key') if (ws.get('prefetch') and not ws.get('packed')) else None
         key = ('train_dp' if dp else 'train', gc, tuple(self.trainable_ranges(ws['sid'])), self.grad_scale,
-               tuple(sorted(self.hyper.items())), bool(ws.get('packed')), one, id(sync) if (dp and one) else None)   # (captured collectives belong to THAT communicator)
+               tuple(sorted(self.hyper.items())), bool(ws.get('packed')), one, id(sync) if (dp and one) else None, pf)   # (captured collectives belong to THAT communicator)
+        ws['prefetched'] = False
         g = ws['graph'].get(key)
         if g is None:
             # warm-up launch outside capture (lazy module loading), then capture
             self.forward(ws, train=True, pack_first=lazy, global_counts=gc)
             self.backward(ws, train=True)
             torch.cuda.synchronize(self.device)
+            ws['_prefetch_now'] = pf is not None         # (the warm-up passes above left the batch alone: only the CAPTURED forward prefetches)
+            try:
+                g = self._capture_any(ws, sync, gc, dp, one, lazy, use_graph)
+            finally:
+                ws['_prefetch_now'] = False
+            if g is None:
+                return self._train_step(ws, use_graph, sync)
+            ws['graph'][key] = g
+        # (a replay does not run forward(): an assessment in between may have left the flag off)
+        ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
+        for hx, wx in zip(self.spec.aux_extra, ws['auxx']):
+            wx['use'] = hx.get('scale', 1.0) != 0.0
+        ws['prefetched'] = pf is not None
+        if dp and not one:
+            self._replay_staged(ws, g, sync, lazy)
+            return
+        if g[1] and self._img_early != 'all' and self._img_early != g[1]:
+            self.pack('p')           # the graph assumes that the images of ITS early-updated ranges are current
+        g[0].replay()
+        self._packed = None          # the bottom layer's images are those of the weights BEFORE this step's update
+        self._img_early = g[1] if g[1] else None
+
+    def _capture_any(self, ws, sync, gc, dp, one, lazy, use_graph):
+        """The captured form of the step for this process layout (None: every rank falls back to the staged schedule -- try again)."""
+        if True:
+            g = None
             if one and dp:
                 # data parallel: the single graph with the collectives as nodes; should the runtime refuse to record a
                 # collective on ANY rank, every rank falls back to one graph per stage with the collectives issued between them
@@ -1276,26 +1351,13 @@ class Seq2SeqEngine(PackingMixin, DecodingMixin):
                 if refused:
                     print('ecog2txt_amd: the data-parallel step could not be captured as one graph on %d rank(s)%s; every rank uses '
                           'one graph per backward stage' % (refused, ' (here: %s)' % why if why else ''))
-                    g = None
                     ws['graph']['dp_staged'] = True
-                    return self._train_step(ws, use_graph, sync)
+                    return None
             elif dp:
                 g = self._capture_staged(ws, lazy, gc)
             else:
                 g = self._capture_step(ws)
-            ws['graph'][key] = g
-        # (a replay does not run forward(): an assessment in between may have left the flag off)
-        ws['use_aux'] = bool(self.aux and self.spec.aux_scale != 0.0)
-        for hx, wx in zip(self.spec.aux_extra, ws['auxx']):
-            wx['use'] = hx.get('scale', 1.0) != 0.0
-        if dp and not one:
-            self._replay_staged(ws, g, sync, lazy)
-            return
-        if g[1] and self._img_early != 'all' and self._img_early != g[1]:
-            self.pack('p')           # the graph assumes that the images of ITS early-updated ranges are current
-        g[0].replay()
-        self._packed = None          # the bottom layer's images are those of the weights BEFORE this step's update
-        self._img_early = g[1] if g[1] else None
+            return g
 
     @staticmethod
     def _exchange(sync, ranges):

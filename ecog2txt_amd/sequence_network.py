@@ -228,6 +228,18 @@ class SequenceNetwork:
                 data['dev']['Ax'] = [torch.from_numpy(a).to(eng.device) for a in data.get('Ax', [])]
         return data['dev']
 
+    def _prefetch_sources(self, eng, ws, data):
+        """Hand the engine the resident arrays of this partition as the sources of its in-graph batch assembly (False: the
+        partition is not resident, or the engine does not prefetch)."""
+        dev = self._resident(eng, data)
+        if dev is None:
+            eng.set_prefetch(ws, None)
+            return False
+        pairs = [(dev['Y'], ws['Y']), (dev['X'], ws['X'])]
+        if 'A' in dev and eng.aux is not None:
+            pairs.append((dev['A'], ws['auxT']))
+        return eng.set_prefetch(ws, pairs)
+
     def _pack_partition(self, eng, sid, data):
         """bf16-staged inputs of a training partition (input_staging), made once per fit from the resident fp32 array; None
         where the fp32 form stays (small batches, a conv stack, a partition too large to keep resident)."""
@@ -262,6 +274,7 @@ class SequenceNetwork:
         B = ws['B']
         dev = self._resident(eng, data)
         ws['packed'] = False
+        ws['have'] = None                    # (whatever batch a captured step prefetched into this workspace is gone)
         if dev is not None:
             if idx_dev is None:
                 full = np.full(B, -1, np.int32)
@@ -361,15 +374,27 @@ class SequenceNetwork:
                     cnt[k] = [d['tok'][g].sum(), d['val'][g].sum()] + [v[g].sum() for v in d.get('valx', [])]
                 plans.append((s.subnet_id, d, idx, torch.from_numpy(idx).to(eng.device), cnt, self._pack_partition(eng, s.subnet_id, d)))
             ws = None
+            self._epoch_serial = getattr(self, '_epoch_serial', 0) + 1        # (names an epoch's plan: see `have` below)
             for k in range(max((len(p[2]) for p in plans), default=0)):      # round-robin over subjects ('parallel' learning)
                 for sid, d, idx, idx_dev, cnt, pk in plans:
                     if k >= len(idx):
                         continue
                     ws = eng.workspace(sid, B, d['T'], d['L'])
-                    self._load_batch(eng, ws, d, idx[k], idx_dev[k], packed=pk)
+                    # Round 6: with the partition resident in HBM the captured step assembles the NEXT batch itself, on a side
+                    # branch under its encoder (Seq2SeqEngine.set_prefetch: 42 us per cfg2 step between two replays otherwise).
+                    # `have` names the batch the workspace holds: the fit gathers only when that is not the one this step wants
+                    # (first step of an epoch, an assessment in between, an eager fallback step).
+                    pf = pk is None and self._prefetch_sources(eng, ws, d)
+                    want = (self._epoch_serial, sid, k)
+                    if not (pf and ws.get('have') == want):
+                        self._load_batch(eng, ws, d, idx[k], idx_dev[k], packed=pk)
+                    if pf:
+                        nk = min(k + 1, len(idx) - 1)
+                        ws['next_idx'].copy_(idx_dev[nk])
                     if sync is not None:
                         eng.set_global_counts(ws, int(cnt[k, 0]), int(cnt[k, 1]), [int(v) for v in cnt[k, 2:]])
                     eng.train_step(ws, sync=sync)
+                    ws['have'] = (self._epoch_serial, sid, nk) if (pf and ws.get('prefetched')) else None
             if ws is not None:
                 lo = eng.losses(ws)                                  # (also raises if an in-kernel wait timed out this epoch)
                 if sync is not None:

@@ -27,7 +27,9 @@ SyntheticSpeechDataGenerator.min_seconds, SyntheticSpeechDataGenerator.max_secon
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 path = XF.make_experiment(tmp, subject_ids=(401,), epochs=epochs, interval=10 ** 6, grid=(16, 16), nwords=1803)
 ck = os.path.join(tmp, 'ck'); os.makedirs(ck)
-tr = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False, SN_kwargs={'N_cases': 256, 'max_hyp_length': 10},
+# BENCH_FIT_OPTIONS="k=v,k=v": engine options for an A/B (e.g. prefetch_batches=False)
+eopts = dict(kv.split('=', 1) for kv in os.environ.get('BENCH_FIT_OPTIONS', '').split(',') if kv)
+tr = MultiSubjectTrainer(path, [401], checkpoint_dir=ck, VERBOSE=False, SN_kwargs={'N_cases': 256, 'max_hyp_length': 10, 'engine_options': eopts},
                          DG_kwargs={'max_samples': 400})
 t0 = time.perf_counter()
 for s in tr.ecog_subjects:
@@ -71,6 +73,23 @@ def timed_step(*a, **k):
     n_calls[0] += 1
     return orig_step(*a, **k)
 eng.train_step = timed_step
+# ceiling probes (wrong training, timing only): BENCH_FIT_HACK=nogather -- the batch assembly skipped after the first epoch;
+# noloss -- the per-epoch loss read-back (a device -> host sync) answered from a cached value; both
+hack = os.environ.get('BENCH_FIT_HACK', '')
+if 'nogather' in hack or hack == 'both':
+    orig_load, n_load = net._load_batch, [0]
+    def load_once(*a, **k):
+        n_load[0] += 1
+        if n_load[0] <= 8:
+            return orig_load(*a, **k)
+    net._load_batch = load_once
+if 'noloss' in hack or hack == 'both':
+    orig_losses, cached = eng.losses, [None]
+    def losses_cached(ws):
+        if cached[0] is None:
+            cached[0] = orig_losses(ws)
+        return cached[0]
+    eng.losses = losses_cached
 orig_save, t_save = net._save, [0.0]
 def timed_save(*a, **k):
     torch.cuda.synchronize(); t = time.perf_counter(); r = orig_save(*a, **k); t_save[0] += time.perf_counter() - t

@@ -159,6 +159,39 @@ def test_fit_with_bf16_staged_inputs_equals_the_fp32_staged_fit(small):
             assert np.array_equal(z0[k], z1[k]), k
 
 
+def test_fit_with_in_graph_batch_prefetch_equals_the_fit_that_gathers_between_steps(small):
+    """Round 6 (engine option prefetch_batches, Seq2SeqEngine.set_prefetch): with the partition resident in HBM the captured step
+    gathers the NEXT batch into its own input buffers on a side branch under the encoder; the fit gathers itself only at the first
+    step of an epoch and behind an assessment.  Several steps per epoch (N_cases 16 on 48 training utterances), two participants
+    in turn, assessments every other epoch: the fit ends with the same weights, losses and hypotheses as the one that gathers
+    between steps -- the same batches reached the same steps."""
+    from ecog2txt_amd.trainers import MultiSubjectTrainer
+    out = {}
+    for mode in (True, False):
+        path = make_experiment(small / str(mode), subject_ids=(400, 401), epochs=6, interval=2)
+        ck = str(small / str(mode) / 'ck'); os.makedirs(ck)
+        tr = MultiSubjectTrainer(path, [400, 401], checkpoint_dir=ck, VERBOSE=False,
+                                 SN_kwargs={'N_cases': 16, 'learning_rate': 3e-3, 'FF_dropout': 0.1, 'RNN_dropout': 0.1, 'EMA_decay': 0.9,
+                                            'engine_options': {'prefetch_batches': mode}},
+                                 DG_kwargs={'max_samples': 420})
+        for s in tr.ecog_subjects:
+            s.write_tf_records_maybe()
+        a = tr.parallel_transfer_learn()
+        eng = tr.net._engine
+        used = [bool(w.get('prefetch')) for k, w in eng._ws.items() if isinstance(k, tuple) and len(k) == 4 and k[0] in (400, 401) and w.get('graph')]
+        assert used and all(u == mode for u in used), (mode, used)
+        z = np.load(os.path.join(ck, 'model.ckpt-6.npz'))
+        out[mode] = (a, {k: z[k] for k in z.files})
+    (a0, z0), (a1, z1) = out[True], out[False]
+    assert [l['decoder'] for l in a0['training'].losses] == [l['decoder'] for l in a1['training'].losses]
+    assert a0['validation'].hypotheses == a1['validation'].hypotheses
+    for k in z0:
+        if 'decoder_embedding' in k or k.startswith('__'):   # (scatter-add of fp32 atomics: any order; '__adam_*' = whole-store arrays)
+            np.testing.assert_allclose(z0[k], z1[k], atol=1e-5)
+        else:
+            assert np.array_equal(z0[k], z1[k]), k
+
+
 def test_sequential_transfer_and_resume(small):
     from ecog2txt_amd.trainers import MultiSubjectTrainer
     path = make_experiment(small, subject_ids=(400, 401), epochs=2, interval=1)
