@@ -443,8 +443,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // of in front of them.  Same arithmetic, same bits.  Phase stamps (profiles/r06_rec_sidework_probe.txt): the mask does hide under the
 // loads (state landed 0.72 vs 0.68 us, no retries) and the side phase shrinks 0.6 -> 0.4 us, but the pending store in front of the
 // MFMAs lengthens that phase 0.56 -> 0.80: 2.44 vs 2.36 us from step top to step bottom, 2.81 vs 2.70 us per step by the clock, the
-// cfg2 train step 1.671 vs 1.562 ms.  (What the side work in front of the loads does buy: with NOTHING between the exchange store and
-// the loads the first attempt always finds stale stamps and pays a second round trip -- 2.94 us per step.)
+// cfg2 train step 1.671 vs 1.562 ms.  Second form (the pending store behind the exchange store instead; E2T_REC_VARIANT=16 selects the
+// first): state landed 0.72, MFMA phase still 0.68 (the carried state costs register moves around the MFMAs), gates 0.54, side 0.5:
+// 2.44 vs 2.36 us, the step 1.579 vs 1.576 ms over three same-box pairs -- no gain either.  (What the side work in front of the loads
+// does buy: with NOTHING between the exchange store and the loads the first attempt always finds stale stamps and pays a second
+// round trip -- 2.94 us per step.)
 // PIPE (round 6 experiment, diagnostics build only -- MEASURED AND REJECTED): the state fragments consumed AS THEY LAND -- VMEM returns
 // in issue order, so `s_waitcnt vmcnt(KB-1-kb)` retires exactly fragment kb; its stamps go into running AND / OR words, its four MFMAs
 // are issued at once (behind a sched_barrier: hipcc otherwise sinks all 52 behind the last wait) -- and the freshness check is made
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
             }
             PSTAMP(2);
             if (s + 2 < S) gx_load(s + 2);
-            if (DEFER && p.Ydrop && own) ydrop_put(dscp);
+            if (DEFER && p.Ydrop && own && (E2T_DBGV(p) & 16)) ydrop_put(dscp);      // (first form of the experiment: the pending store in front of the MFMAs)
 
             if (!(PIPE && s > 0)) {
     #pragma unroll
@@ -708,6 +711,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_persist(LstmPersistArgs pa
         PSTAMP(5);
         // ---- off the critical path: saves for BPTT, dropped copy for the next layer, Gx of the next step ----
         const int dv = E2T_DBGV(p);      // (0 in the product build: folds away)
+        // DEFER, second form: the previous step's dropped copy (its mask was computed under this step's state loads) leaves HERE, behind
+        // the exchange store, where a store costs the critical chain nothing -- in front of the MFMAs it lengthened that phase by 0.24 us
+        if (DEFER && p.Ydrop && own && !(dv & 16)) ydrop_put(dscp);
         if (own && !(dv & 8)) {            // row-major copy for the next layer and BPTT (time block t+1); padded positions emit zeros
             const size_t blk = active ? (size_t)(t + 1) : (size_t)(s + 1);
             *(unsigned long long*)(p.Yext + (blk * B + b) * p.ldy + dir * p.H8 + u0) = hb;
